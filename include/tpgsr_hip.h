@@ -1,0 +1,240 @@
+/*
+ * tpgsr_hip.h -- C ABI of libtpgsr_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the TPGSR-TSRN
+ * training / inference hot path.
+ *
+ * The reference (mjq11302010044/TPGSR) has NO native layer: its operator API is Python nn.Modules
+ *  whose forward()s bottom out in stock ATen/cuDNN kernels.  Every entry point
+ * below replaces one of those implicit kernel calls; the reference call site each one stands in for is
+ * cited as file:line (relative to the reference tree).  The Python host side (tpgsr_amd/) mirrors the
+ * reference's module names / state_dict layout and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - all tensors are fp32, device pointers, owned by the caller (kernels never allocate);
+ *   - activations are NHWC ("pixel-major"): element (n,h,w,c) of a logical [N][H][W][C] tensor lives at
+ *     ((n*H+h)*W+w)*ld + coff + c   (ld = floats per pixel, coff = channel offset; default ld=C, coff=0);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no internal sync, safe to
+ *     capture into a hipGraph;
+ *   - return 0 on success, a negative code on a rejected argument / failed launch; the message is
+ *     available from tpgsr_last_error().
+ */
+#ifndef TPGSR_HIP_H
+#define TPGSR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPGSR_ACT_NONE 0
+#define TPGSR_ACT_RELU 1
+#define TPGSR_ACT_MISH 2   /* x * tanh(softplus(x)), model/tsrn.py:480-488 */
+#define TPGSR_ACT_TANH 3
+#define TPGSR_ACT_PRELU 4
+
+const char* tpgsr_last_error(void);
+int tpgsr_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), stride 1.
+ * Replaces every nn.Conv2d / nn.Linear / 1x1 conv on the path:
+ *   model/tsrn.py:28 (9x9 4->64), :375,:379 (3x3 64->64), :467 (3x3 64->256 + PixelShuffle),
+ *   :495 (GruBlock 1x1), :40/:159 (tail 9x9, run as a 9x1 conv with the 9 kw taps folded into N),
+ *   the GRU/LSTM input projections (nn.GRU tsrn.py:496, nn.LSTM crnn/crnn.py:10),
+ *   model/stn_head.py:15,48-52 and model/crnn/crnn.py:45-46,12.
+ * out[m][n] = epilogue( sum_k A[m][k] * wt[k][n] ),  m = output pixel, k = (tap, ci), n = co.
+ * A-operand prologue, fused into the tile loader (never materialised in HBM):
+ *     a = act_in( in * in_scale[c] + in_shift[c] ) + in2        (zero padding applied afterwards)
+ * which is how train-mode BatchNorm-apply + mish/ReLU and the residual adds of
+ * model/tsrn.py:388-394,211 ride on the consumer conv.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* in;        /* logical [N][H][W][Cin] */
+  const float* in2;       /* optional, same geometry as `in` (ld = in2_ld, coff = 0) */
+  const float* in_scale;  /* optional [Cin] */
+  const float* in_shift;  /* optional [Cin] */
+  const float* wt;        /* packed [K = KH*KW*Cin][Cout], k = (kh*KW+kw)*Cin + ci */
+  const float* bias;      /* optional [Cout] */
+  float* out;             /* logical [N][OH][OW][Cout] */
+  float* bn_partial;      /* optional [ceil(M/64)][2][Cout]: per-row-block sum / sum of squares of (out-bias) */
+  int N, H, W, Cin;
+  int in_ld, in_coff, in2_ld;
+  int in_act;             /* TPGSR_ACT_NONE / RELU / MISH applied in the loader */
+  int in_ps;              /* 1: `in` is stored pixel-shuffled: [N][2H][2W][Cin/4]  (un-PixelShuffle gather) */
+  int Cout, KH, KW, pad_h, pad_w, OH, OW;
+  int out_ld, out_coff;
+  int out_act;            /* NONE / RELU / TANH */
+  int out_ps;             /* 1: store pixel-shuffled (nn.PixelShuffle(2), model/tsrn.py:469): [N][2OH][2OW][Cout/4] */
+} tpgsr_conv_args;
+
+int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);
+
+/* Weight-gradient GEMM:  part[z][k][n] = sum_{m in split z} A[m][k] * dy[m][n]   (A through the same
+ * loader/prologue as tpgsr_conv_fwd), plus optional bias-gradient partials dbpart[z][n] = sum_m dy[m][n].
+ * Replaces the cuDNN wgrad kernels autograd launches for every conv/linear above.
+ * tpgsr_wgrad_splits() returns the number of splits Z the kernel will use for (M, K, Cout). */
+typedef struct {
+  tpgsr_conv_args c;      /* geometry + A-operand description (wt/bias/out/bn_partial/out_* ignored) */
+  const float* dy;        /* logical [N][OH][OW][Cout] */
+  int dy_ld, dy_coff;
+  int dy_ps;              /* 1: dy stored pixel-shuffled [N][2OH][2OW][Cout/4] */
+  float* part;            /* [Z][K][Cout] */
+  float* dbpart;          /* optional [Z][Cout] */
+} tpgsr_wgrad_args;
+
+int tpgsr_wgrad_splits(int M, int K, int Cout);
+int tpgsr_conv_wgrad(const tpgsr_wgrad_args* a, void* stream);
+
+/* Deterministic second stage: dw (+)= sum_z part[z], written in the PyTorch parameter layout
+ *   layout 0: conv / linear weight [Cout][Cin][KH][KW]
+ *   layout 1: ConvTranspose2d weight [Cin][Cout][KH][KW] run as its equivalent conv (flipped taps)
+ *   layout 2: the folded tail conv (KH = KS, KW = 1, Cout = KS*Co) back to [Co][Cin][KS][KS]
+ * and db (+)= sum_z dbpart[z].  accumulate != 0 adds to the existing gradient (autograd semantics). */
+int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
+                       int layout, float* dw, float* db, int accumulate, float gscale /* multiplies dw only */,
+                       void* stream);
+
+/* Pack a PyTorch conv weight [Cout][Cin][KH][KW] into the forward operand wt_f[(kh*KW+kw)*Cin+ci][co] and the
+ * data-gradient operand wt_d[((KH-1-kh)*KW+(KW-1-kw))*Cout+co][ci] (dgrad == tpgsr_conv_fwd over dy with wt_d
+ * and pad' = K-1-pad).  Either output may be NULL.  transposed != 0: source is a ConvTranspose2d weight
+ * [Cin][Cout][KH][KW].  wscale multiplies the packed copies (STN fc2 sees 0.1*feat, model/stn_head.py:100). */
+int tpgsr_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int transposed, float wscale,
+                           float* wt_f, float* wt_d, void* stream);
+/* Tail conv 9x9 C->Co (Co = 3 or 4) folded to a 9x1 conv with N' = 9*Co columns (n' = kw*Co+co):
+ * wt_f[(kh*C+ci)][kw*Co+co] = w[co][ci][kh][kw];  wt_d = its dgrad packing over the 9x1 conv. */
+int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, float* wt_d, void* stream);
+
+/* All operand packing of a model in ONE launch: a device-resident table of descriptors.
+ *   kind 0: conv/linear weight [Cout][Cin][KH][KW] -> dst_f[k*f_ld + f_coff + co] and/or dst_d (dgrad operand)
+ *   kind 1: tail conv [Co][C][KS][KS] folded (Cout = Co, KH = KW = KS)     kind 2: plain copy of numel floats
+ *   kind 3: ConvTranspose2d weight [Cin][Cout][KH][KW] as its equivalent conv
+ * blk0 = prefix sum of ceil(numel/256) over the preceding descriptors; total_blocks = the full sum. */
+typedef struct {
+  const float* src;
+  float* dst_f;
+  float* dst_d;
+  int Cout, Cin, KH, KW;
+  int kind, f_ld, f_coff;
+  float wscale;
+  int numel, blk0;
+} tpgsr_pack_desc;
+int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+int tpgsr_copy(const float* src, float* dst, long long n, void* stream);   /* async D2D copy (graph memcpy node) */
+int tpgsr_zero(float* dst, long long n, void* stream);                     /* async memset */
+
+/* ------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm pieces (nn.BatchNorm2d model/tsrn.py:376,380,153; stn_head.py:19; crnn.py:48).
+ * ---------------------------------------------------------------------------------------------- */
+/* From the conv epilogue partials: batch mean / biased var -> scale = gamma*rstd, shift = beta - mean*scale,
+ * save_mean / save_rstd, and the running-stat update (momentum 0.1, unbiased var). bias (optional) is the conv
+ * bias the partials were shifted by.  eval != 0: scale/shift from the running stats, nothing updated. */
+int tpgsr_bn_finalize(const float* partial, int nblk, int C, long long count, const float* conv_bias,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, int eval, float* scale, float* shift, float* save_mean,
+                      float* save_rstd, void* stream);
+/* Per-channel partial stats of an arbitrary [M][C] tensor (used where no conv epilogue produced them). */
+int tpgsr_bn_stats(const float* x, long long M, int C, int ld, float* partial, int nblk, void* stream);
+/* BN(+activation) backward, pass 1: dz = da * act'(scale*y+shift); partial sums of dz and dz*xhat. */
+int tpgsr_bn_bwd_reduce(const float* da, const float* da2, const float* y, long long M, int C, const float* scale,
+                        const float* shift, const float* save_mean, const float* save_rstd, int act,
+                        float* partial, int nblk, void* stream);
+/* finalize: dgamma, dbeta (accumulate flag) and the per-channel coefficients of pass 2 */
+int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long long count, const float* gamma,
+                          const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                          int accumulate, float* coef /* [3][C] */, void* stream);
+/* pass 2: dy = coef0*dz + coef1*y + coef2 (dz recomputed from da(+da2), y) */
+int tpgsr_bn_bwd_apply(const float* da, const float* da2, const float* y, long long M, int C, const float* scale,
+                       const float* shift, int act, const float* coef, float* dy, void* stream);
+/* Materialise act(scale*x+shift) (+ optional 2x2 / 1x2 max-pool, STN head model/stn_head.py:34-45) */
+int tpgsr_affine_act_pool(const float* x, int N, int H, int W, int C, const float* scale, const float* shift,
+                          int act, int pool_h, int pool_w, float* out, void* stream);
+/* backward of the above: routes dout to the arg-max position and multiplies by act' and scale -> d(pre-affine)=dz;
+ * writes dz (the BN-backward passes then run with act = NONE on dz). */
+int tpgsr_affine_act_pool_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale,
+                              const float* shift, int act, int pool_h, int pool_w, float* dz, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise
+ * ---------------------------------------------------------------------------------------------- */
+/* PReLU with one shared slope (model/tsrn.py:29-31) */
+int tpgsr_prelu_fwd(const float* x, const float* alpha, long long n, float* y, void* stream);
+int tpgsr_prelu_bwd(const float* x, const float* alpha, const float* dy, const float* dy2, long long n, float* dx,
+                    float* dalpha_partial, int nblk, void* stream);
+/* out = a + b (b optional scale) ; out = a*mish'(x) etc. */
+int tpgsr_add(const float* a, const float* b, long long n, float* out, void* stream);
+int tpgsr_act_bwd(const float* x, const float* dy, long long n, int act, float* dx, void* stream);
+int tpgsr_nchw_to_nhwc(const float* in, int N, int C, int H, int W, float* out, void* stream);
+int tpgsr_nhwc_to_nchw(const float* in, int N, int C, int H, int W, float* out, void* stream);
+/* sum_z part[z][n] -> out[n] (+=) ; used for small parameter gradients (PReLU slope, GRU b_hh ...) */
+int tpgsr_reduce_partials(const float* part, int Z, int n, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bidirectional GRU (hidden 32) over one spatial axis of an NHWC map -- GruBlock, model/tsrn.py:491-508.
+ * gi [P][192] = input projections (+b_ih) for both directions, column = dir*96 + gate*32 + j, gate order
+ * (r,z,n); h_out [P][64], column = dir*32 + j.  axis 0: sequences run along W (one per (n,row));
+ * axis 1: along H (one per (n,col)) -- the `.transpose(-1,-2)` of model/tsrn.py:391 without a copy.
+ * ---------------------------------------------------------------------------------------------- */
+int tpgsr_bigru_fwd(const float* gi, const float* w_hh /* [2][96][32] */, const float* b_hh /* [2][96] */,
+                    int N, int H, int W, int axis, float* h_out, void* stream);
+/* Backward through time.  Recomputes the gates from gi and h_out; dh = dh_out (+ dh_out2 if non-NULL).
+ * Writes dgi [P][192] = (dr, dz, dn) pre-activation gradients of the input side (must NOT alias gi) and
+ * dgh [P][192] = (dr, dz, dn*r) of the hidden side, from which dW_ih/db_ih/d(input) and dW_hh/db_hh follow
+ * as plain GEMMs / column sums (tpgsr_conv_wgrad against the input resp. the one-step-shifted states). */
+int tpgsr_bigru_bwd(const float* gi, const float* h_out, const float* dh_out, const float* dh_out2,
+                    const float* w_hh, const float* b_hh, int N, int H, int W, int axis, float* dgi, float* dgh,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * STN / TPS rectification -- model/tps_spatial_transformer.py:97-112, grid_sample :10-18
+ * ---------------------------------------------------------------------------------------------- */
+/* ctrl [N][NC][2] -> src [N][HW][2] (pre-clamp source coordinates, optional output) and the sampling grid
+ * [N][HW][2] = 2*clamp(src,0,1)-1.  inv_kernel [NC+3][NC+3], coord_repr [HW][NC+3] are the registered
+ * buffers `tps.inverse_kernel` / `tps.target_coordinate_repr`. */
+int tpgsr_tps_grid_fwd(const float* ctrl, const float* inv_kernel, const float* coord_repr, int N, int HW,
+                       int NC, float* grid, float* src, void* stream);
+/* dctrl [N][NC][2] from dgrid; src (saved by the forward) decides the clamp mask. */
+int tpgsr_tps_grid_bwd(const float* dgrid, const float* src, const float* inv_kernel, const float* coord_repr,
+                       int N, int HW, int NC, float* dctrl, void* stream);
+/* bilinear, zeros padding; NHWC in/out with C channels (C = 3 or 4). */
+int tpgsr_grid_sample_fwd(const float* in, const float* grid, int N, int H, int W, int C, int OH, int OW,
+                          int align_corners, float* out, void* stream);
+int tpgsr_grid_sample_bwd(const float* in, const float* grid, const float* dout, int N, int H, int W, int C,
+                          int OH, int OW, int align_corners, float* din /* optional; zero-filled by callee */,
+                          float* dgrid /* optional */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tail: out = tanh(bias + sum_kw P[h][w+kw-4][kw][co])  (model/tsrn.py:159,213), NCHW output
+ * ---------------------------------------------------------------------------------------------- */
+int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,
+                             float* out_nchw, void* stream);
+/* dP[h][x][kw][co] = dpre[h][x-kw+4][co], dpre = dout*(1-out^2); also bias-grad partials */
+int tpgsr_tail_bwd(const float* out_nchw, const float* dout_nchw, int N, int H, int W, int Co, int KS,
+                   float* dP, float* dbias_partial /* optional [nblk][Co] */, int nblk, void* stream);
+int tpgsr_tail_bwd_blocks(int N, int H, int W, int Co, int KS); /* the nblk tpgsr_tail_bwd expects */
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses -- loss/image_loss.py:10-51, loss/semantic_loss.py:10-39; NCHW tensors like the reference
+ * ---------------------------------------------------------------------------------------------- */
+/* loss = w0*MSE(all C) + w1*L1(gradmag(out[:, :3]), gradmag(tgt[:, :3])); writes partial sums [nblk][2] */
+int tpgsr_image_loss_fwd(const float* out, const float* tgt, int N, int C, int H, int W, int gradient,
+                         float* partial, int nblk, void* stream);
+int tpgsr_image_loss_finalize(const float* partial, int nblk, long long n_mse, long long n_gp, float w0, float w1,
+                              float* loss, void* stream);
+int tpgsr_image_loss_bwd(const float* out, const float* tgt, const float* dloss, int N, int C, int H, int W,
+                         int gradient, float w0, float w1, float* dout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser -- clip_grad_norm_(0.25) + Adam(lr 1e-3, betas (0.5,0.999)) over flat arenas
+ * (interfaces/super_resolution.py:419-424, interfaces/base.py:449-450)
+ * ---------------------------------------------------------------------------------------------- */
+int tpgsr_sumsq_partial(const float* x, long long n, float* partial, int nblk, void* stream);
+/* coef[0] = min(1, max_norm / (sqrt(sum partial) + 1e-6)); norm_out[0] = sqrt(sum) */
+int tpgsr_clip_coef(const float* partial, int nblk, float max_norm, float* coef, float* norm_out, void* stream);
+/* g' = g * (*gscale if gscale else 1);  Adam update with bias correction from the device step counter */
+int tpgsr_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* gscale, float lr,
+                    float beta1, float beta2, float eps, const int* step_dev, void* stream);
+int tpgsr_step_inc(int* step_dev, void* stream);
+int tpgsr_scale_(float* x, long long n, const float* coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPGSR_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libtpgsr_hip.so (the C ABI declared in include/tpgsr_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel call fails, the product path
+raises.  The CPU oracle under oracle/ is test infrastructure and is never imported from here."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtpgsr_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_MISH, ACT_TANH, ACT_PRELU = 0, 1, 2, 3, 4
+_ACT = {None: 0, "none": 0, "relu": 1, "mish": 2, "tanh": 3}
+
+vp = C.c_void_p
+ci = C.c_int
+ll = C.c_longlong
+cf = C.c_float
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("in_", vp), ("in2", vp), ("in_scale", vp), ("in_shift", vp), ("wt", vp), ("bias", vp), ("out", vp),
+                ("bn_partial", vp),
+                ("N", ci), ("H", ci), ("W", ci), ("Cin", ci),
+                ("in_ld", ci), ("in_coff", ci), ("in2_ld", ci), ("in_act", ci), ("in_ps", ci),
+                ("Cout", ci), ("KH", ci), ("KW", ci), ("pad_h", ci), ("pad_w", ci), ("OH", ci), ("OW", ci),
+                ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("c", ConvArgs), ("dy", vp), ("dy_ld", ci), ("dy_coff", ci), ("dy_ps", ci), ("part", vp), ("dbpart", vp)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst_f", vp), ("dst_d", vp), ("Cout", ci), ("Cin", ci), ("KH", ci), ("KW", ci),
+                ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci)]
+
+
+_SIGS = {
+    "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
+    "tpgsr_copy": (ci, [vp, vp, ll, vp]),
+    "tpgsr_zero": (ci, [vp, ll, vp]),
+    "tpgsr_version": (ci, []),
+    "tpgsr_conv_fwd": (ci, [C.POINTER(ConvArgs), vp]),
+    "tpgsr_wgrad_splits": (ci, [ci, ci, ci]),
+    "tpgsr_conv_wgrad": (ci, [C.POINTER(WgradArgs), vp]),
+    "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
+    "tpgsr_pack_conv_weight": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp]),
+    "tpgsr_pack_tail_weight": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_bn_finalize": (ci, [vp, ci, ci, ll, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp]),
+    "tpgsr_bn_stats": (ci, [vp, ll, ci, ci, vp, ci, vp]),
+    "tpgsr_bn_bwd_reduce": (ci, [vp, vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, ci, vp]),
+    "tpgsr_bn_bwd_finalize": (ci, [vp, ci, ci, ll, vp, vp, vp, vp, vp, ci, vp, vp]),
+    "tpgsr_bn_bwd_apply": (ci, [vp, vp, vp, ll, ci, vp, vp, ci, vp, vp, vp]),
+    "tpgsr_affine_act_pool": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp]),
+    "tpgsr_affine_act_pool_bwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp]),
+    "tpgsr_prelu_fwd": (ci, [vp, vp, ll, vp, vp]),
+    "tpgsr_prelu_bwd": (ci, [vp, vp, vp, vp, ll, vp, vp, ci, vp]),
+    "tpgsr_add": (ci, [vp, vp, ll, vp, vp]),
+    "tpgsr_act_bwd": (ci, [vp, vp, ll, ci, vp, vp]),
+    "tpgsr_nchw_to_nhwc": (ci, [vp, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_nhwc_to_nchw": (ci, [vp, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_reduce_partials": (ci, [vp, ci, ci, vp, ci, vp]),
+    "tpgsr_bigru_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_bigru_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_tps_grid_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_tps_grid_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
+    "tpgsr_grid_sample_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_grid_sample_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_tail_shiftsum_tanh": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_tail_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]),
+    "tpgsr_tail_bwd_blocks": (ci, [ci, ci, ci, ci, ci]),
+    "tpgsr_image_loss_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "tpgsr_image_loss_finalize": (ci, [vp, ci, ll, ll, cf, cf, vp, vp]),
+    "tpgsr_image_loss_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, vp]),
+    "tpgsr_sumsq_partial": (ci, [vp, ll, vp, ci, vp]),
+    "tpgsr_clip_coef": (ci, [vp, ci, cf, vp, vp, vp]),
+    "tpgsr_adam_step": (ci, [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]),
+    "tpgsr_step_inc": (ci, [vp, vp]),
+    "tpgsr_scale_": (ci, [vp, ll, vp, vp]),
+}
+
+EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["tpgsr_last_error"])
+
+_lib = None
+
+
+class TpgsrKernelError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (building is __graft_entry__.build()'s / tpgsr_amd.build's job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TpgsrKernelError(
+            f"{LIB_PATH} is missing: build it with `python -m tpgsr_amd.build` (hipcc --offload-arch=gfx950). "
+            "tpgsr_amd has no CPU / PyTorch fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    lib.tpgsr_last_error.restype = C.c_char_p
+    lib.tpgsr_last_error.argtypes = []
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tpgsr_last_error().decode(errors="replace")
+        raise TpgsrKernelError(f"{what or 'tpgsr kernel'} failed (rc={rc}): {msg}")
+
+
+def act_code(name):
+    return _ACT[name] if not isinstance(name, int) else name

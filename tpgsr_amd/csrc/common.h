@@ -1,0 +1,75 @@
+// Shared device/host helpers for libtpgsr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/tpgsr_hip.h"
+
+#define TPGSR_ERR_ARG (-1)
+#define TPGSR_ERR_LAUNCH (-2)
+
+void tpgsr_set_error(const char* fmt, ...);
+
+#define TPGSR_CHECK_ARG(cond, ...)                 \
+  do {                                             \
+    if (!(cond)) {                                 \
+      tpgsr_set_error(__VA_ARGS__);                \
+      return TPGSR_ERR_ARG;                        \
+    }                                              \
+  } while (0)
+
+#define TPGSR_LAUNCH_CHECK(name)                                                   \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      tpgsr_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return TPGSR_ERR_LAUNCH;                                                     \
+    }                                                                              \
+    return 0;                                                                      \
+  } while (0)
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- activations (fp32, matching ATen's formulas) -------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
+// d/dx [x * tanh(sp(x))] = tanh(sp) + x * (1 - tanh(sp)^2) * sigmoid(x)
+__device__ __forceinline__ float mish_grad_f(float x) {
+  float sp = softplus_f(x);
+  float t = tanhf(sp);
+  float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+  return t + x * (1.f - t * t) * sg;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == TPGSR_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == TPGSR_ACT_MISH) return mish_f(x);
+  if (act == TPGSR_ACT_TANH) return tanhf(x);
+  return x;
+}
+// derivative w.r.t. the pre-activation value x
+__device__ __forceinline__ float act_grad(float x, int act) {
+  if (act == TPGSR_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == TPGSR_ACT_MISH) return mish_grad_f(x);
+  if (act == TPGSR_ACT_TANH) {
+    float t = tanhf(x);
+    return 1.f - t * t;
+  }
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

@@ -1,0 +1,613 @@
+// Implicit-GEMM convolution / linear layers on the gfx950 fp32 matrix cores.
+//
+//   fwd / dgrad :  out[m][n]   = sum_k A[m][k] * wt[k][n]          (tile 64 pixels x 64 channels, 4 waves)
+//   wgrad       :  part[k][n]  = sum_m A[m][k] * dy[m][n]          (tile 64 k x 64 channels, split over m)
+//
+// A[m][k] is never materialised: it is gathered (im2col on the fly, zero padding, optional un-PixelShuffle)
+// from the NHWC activation by the tile loader, which also applies the producer's pending per-channel affine
+// (train-mode BatchNorm), activation (mish / ReLU) and residual add.  Both kernels stage A as As[k][m] and the
+// second operand row-major in LDS; v_mfma_f32_32x32x2_f32 fragments are fetched with conflict-free ds_read_b32
+// (lane l reads row k0 + (l>>5), column (l&31)).  fp32 in, fp32 accumulate: bit-for-bit an fmaf chain.
+#include "common.h"
+
+#define BM 64
+#define BN 64
+#define KC 32
+#define ALD (BM + 1)
+
+struct PixelPos {
+  int n, oh, ow;
+  bool valid;
+};
+
+__device__ __forceinline__ PixelPos decode_pixel(const tpgsr_conv_args& a, int m, int M) {
+  PixelPos p;
+  p.valid = m < M;
+  int mm = p.valid ? m : 0;
+  int ohw = a.OH * a.OW;
+  p.n = mm / ohw;
+  int r = mm - p.n * ohw;
+  p.oh = r / a.OW;
+  p.ow = r - p.oh * a.OW;
+  return p;
+}
+
+// one float of the A operand: logical input element (n, ih, iw, c) after the fused prologue
+__device__ __forceinline__ float load_a_scalar(const tpgsr_conv_args& a, const PixelPos& p, int k, int K) {
+  if (!p.valid || k >= K) return 0.f;
+  int tap = k / a.Cin;
+  int c = k - tap * a.Cin;
+  int kh = tap / a.KW, kw = tap - kh * a.KW;
+  int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
+  if ((unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) return 0.f;
+  float v;
+  size_t pix = (size_t)(p.n * a.H + ih) * a.W + iw;
+  if (!a.in_ps) {
+    v = a.in[pix * a.in_ld + a.in_coff + c];
+  } else {
+    int C4 = a.Cin >> 2, cs = c >> 2, i = (c >> 1) & 1, j = c & 1;
+    v = a.in[((size_t)(p.n * 2 * a.H + 2 * ih + i) * (2 * a.W) + 2 * iw + j) * C4 + cs];
+  }
+  if (a.in_scale) v = v * a.in_scale[c] + a.in_shift[c];
+  v = apply_act(v, a.in_act);
+  if (a.in2) v += a.in2[pix * a.in2_ld + c];
+  return v;
+}
+
+// four consecutive k (one (tap, 4-channel) quad) of the A operand; requires Cin % 4 == 0
+__device__ __forceinline__ float4 load_a_quad(const tpgsr_conv_args& a, const PixelPos& p, int tap, int c, int ntaps) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!p.valid || tap >= ntaps) return v;
+  int kh = tap / a.KW, kw = tap - kh * a.KW;
+  int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
+  if ((unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) return v;
+  size_t pix = (size_t)(p.n * a.H + ih) * a.W + iw;
+  if (!a.in_ps) {
+    v = *reinterpret_cast<const float4*>(a.in + pix * a.in_ld + a.in_coff + c);
+  } else {
+    int C4 = a.Cin >> 2, cs = c >> 2;
+    size_t W2 = 2 * (size_t)a.W;
+    const float* b = a.in + ((size_t)(p.n * 2 * a.H + 2 * ih) * W2 + 2 * iw) * C4 + cs;
+    v.x = b[0];
+    v.y = b[C4];
+    v.z = b[W2 * C4];
+    v.w = b[W2 * C4 + C4];
+  }
+  if (a.in_scale) {
+    float4 s = *reinterpret_cast<const float4*>(a.in_scale + c);
+    float4 t = *reinterpret_cast<const float4*>(a.in_shift + c);
+    v.x = v.x * s.x + t.x;
+    v.y = v.y * s.y + t.y;
+    v.z = v.z * s.z + t.z;
+    v.w = v.w * s.w + t.w;
+  }
+  if (a.in_act) {
+    v.x = apply_act(v.x, a.in_act);
+    v.y = apply_act(v.y, a.in_act);
+    v.z = apply_act(v.z, a.in_act);
+    v.w = apply_act(v.w, a.in_act);
+  }
+  if (a.in2) {
+    float4 r = *reinterpret_cast<const float4*>(a.in2 + pix * a.in2_ld + c);
+    v.x += r.x;
+    v.y += r.y;
+    v.z += r.z;
+    v.w += r.w;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float4 load_row4(const float* base, size_t row, int ld, int col, int ncols, bool rowvalid,
+                                            bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!rowvalid || col >= ncols) return v;
+  const float* p = base + row * (size_t)ld + col;
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  v.x = p[0];
+  if (col + 1 < ncols) v.y = p[1];
+  if (col + 2 < ncols) v.z = p[2];
+  if (col + 3 < ncols) v.w = p[3];
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ------------------------------------------------------------------------------------------------------
+template <bool VEC_A>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M, int K, int vecB) {
+  __shared__ float As[KC][ALD];
+  __shared__ float Bs[KC][BN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ntaps = a.KH * a.KW;
+  const int cin4 = a.Cin >> 2;
+  const int nchunks = (K + KC - 1) / KC;
+
+  // A staging: thread -> quad (tid&7) of the chunk, pixels (tid>>3) and (tid>>3)+32
+  const int aq = tid & 7;
+  const int am0 = tid >> 3;
+  PixelPos px0 = decode_pixel(a, m0 + am0, M);
+  PixelPos px1 = decode_pixel(a, m0 + am0 + 32, M);
+  // B staging: rows (tid>>4) and (tid>>4)+16, columns (tid&15)*4
+  const int bk0 = tid >> 4;
+  const int bc = (tid & 15) * 4;
+
+  float4 ra0, ra1, rb0, rb1;
+  auto load_chunk = [&](int ch) {
+    if (VEC_A) {
+      int kq = ch * (KC / 4) + aq;
+      int tap = kq / cin4;
+      int c = (kq - tap * cin4) * 4;
+      ra0 = load_a_quad(a, px0, tap, c, ntaps);
+      ra1 = load_a_quad(a, px1, tap, c, ntaps);
+    } else {
+      int k = ch * KC + aq * 4;
+      ra0 = make_float4(load_a_scalar(a, px0, k, K), load_a_scalar(a, px0, k + 1, K), load_a_scalar(a, px0, k + 2, K),
+                        load_a_scalar(a, px0, k + 3, K));
+      ra1 = make_float4(load_a_scalar(a, px1, k, K), load_a_scalar(a, px1, k + 1, K), load_a_scalar(a, px1, k + 2, K),
+                        load_a_scalar(a, px1, k + 3, K));
+    }
+    int k0 = ch * KC + bk0, k1 = k0 + 16;
+    rb0 = load_row4(a.wt, k0, a.Cout, n0 + bc, a.Cout, k0 < K, vecB);
+    rb1 = load_row4(a.wt, k1, a.Cout, n0 + bc, a.Cout, k1 < K, vecB);
+  };
+  auto store_chunk = [&]() {
+    As[aq * 4 + 0][am0] = ra0.x;
+    As[aq * 4 + 1][am0] = ra0.y;
+    As[aq * 4 + 2][am0] = ra0.z;
+    As[aq * 4 + 3][am0] = ra0.w;
+    As[aq * 4 + 0][am0 + 32] = ra1.x;
+    As[aq * 4 + 1][am0 + 32] = ra1.y;
+    As[aq * 4 + 2][am0 + 32] = ra1.z;
+    As[aq * 4 + 3][am0 + 32] = ra1.w;
+    *reinterpret_cast<float4*>(&Bs[bk0][bc]) = rb0;
+    *reinterpret_cast<float4*>(&Bs[bk0 + 16][bc]) = rb1;
+  };
+
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  const int arow = lane >> 5;
+  const int acol = wm * 32 + (lane & 31);
+  const int bcol = wn * 32 + (lane & 31);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) load_chunk(ch + 1);
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      float av = As[2 * kk + arow][acol];
+      float bv = Bs[2 * kk + arow][bcol];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+    if (ch + 1 < nchunks) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias, activation, (pixel-shuffled) store, BN partial statistics ----
+  const int n = n0 + bcol;
+  const bool nvalid = n < a.Cout;
+  const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+  float s = 0.f, ss = 0.f;
+  const int ohw = a.OH * a.OW;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int m = m0 + wm * 32 + row;
+    if (m < M && nvalid) {
+      float raw = acc[r];
+      s += raw;
+      ss += raw * raw;
+      float v = apply_act(raw + bias, a.out_act);
+      if (!a.out_ps) {
+        a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+      } else {
+        int nn = m / ohw;
+        int rem = m - nn * ohw;
+        int oh = rem / a.OW, ow = rem - oh * a.OW;
+        int cs = n >> 2, i = (n >> 1) & 1, j = n & 1;
+        a.out[((size_t)(nn * 2 * a.OH + 2 * oh + i) * (2 * a.OW) + 2 * ow + j) * (a.Cout >> 2) + cs] = v;
+      }
+    }
+  }
+  if (a.bn_partial) {
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    float* red = &As[0][0];  // all MFMA reads finished behind the loop's final barrier
+    if (lane < 32) {
+      red[(wm * 2 + 0) * BN + bcol] = s;
+      red[(wm * 2 + 1) * BN + bcol] = ss;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Cout) {
+      float* dst = a.bn_partial + (size_t)blockIdx.x * 2 * a.Cout;
+      dst[n0 + tid] = red[0 * BN + tid] + red[2 * BN + tid];
+      dst[a.Cout + n0 + tid] = red[1 * BN + tid] + red[3 * BN + tid];
+    }
+  }
+}
+
+static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
+  TPGSR_CHECK_ARG(a && a->in, "%s: null input", who);
+  TPGSR_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0,
+                  "%s: non-positive dimension", who);
+  TPGSR_CHECK_ARG(a->OH > 0 && a->OW > 0, "%s: non-positive output size", who);
+  TPGSR_CHECK_ARG(a->in_ld >= a->Cin + a->in_coff || a->in_ps, "%s: in_ld %d < Cin %d + coff %d", who, a->in_ld, a->Cin,
+                  a->in_coff);
+  if (a->in_ps) TPGSR_CHECK_ARG((a->Cin & 3) == 0 && a->in_coff == 0, "%s: in_ps needs Cin %% 4 == 0", who);
+  if ((a->Cin & 3) == 0 && !a->in_ps)
+    TPGSR_CHECK_ARG((a->in_ld & 3) == 0 && (a->in_coff & 3) == 0 && ((uintptr_t)a->in & 15) == 0,
+                    "%s: vector loader needs 16-byte aligned rows", who);
+  if (a->in2) TPGSR_CHECK_ARG(a->in2_ld >= a->Cin && ((a->Cin & 3) || (a->in2_ld & 3) == 0), "%s: bad in2_ld", who);
+  TPGSR_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "%s: in_scale/in_shift must come together", who);
+  return 0;
+}
+
+extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
+  int rc = check_conv_args(a, "tpgsr_conv_fwd");
+  if (rc) return rc;
+  TPGSR_CHECK_ARG(a->wt && a->out, "tpgsr_conv_fwd: null weight/output");
+  TPGSR_CHECK_ARG(a->out_ps || a->out_ld >= a->Cout + a->out_coff, "tpgsr_conv_fwd: out_ld too small");
+  if (a->out_ps) TPGSR_CHECK_ARG((a->Cout & 3) == 0, "tpgsr_conv_fwd: out_ps needs Cout %% 4 == 0");
+  TPGSR_CHECK_ARG(a->out_act == TPGSR_ACT_NONE || a->out_act == TPGSR_ACT_RELU || a->out_act == TPGSR_ACT_TANH,
+                  "tpgsr_conv_fwd: unsupported out_act %d", a->out_act);
+  long long M = (long long)a->N * a->OH * a->OW;
+  int K = a->KH * a->KW * a->Cin;
+  TPGSR_CHECK_ARG(M < (1ll << 31), "tpgsr_conv_fwd: M too large");
+  dim3 grid(cdiv(M, BM), cdiv(a->Cout, BN));
+  int vecB = ((a->Cout & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;
+  if ((a->Cin & 3) == 0)
+    hipLaunchKernelGGL(conv_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a, (int)M, K, vecB);
+  else
+    hipLaunchKernelGGL(conv_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a, (int)M, K, vecB);
+  TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight-gradient kernel:  part[z][k][n] = sum_{m in split z} A[m][k] * dy[m][n]
+// ------------------------------------------------------------------------------------------------------
+#define WK 64  // k rows per block
+#define WM 32  // pixels per staged chunk
+#define WALD (WM + 1)
+
+__device__ __forceinline__ float4 load_dy4(const tpgsr_wgrad_args& w, const PixelPos& p, int m, int col, int vec) {
+  const tpgsr_conv_args& a = w.c;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!p.valid || col >= a.Cout) return v;
+  if (!w.dy_ps) return load_row4(w.dy + w.dy_coff, (size_t)m, w.dy_ld, col, a.Cout, true, vec);
+  // logical channels col..col+3 = (cs = col/4, i, j) of a [N][2OH][2OW][Cout/4] tensor
+  int C4 = a.Cout >> 2, cs = col >> 2;
+  size_t W2 = 2 * (size_t)a.OW;
+  const float* b = w.dy + ((size_t)(p.n * 2 * a.OH + 2 * p.oh) * W2 + 2 * p.ow) * C4 + cs;
+  v.x = b[0];
+  v.y = b[C4];
+  v.z = b[W2 * C4];
+  v.w = b[W2 * C4 + C4];
+  return v;
+}
+
+template <bool VEC_A>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int M, int K, int MB, int vecY) {
+  __shared__ float As[WK][WALD];
+  __shared__ float Ys[WM][BN];
+  const tpgsr_conv_args& a = w.c;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wk = wave & 1, wn = wave >> 1;
+  const int k0 = blockIdx.x * WK, n0 = blockIdx.y * BN;
+  const int mbeg = blockIdx.z * MB;
+  const int mend = min(M, mbeg + MB);
+  const int ntaps = a.KH * a.KW;
+  const int cin4 = a.Cin >> 2;
+
+  // A staging: quad (tid&15) of this block's 64 k rows (fixed for the whole kernel), pixels (tid>>4), +16
+  const int aq = tid & 15;
+  const int ap0 = tid >> 4;
+  int atap = 0, ac = 0;
+  if (VEC_A) {
+    int kq = (k0 >> 2) + aq;
+    atap = kq / cin4;
+    ac = (kq - atap * cin4) * 4;
+  }
+  const int yr0 = tid >> 4;
+  const int yc = (tid & 15) * 4;
+
+  float4 ra0, ra1, ry0, ry1;
+  auto load_chunk = [&](int mc) {
+    int ma = mc + ap0, mb = mc + ap0 + 16;
+    PixelPos p0 = decode_pixel(a, ma, mend);
+    PixelPos p1 = decode_pixel(a, mb, mend);
+    if (VEC_A) {
+      ra0 = load_a_quad(a, p0, atap, ac, ntaps);
+      ra1 = load_a_quad(a, p1, atap, ac, ntaps);
+    } else {
+      int k = k0 + aq * 4;
+      ra0 = make_float4(load_a_scalar(a, p0, k, K), load_a_scalar(a, p0, k + 1, K), load_a_scalar(a, p0, k + 2, K),
+                        load_a_scalar(a, p0, k + 3, K));
+      ra1 = make_float4(load_a_scalar(a, p1, k, K), load_a_scalar(a, p1, k + 1, K), load_a_scalar(a, p1, k + 2, K),
+                        load_a_scalar(a, p1, k + 3, K));
+    }
+    ry0 = load_dy4(w, p0, ma, n0 + yc, vecY);
+    ry1 = load_dy4(w, p1, mb, n0 + yc, vecY);
+  };
+  auto store_chunk = [&]() {
+    As[aq * 4 + 0][ap0] = ra0.x;
+    As[aq * 4 + 1][ap0] = ra0.y;
+    As[aq * 4 + 2][ap0] = ra0.z;
+    As[aq * 4 + 3][ap0] = ra0.w;
+    As[aq * 4 + 0][ap0 + 16] = ra1.x;
+    As[aq * 4 + 1][ap0 + 16] = ra1.y;
+    As[aq * 4 + 2][ap0 + 16] = ra1.z;
+    As[aq * 4 + 3][ap0 + 16] = ra1.w;
+    *reinterpret_cast<float4*>(&Ys[yr0][yc]) = ry0;
+    *reinterpret_cast<float4*>(&Ys[yr0 + 16][yc]) = ry1;
+  };
+
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float dbacc = 0.f;
+  const bool want_db = (w.dbpart != nullptr) && blockIdx.x == 0 && tid < BN;
+
+  if (mbeg < mend) {
+    load_chunk(mbeg);
+    store_chunk();
+  }
+  __syncthreads();
+  const int arow = wk * 32 + (lane & 31);
+  const int bcol = wn * 32 + (lane & 31);
+  const int half = lane >> 5;
+  for (int mc = mbeg; mc < mend; mc += WM) {
+    const bool more = mc + WM < mend;
+    if (more) load_chunk(mc + WM);
+#pragma unroll
+    for (int mm = 0; mm < WM / 2; ++mm) {
+      float av = As[arow][2 * mm + half];
+      float bv = Ys[2 * mm + half][bcol];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (want_db) {
+#pragma unroll 8
+      for (int r = 0; r < WM; ++r) dbacc += Ys[r][tid];
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+  const int n = n0 + bcol;
+  float* dst = w.part + (size_t)blockIdx.z * K * a.Cout;
+  if (n < a.Cout) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int k = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (k < K) dst[(size_t)k * a.Cout + n] = acc[r];
+    }
+  }
+  if (want_db && n0 + tid < a.Cout) w.dbpart[(size_t)blockIdx.z * a.Cout + n0 + tid] = dbacc;
+}
+
+static void wgrad_plan(long long M, int K, int Cout, int* Z, int* MB) {
+  int kb = cdiv(K, WK), nb = cdiv(Cout, BN);
+  long long target = 1536;  // ~6 blocks per CU
+  long long z = (target + (long long)kb * nb - 1) / ((long long)kb * nb);
+  long long maxz = (M + 127) / 128;  // at least 128 pixels per split
+  if (z > maxz) z = maxz;
+  if (z < 1) z = 1;
+  long long mb = (M + z - 1) / z;
+  mb = (mb + WM - 1) / WM * WM;
+  z = (M + mb - 1) / mb;
+  *Z = (int)z;
+  *MB = (int)mb;
+}
+
+extern "C" int tpgsr_wgrad_splits(int M, int K, int Cout) {
+  int Z, MB;
+  wgrad_plan(M, K, Cout, &Z, &MB);
+  return Z;
+}
+
+extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
+  TPGSR_CHECK_ARG(w != nullptr, "tpgsr_conv_wgrad: null args");
+  int rc = check_conv_args(&w->c, "tpgsr_conv_wgrad");
+  if (rc) return rc;
+  TPGSR_CHECK_ARG(w->dy && w->part, "tpgsr_conv_wgrad: null dy/part");
+  const tpgsr_conv_args* a = &w->c;
+  if (w->dy_ps) TPGSR_CHECK_ARG((a->Cout & 3) == 0 && w->dy_coff == 0, "tpgsr_conv_wgrad: dy_ps needs Cout %% 4 == 0");
+  else TPGSR_CHECK_ARG(w->dy_ld >= a->Cout + w->dy_coff, "tpgsr_conv_wgrad: dy_ld too small");
+  long long M = (long long)a->N * a->OH * a->OW;
+  int K = a->KH * a->KW * a->Cin;
+  int Z, MB;
+  wgrad_plan(M, K, a->Cout, &Z, &MB);
+  dim3 grid(cdiv(K, WK), cdiv(a->Cout, BN), Z);
+  int vecY = (!w->dy_ps && (a->Cout & 3) == 0 && (w->dy_ld & 3) == 0 && (w->dy_coff & 3) == 0 &&
+              ((uintptr_t)w->dy & 15) == 0) ? 1 : 0;
+  if ((a->Cin & 3) == 0)
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *w, (int)M, K, MB, vecY);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *w, (int)M, K, MB, vecY);
+  TPGSR_LAUNCH_CHECK("tpgsr_conv_wgrad");
+}
+
+// dw (+)= sum_z part[z][k][co], scattered into the PyTorch layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart, int Z, int K,
+                                    int Cin, int Cout, int KH, int KW, int layout, float* dw, float* db, int accumulate, float gscale) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)K * Cout;
+  if (idx < total) {
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) s += part[(size_t)z * total + idx];
+    s *= gscale;
+    int k = (int)(idx / Cout), co = (int)(idx - (size_t)k * Cout);
+    int tap = k / Cin, ci = k - tap * Cin;
+    int kh = tap / KW, kw = tap - kh * KW;
+    size_t o;
+    if (layout == 0) {
+      o = (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
+    } else if (layout == 1) {  // ConvTranspose2d weight wT[ci][co][KH-1-kh][KW-1-kw] == equivalent-conv w_eq[co][ci][kh][kw]
+      o = (((size_t)ci * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
+    } else {  // layout 2: folded tail conv (KH = KS, KW = 1, Cout = KS*Co, n' = kw*Co + co) -> w[co][ci][kh][kw]
+      int Co = Cout / KH;
+      int tkw = co / Co, tco = co - tkw * Co;
+      o = (((size_t)tco * Cin + ci) * KH + kh) * KH + tkw;
+    }
+    dw[o] = accumulate ? dw[o] + s : s;
+  }
+  if (db && dbpart && idx < (size_t)Cout) {
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) s += dbpart[(size_t)z * Cout + idx];
+    db[idx] = accumulate ? db[idx] + s : s;
+  }
+}
+
+extern "C" int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
+                                  int layout, float* dw, float* db, int accumulate, float gscale, void* stream) {
+  TPGSR_CHECK_ARG(part && dw && Z > 0 && K == KH * KW * Cin, "tpgsr_wgrad_reduce: bad arguments");
+  size_t total = (size_t)K * Cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, part, dbpart, Z, K,
+                     Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale);
+  TPGSR_LAUNCH_CHECK("tpgsr_wgrad_reduce");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int transposed,
+                                        float wscale, float* wt_f, float* wt_d) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Cout * Cin * KH * KW;
+  if (idx >= total) return;
+  int kw = idx % KW;
+  size_t r = idx / KW;
+  int kh = r % KH;
+  r /= KH;
+  int co, ci;
+  if (!transposed) {
+    ci = r % Cin;
+    co = (int)(r / Cin);
+  } else {  // source [Cin][Cout][KH][KW]; equivalent conv weight w_eq[co][ci][kh'][kw'] with flipped taps
+    co = r % Cout;
+    ci = (int)(r / Cout);
+    kh = KH - 1 - kh;
+    kw = KW - 1 - kw;
+  }
+  float v = w[idx] * wscale;
+  if (wt_f) wt_f[((size_t)(kh * KW + kw) * Cin + ci) * Cout + co] = v;
+  if (wt_d) wt_d[((size_t)((KH - 1 - kh) * KW + (KW - 1 - kw)) * Cout + co) * Cin + ci] = v;
+}
+
+extern "C" int tpgsr_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int transposed, float wscale,
+                                      float* wt_f, float* wt_d, void* stream) {
+  TPGSR_CHECK_ARG(w && (wt_f || wt_d), "tpgsr_pack_conv_weight: null pointer");
+  size_t total = (size_t)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                     KH, KW, transposed, wscale, wt_f, wt_d);
+  TPGSR_LAUNCH_CHECK("tpgsr_pack_conv_weight");
+}
+
+__global__ void pack_tail_weight_kernel(const float* __restrict__ w, int Co, int C, int KS, float* wt_f, float* wt_d) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Co * C * KS * KS;
+  if (idx >= total) return;
+  int kw = idx % KS;
+  size_t r = idx / KS;
+  int kh = r % KS;
+  r /= KS;
+  int ci = r % C;
+  int co = (int)(r / C);
+  float v = w[idx];
+  int NP = KS * Co;  // folded output columns
+  int np = kw * Co + co;
+  if (wt_f) wt_f[((size_t)kh * C + ci) * NP + np] = v;
+  if (wt_d) wt_d[((size_t)(KS - 1 - kh) * NP + np) * C + ci] = v;
+}
+
+extern "C" int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, float* wt_d, void* stream) {
+  TPGSR_CHECK_ARG(w && (wt_f || wt_d), "tpgsr_pack_tail_weight: null pointer");
+  size_t total = (size_t)Co * C * KS * KS;
+  hipLaunchKernelGGL(pack_tail_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Co, C, KS,
+                     wt_f, wt_d);
+  TPGSR_LAUNCH_CHECK("tpgsr_pack_tail_weight");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pack program: ALL per-step operand packing of a model in one launch (a device-resident descriptor table)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc* __restrict__ descs, int ndesc) {
+  __shared__ int s_d;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = ndesc - 1;  // last descriptor whose blk0 <= blockIdx.x
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    s_d = lo;
+  }
+  __syncthreads();
+  const tpgsr_pack_desc d = descs[s_d];
+  long long idx = (long long)(blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  if (idx >= d.numel) return;
+  float v = d.src[idx] * d.wscale;
+  if (d.kind == 2) {  // plain copy
+    d.dst_f[idx] = v;
+    return;
+  }
+  int kw = idx % d.KW;
+  long long r = idx / d.KW;
+  int kh = r % d.KH;
+  r /= d.KH;
+  if (d.kind == 1) {  // folded tail conv: src [Co][C][KS][KS]
+    int ci = r % d.Cin;
+    int co = (int)(r / d.Cin);
+    int NP = d.KH * d.Cout, np = kw * d.Cout + co;  // here Cout = Co, KH = KW = KS
+    if (d.dst_f) d.dst_f[((size_t)kh * d.Cin + ci) * NP + np] = v;
+    if (d.dst_d) d.dst_d[((size_t)(d.KH - 1 - kh) * NP + np) * d.Cin + ci] = v;
+    return;
+  }
+  int co, ci;
+  if (d.kind == 0) {
+    ci = r % d.Cin;
+    co = (int)(r / d.Cin);
+  } else {  // kind 3: ConvTranspose2d weight [Cin][Cout][KH][KW] -> equivalent conv (flipped taps)
+    co = r % d.Cout;
+    ci = (int)(r / d.Cout);
+    kh = d.KH - 1 - kh;
+    kw = d.KW - 1 - kw;
+  }
+  if (d.dst_f) d.dst_f[((size_t)(kh * d.KW + kw) * d.Cin + ci) * d.f_ld + d.f_coff + co] = v;
+  if (d.dst_d) d.dst_d[((size_t)((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.Cout + co) * d.Cin + ci] = v;
+}
+
+extern "C" int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream) {
+  TPGSR_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0, "tpgsr_pack_program: bad arguments");
+  hipLaunchKernelGGL(pack_program_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc);
+  TPGSR_LAUNCH_CHECK("tpgsr_pack_program");
+}
+
+extern "C" int tpgsr_copy(const float* src, float* dst, long long n, void* stream) {
+  TPGSR_CHECK_ARG(src && dst && n > 0, "tpgsr_copy: bad arguments");
+  hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    tpgsr_set_error("tpgsr_copy: %s", hipGetErrorString(e));
+    return TPGSR_ERR_LAUNCH;
+  }
+  return 0;
+}
+
+extern "C" int tpgsr_zero(float* dst, long long n, void* stream) {
+  TPGSR_CHECK_ARG(dst && n > 0, "tpgsr_zero: bad arguments");
+  hipError_t e = hipMemsetAsync(dst, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) {
+    tpgsr_set_error("tpgsr_zero: %s", hipGetErrorString(e));
+    return TPGSR_ERR_LAUNCH;
+  }
+  return 0;
+}

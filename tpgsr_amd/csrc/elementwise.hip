@@ -1,0 +1,485 @@
+// HBM-bound elementwise / per-channel reduction kernels: train-mode BatchNorm (statistics, backward),
+// activation + max-pool materialisation (STN head), PReLU, layout transposes, small reductions.
+// All tensors are [M][C] row-major (NHWC flattened); channel loops are float4-vectorised when C % 4 == 0.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// BatchNorm statistics
+// ------------------------------------------------------------------------------------------------------
+// partial[b][0][c] = sum_m x, partial[b][1][c] = sum_m x^2 over the rows of block b
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, int ld,
+                                                       float* __restrict__ partial, int nblk) {
+  long long rows_per = (M + nblk - 1) / nblk;
+  long long r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f, ss = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+      float v = x[r * ld + c];
+      s += v;
+      ss += v * v;
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = ss;
+  }
+}
+
+extern "C" int tpgsr_bn_stats(const float* x, long long M, int C, int ld, float* partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(x && partial && M > 0 && C > 0 && nblk > 0, "tpgsr_bn_stats: bad arguments");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, partial, nblk);
+  TPGSR_LAUNCH_CHECK("tpgsr_bn_stats");
+}
+
+// one block of 256 threads per 32 channels; 8 row-slices per channel, fp64 combine
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                          long long count, const float* conv_bias,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum,
+                                                          float eps, int eval, float* scale, float* shift,
+                                                          float* save_mean, float* save_rstd) {
+  __shared__ double red[2][8][32];
+  int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  int c = blockIdx.x * 32 + cl;
+  if (eval) {
+    if (sl == 0 && c < C) {
+      float rstd = 1.f / sqrtf(running_var[c] + eps);
+      float sc = gamma[c] * rstd;
+      scale[c] = sc;
+      shift[c] = beta[c] - running_mean[c] * sc;
+    }
+    return;
+  }
+  double s = 0.0, ss = 0.0;
+  if (c < C)
+    for (int b = sl; b < nblk; b += 8) {
+      s += (double)partial[((size_t)b * 2 + 0) * C + c];
+      ss += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+  red[0][sl][cl] = s;
+  red[1][sl][cl] = ss;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int i = 1; i < 8; ++i) {
+      s += red[0][i][cl];
+      ss += red[1][i][cl];
+    }
+    double mean_raw = s / (double)count;
+    double var = ss / (double)count - mean_raw * mean_raw;
+    if (var < 0.0) var = 0.0;
+    double mean = mean_raw + (conv_bias ? (double)conv_bias[c] : 0.0);
+    double rstd = 1.0 / sqrt(var + (double)eps);
+    float sc = (float)((double)gamma[c] * rstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_rstd) save_rstd[c] = (float)rstd;
+    if (running_mean) {
+      double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+extern "C" int tpgsr_bn_finalize(const float* partial, int nblk, int C, long long count, const float* conv_bias,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, int eval, float* scale, float* shift, float* save_mean,
+                                 float* save_rstd, void* stream) {
+  TPGSR_CHECK_ARG(gamma && beta && scale && shift && C > 0, "tpgsr_bn_finalize: null pointer");
+  TPGSR_CHECK_ARG(eval || (partial && nblk > 0 && count > 0), "tpgsr_bn_finalize: training mode needs partial statistics");
+  TPGSR_CHECK_ARG(!eval || (running_mean && running_var), "tpgsr_bn_finalize: eval mode needs running statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
+                     conv_bias, gamma, beta, running_mean, running_var, momentum, eps, eval, scale, shift, save_mean,
+                     save_rstd);
+  TPGSR_LAUNCH_CHECK("tpgsr_bn_finalize");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BatchNorm (+activation) backward
+//   z = scale*y + shift ; a = act(z) ; given da (+da2): dz = da*act'(z)
+//   pass 1: partial[b][0][c] = sum dz ; partial[b][1][c] = sum dz*xhat, xhat = (y-mean)*rstd
+//   pass 2: dy = coef0*dz + coef1*y + coef2
+// thread layout: C4 = C/4 channel quads across threads, 256/C4 row lanes; requires C%4==0, 256%(C/4)==0
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ da2,
+                                                            const float* __restrict__ y, long long M, int C,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_rstd, int act,
+                                                            float* __restrict__ partial, int nblk) {
+  extern __shared__ float sm[];  // [rowlanes][2][C]
+  const int C4 = C >> 2;
+  const int rl = 256 / C4;
+  const int q = threadIdx.x % C4, lane_r = threadIdx.x / C4;
+  const int c = q * 4;
+  long long rows_per = (M + nblk - 1) / nblk;
+  long long r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  float4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(save_mean + c), rs = ld4(save_rstd + c);
+  float4 s = make_float4(0, 0, 0, 0), sx = make_float4(0, 0, 0, 0);
+  for (long long r = r0 + lane_r; r < r1; r += rl) {
+    float4 g = ld4(da + r * C + c);
+    if (da2) {
+      float4 g2 = ld4(da2 + r * C + c);
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+    }
+    float4 yv = ld4(y + r * C + c);
+    if (act) {
+      g.x *= act_grad(yv.x * sc.x + sh.x, act);
+      g.y *= act_grad(yv.y * sc.y + sh.y, act);
+      g.z *= act_grad(yv.z * sc.z + sh.z, act);
+      g.w *= act_grad(yv.w * sc.w + sh.w, act);
+    }
+    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+    sx.x += g.x * (yv.x - mu.x) * rs.x;
+    sx.y += g.y * (yv.y - mu.y) * rs.y;
+    sx.z += g.z * (yv.z - mu.z) * rs.z;
+    sx.w += g.w * (yv.w - mu.w) * rs.w;
+  }
+  float* a0 = sm + ((size_t)lane_r * 2 + 0) * C + c;
+  float* a1 = sm + ((size_t)lane_r * 2 + 1) * C + c;
+  *reinterpret_cast<float4*>(a0) = s;
+  *reinterpret_cast<float4*>(a1) = sx;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int l = 0; l < rl; ++l) t += sm[(size_t)l * 2 * C + i];
+    partial[(size_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+static int bn_vec_ok(int C) { return (C & 3) == 0 && C >= 4 && C <= 1024 && (256 % (C >> 2)) == 0; }
+
+extern "C" int tpgsr_bn_bwd_reduce(const float* da, const float* da2, const float* y, long long M, int C,
+                                   const float* scale, const float* shift, const float* save_mean,
+                                   const float* save_rstd, int act, float* partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(da && y && scale && shift && save_mean && save_rstd && partial && nblk > 0, "tpgsr_bn_bwd_reduce: null pointer");
+  TPGSR_CHECK_ARG(bn_vec_ok(C), "tpgsr_bn_bwd_reduce: unsupported channel count %d", C);
+  size_t smem = (size_t)(256 / (C >> 2)) * 2 * C * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), smem, (hipStream_t)stream, da, da2, y, M, C, scale, shift,
+                     save_mean, save_rstd, act, partial, nblk);
+  TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_reduce");
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              long long count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ save_mean,
+                                                              const float* __restrict__ save_rstd, float* dgamma,
+                                                              float* dbeta, int accumulate, float* coef) {
+  __shared__ double red[2][8][32];
+  int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  int c = blockIdx.x * 32 + cl;
+  double s = 0.0, sx = 0.0;
+  if (c < C)
+    for (int b = sl; b < nblk; b += 8) {
+      s += (double)partial[((size_t)b * 2 + 0) * C + c];
+      sx += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+  red[0][sl][cl] = s;
+  red[1][sl][cl] = sx;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int i = 1; i < 8; ++i) {
+      s += red[0][i][cl];
+      sx += red[1][i][cl];
+    }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sx : (float)sx;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    double rstd = save_rstd[c], mu = save_mean[c], g = gamma[c];
+    double mdz = s / (double)count, mdzx = sx / (double)count;
+    double c0 = g * rstd;
+    coef[c] = (float)c0;
+    coef[C + c] = (float)(-c0 * mdzx * rstd);
+    coef[2 * C + c] = (float)(-c0 * (mdz - mu * rstd * mdzx));
+  }
+}
+
+extern "C" int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long long count, const float* gamma,
+                                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                                     int accumulate, float* coef, void* stream) {
+  TPGSR_CHECK_ARG(partial && gamma && save_mean && save_rstd && coef && nblk > 0 && count > 0, "tpgsr_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
+                     gamma, save_mean, save_rstd, dgamma, dbeta, accumulate, coef);
+  TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_finalize");
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ da2,
+                                                           const float* __restrict__ y, long long total4, int C,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int act, const float* __restrict__ coef, float* __restrict__ dy) {
+  const int C4 = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C4) * 4;
+    float4 g = ld4(da + i * 4);
+    if (da2) {
+      float4 g2 = ld4(da2 + i * 4);
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+    }
+    float4 yv = ld4(y + i * 4);
+    if (act) {
+      float4 sc = ld4(scale + c), sh = ld4(shift + c);
+      g.x *= act_grad(yv.x * sc.x + sh.x, act);
+      g.y *= act_grad(yv.y * sc.y + sh.y, act);
+      g.z *= act_grad(yv.z * sc.z + sh.z, act);
+      g.w *= act_grad(yv.w * sc.w + sh.w, act);
+    }
+    float4 c0 = ld4(coef + c), c1 = ld4(coef + C + c), c2 = ld4(coef + 2 * C + c);
+    float4 o;
+    o.x = c0.x * g.x + c1.x * yv.x + c2.x;
+    o.y = c0.y * g.y + c1.y * yv.y + c2.y;
+    o.z = c0.z * g.z + c1.z * yv.z + c2.z;
+    o.w = c0.w * g.w + c1.w * yv.w + c2.w;
+    *reinterpret_cast<float4*>(dy + i * 4) = o;
+  }
+}
+
+extern "C" int tpgsr_bn_bwd_apply(const float* da, const float* da2, const float* y, long long M, int C, const float* scale,
+                                  const float* shift, int act, const float* coef, float* dy, void* stream) {
+  TPGSR_CHECK_ARG(da && y && coef && dy && (C & 3) == 0, "tpgsr_bn_bwd_apply: bad arguments");
+  TPGSR_CHECK_ARG(!act || (scale && shift), "tpgsr_bn_bwd_apply: activation needs scale/shift");
+  long long total4 = M * C / 4;
+  int grid = (int)min((long long)4096, (total4 + 255) / 256);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, da, da2, y, total4, C, scale, shift,
+                     act, coef, dy);
+  TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_apply");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// act(scale*x+shift) + max-pool (ph x pw, stride = window, floor) -- STN head / CRNN pooling stages
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_pool_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int act, int ph, int pw,
+                                                              float* __restrict__ out) {
+  int OH = H / ph, OW = W / pw;
+  long long total = (long long)N * OH * OW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int ow = (int)(p % OW);
+    p /= OW;
+    int oh = (int)(p % OH);
+    int n = (int)(p / OH);
+    float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    float best = -INFINITY;
+    for (int a = 0; a < ph; ++a)
+      for (int b = 0; b < pw; ++b) {
+        float v = x[((size_t)(n * H + oh * ph + a) * W + ow * pw + b) * C + c];
+        v = apply_act(v * sc + sh, act);
+        if (v > best || v != v) best = v;
+      }
+    out[i] = best;
+  }
+}
+
+extern "C" int tpgsr_affine_act_pool(const float* x, int N, int H, int W, int C, const float* scale, const float* shift,
+                                     int act, int pool_h, int pool_w, float* out, void* stream) {
+  TPGSR_CHECK_ARG(x && out && pool_h >= 1 && pool_w >= 1 && H >= pool_h && W >= pool_w, "tpgsr_affine_act_pool: bad arguments");
+  long long total = (long long)N * (H / pool_h) * (W / pool_w) * C;
+  int grid = (int)min((long long)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(affine_act_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, scale, shift, act,
+                     pool_h, pool_w, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_affine_act_pool");
+}
+
+// dz[n][h][w][c] = (h,w is the first arg-max of its window) ? dout * act'(scale*x+shift) : 0
+__global__ __launch_bounds__(256) void affine_act_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                                  int N, int H, int W, int C,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int act, int ph, int pw,
+                                                                  float* __restrict__ dz) {
+  int OH = H / ph, OW = W / pw;
+  long long total = (long long)N * OH * OW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int ow = (int)(p % OW);
+    p /= OW;
+    int oh = (int)(p % OH);
+    int n = (int)(p / OH);
+    float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    float best = -INFINITY, bestpre = 0.f;
+    int ba = 0, bb = 0;
+    for (int a = 0; a < ph; ++a)
+      for (int b = 0; b < pw; ++b) {
+        float pre = x[((size_t)(n * H + oh * ph + a) * W + ow * pw + b) * C + c] * sc + sh;
+        float v = apply_act(pre, act);
+        if (v > best || v != v) {
+          best = v;
+          bestpre = pre;
+          ba = a;
+          bb = b;
+        }
+      }
+    float g = dout[i] * act_grad(bestpre, act);
+    for (int a = 0; a < ph; ++a)
+      for (int b = 0; b < pw; ++b)
+        dz[((size_t)(n * H + oh * ph + a) * W + ow * pw + b) * C + c] = (a == ba && b == bb) ? g : 0.f;
+  }
+  // rows/cols dropped by the floor (H % ph, W % pw) receive no gradient
+  if (H % ph || W % pw) {
+    long long tot2 = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot2; i += (long long)gridDim.x * blockDim.x) {
+      long long p = i / C;
+      int w = (int)(p % W);
+      int h = (int)((p / W) % H);
+      if (h >= OH * ph || w >= OW * pw) dz[i] = 0.f;
+    }
+  }
+}
+
+extern "C" int tpgsr_affine_act_pool_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale,
+                                         const float* shift, int act, int pool_h, int pool_w, float* dz, void* stream) {
+  TPGSR_CHECK_ARG(x && dout && dz && pool_h >= 1 && pool_w >= 1, "tpgsr_affine_act_pool_bwd: bad arguments");
+  long long total = (long long)N * (H / pool_h) * (W / pool_w) * C;
+  int grid = (int)min((long long)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(affine_act_pool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dout, N, H, W, C, scale,
+                     shift, act, pool_h, pool_w, dz);
+  TPGSR_LAUNCH_CHECK("tpgsr_affine_act_pool_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// PReLU (single shared slope), add, activation backward, transposes, small reductions
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                        long long n4, float* __restrict__ y) {
+  float a = alpha[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = ld4(x + i * 4);
+    v.x = v.x > 0.f ? v.x : a * v.x;
+    v.y = v.y > 0.f ? v.y : a * v.y;
+    v.z = v.z > 0.f ? v.z : a * v.z;
+    v.w = v.w > 0.f ? v.w : a * v.w;
+    *reinterpret_cast<float4*>(y + i * 4) = v;
+  }
+}
+
+extern "C" int tpgsr_prelu_fwd(const float* x, const float* alpha, long long n, float* y, void* stream) {
+  TPGSR_CHECK_ARG(x && alpha && y && (n & 3) == 0, "tpgsr_prelu_fwd: bad arguments (n must be a multiple of 4)");
+  int grid = (int)min((long long)4096, (n / 4 + 255) / 256);
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, alpha, n / 4, y);
+  TPGSR_LAUNCH_CHECK("tpgsr_prelu_fwd");
+}
+
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                        const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                        long long n4, float* __restrict__ dx, float* __restrict__ dap) {
+  __shared__ float red[4];
+  float a = alpha[0];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = ld4(x + i * 4);
+    float4 g = ld4(dy + i * 4);
+    if (dy2) {
+      float4 g2 = ld4(dy2 + i * 4);
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+    }
+    float4 o;
+    o.x = v.x > 0.f ? g.x : a * g.x;
+    o.y = v.y > 0.f ? g.y : a * g.y;
+    o.z = v.z > 0.f ? g.z : a * g.z;
+    o.w = v.w > 0.f ? g.w : a * g.w;
+    acc += (v.x > 0.f ? 0.f : g.x * v.x) + (v.y > 0.f ? 0.f : g.y * v.y) + (v.z > 0.f ? 0.f : g.z * v.z) +
+           (v.w > 0.f ? 0.f : g.w * v.w);
+    *reinterpret_cast<float4*>(dx + i * 4) = o;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dap[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+extern "C" int tpgsr_prelu_bwd(const float* x, const float* alpha, const float* dy, const float* dy2, long long n, float* dx,
+                               float* dalpha_partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(x && alpha && dy && dx && dalpha_partial && nblk > 0 && (n & 3) == 0, "tpgsr_prelu_bwd: bad arguments");
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dy2, n / 4, dx,
+                     dalpha_partial);
+  TPGSR_LAUNCH_CHECK("tpgsr_prelu_bwd");
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n4,
+                                                  long long n, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 u = ld4(a + i * 4), v = ld4(b + i * 4);
+    u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+    *reinterpret_cast<float4*>(out + i * 4) = u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long long i = n4 * 4 + threadIdx.x;
+    out[i] = a[i] + b[i];
+  }
+}
+
+extern "C" int tpgsr_add(const float* a, const float* b, long long n, float* out, void* stream) {
+  TPGSR_CHECK_ARG(a && b && out && n > 0, "tpgsr_add: bad arguments");
+  int grid = (int)max((long long)1, min((long long)4096, (n / 4 + 255) / 256));
+  hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, n / 4, n, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_add");
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long long n,
+                                                      int act, float* __restrict__ dx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * act_grad(x[i], act);
+}
+
+extern "C" int tpgsr_act_bwd(const float* x, const float* dy, long long n, int act, float* dx, void* stream) {
+  TPGSR_CHECK_ARG(x && dy && dx && n > 0, "tpgsr_act_bwd: bad arguments");
+  int grid = (int)min((long long)8192, (n + 255) / 256);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dy, n, act, dx);
+  TPGSR_LAUNCH_CHECK("tpgsr_act_bwd");
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, int N, int C, int HW,
+                                                           float* __restrict__ out) {
+  long long total = (long long)N * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int hw = (int)(p % HW);
+    int n = (int)(p / HW);
+    out[i] = in[((size_t)n * C + c) * HW + hw];
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int N, int C, int HW,
+                                                           float* __restrict__ out) {
+  long long total = (long long)N * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int hw = (int)(i % HW);
+    long long p = i / HW;
+    int c = (int)(p % C);
+    int n = (int)(p / C);
+    out[i] = in[((size_t)n * HW + hw) * C + c];
+  }
+}
+
+extern "C" int tpgsr_nchw_to_nhwc(const float* in, int N, int C, int H, int W, float* out, void* stream) {
+  TPGSR_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0, "tpgsr_nchw_to_nhwc: bad arguments");
+  long long total = (long long)N * C * H * W;
+  int grid = (int)min((long long)8192, (total + 255) / 256);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, N, C, H * W, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_nchw_to_nhwc");
+}
+extern "C" int tpgsr_nhwc_to_nchw(const float* in, int N, int C, int H, int W, float* out, void* stream) {
+  TPGSR_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0, "tpgsr_nhwc_to_nchw: bad arguments");
+  long long total = (long long)N * C * H * W;
+  int grid = (int)min((long long)8192, (total + 255) / 256);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, N, C, H * W, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_nhwc_to_nchw");
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int Z, int n, float* out,
+                                                              int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int z = 0; z < Z; ++z) s += (double)part[(size_t)z * n + i];
+  out[i] = accumulate ? out[i] + (float)s : (float)s;
+}
+
+extern "C" int tpgsr_reduce_partials(const float* part, int Z, int n, float* out, int accumulate, void* stream) {
+  TPGSR_CHECK_ARG(part && out && Z > 0 && n > 0, "tpgsr_reduce_partials: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, Z, n, out,
+                     accumulate);
+  TPGSR_LAUNCH_CHECK("tpgsr_reduce_partials");
+}

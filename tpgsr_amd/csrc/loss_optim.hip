@@ -1,0 +1,310 @@
+// Tail of the SR network (shift-sum + tanh of the folded 9x9 conv), the image loss
+// (loss/image_loss.py:10-51) and the optimiser step (clip_grad_norm_ + Adam over flat arenas).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// tail: out[n][co][h][w] = tanh(bias[co] + sum_kw P[n][h][w+kw-KS/2][kw*Co+co])   (NCHW output)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_shiftsum_tanh_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                                 int N, int H, int W, int Co, int KS,
+                                                                 float* __restrict__ out) {
+  long long total = (long long)N * Co * H * W;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int w = (int)(i % W);
+  long long r = i / W;
+  int h = (int)(r % H);
+  r /= H;
+  int co = (int)(r % Co);
+  int n = (int)(r / Co);
+  const int NP = KS * Co, half = KS / 2;
+  float s = bias ? bias[co] : 0.f;
+  const float* row = P + ((size_t)(n * H + h) * W) * NP;
+  for (int kw = 0; kw < KS; ++kw) {
+    int x = w + kw - half;
+    if ((unsigned)x < (unsigned)W) s += row[(size_t)x * NP + kw * Co + co];
+  }
+  out[i] = tanhf(s);
+}
+
+extern "C" int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,
+                                        float* out_nchw, void* stream) {
+  TPGSR_CHECK_ARG(P && out_nchw && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "tpgsr_tail_shiftsum_tanh: bad arguments");
+  long long total = (long long)N * Co * H * W;
+  hipLaunchKernelGGL(tail_shiftsum_tanh_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, P, bias, N, H, W,
+                     Co, KS, out_nchw);
+  TPGSR_LAUNCH_CHECK("tpgsr_tail_shiftsum_tanh");
+}
+
+// dP[n][h][x][kw*Co+co] = dpre[n][co][h][x-kw+KS/2], dpre = dout*(1-out^2); dbias partial per block
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, int N,
+                                                       int H, int W, int Co, int KS, float* __restrict__ dP,
+                                                       float* __restrict__ dbp) {
+  __shared__ float sb[8];
+  if (threadIdx.x < 8) sb[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int NP = KS * Co, half = KS / 2;
+  long long total = (long long)N * H * W * NP;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) {
+    int np = (int)(i % NP);
+    long long r = i / NP;
+    int x = (int)(r % W);
+    r /= W;
+    int h = (int)(r % H);
+    int n = (int)(r / H);
+    int kw = np / Co, co = np - kw * Co;
+    int w = x - kw + half;
+    float v = 0.f;
+    if ((unsigned)w < (unsigned)W) {
+      size_t o = (((size_t)n * Co + co) * H + h) * W + w;
+      float y = out[o];
+      v = dout[o] * (1.f - y * y);
+      if (kw == half && dbp) atomicAdd(&sb[co], v);
+    }
+    dP[i] = v;
+  }
+  __syncthreads();
+  if (dbp && threadIdx.x < Co) dbp[(size_t)blockIdx.x * Co + threadIdx.x] = sb[threadIdx.x];
+}
+
+extern "C" int tpgsr_tail_bwd(const float* out_nchw, const float* dout_nchw, int N, int H, int W, int Co, int KS, float* dP,
+                              float* dbias_partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(out_nchw && dout_nchw && dP && Co <= 8 && (KS & 1), "tpgsr_tail_bwd: bad arguments");
+  long long total = (long long)N * H * W * KS * Co;
+  int grid = cdiv(total, 256);
+  TPGSR_CHECK_ARG(!dbias_partial || nblk == grid, "tpgsr_tail_bwd: dbias_partial needs nblk == %d blocks (got %d)", grid, nblk);
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_nchw, dout_nchw, N, H, W, Co, KS, dP,
+                     dbias_partial);
+  TPGSR_LAUNCH_CHECK("tpgsr_tail_bwd");
+}
+
+extern "C" int tpgsr_tail_bwd_blocks(int N, int H, int W, int Co, int KS) {
+  return cdiv((long long)N * H * W * KS * Co, 256);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// image loss (NCHW): w0*MSE over all C channels + w1*L1(gradmag(out[:, :3]) - gradmag(tgt[:, :3]))
+// gradmag(x)[h][w] = sqrt(((x[h][w+1]-x[h][w-1])/2)^2 + ((x[h-1][w]-x[h+1][w])/2)^2 + 1e-6), zero padding
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float at0(const float* p, int h, int w, int H, int W) {
+  return ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? p[(size_t)h * W + w] : 0.f;
+}
+__device__ __forceinline__ void gradmag(const float* p, int h, int w, int H, int W, float& gm, float& dx, float& dy) {
+  dx = at0(p, h, w + 1, H, W) - at0(p, h, w - 1, H, W);
+  dy = at0(p, h - 1, w, H, W) - at0(p, h + 1, w, H, W);
+  float a = dx * 0.5f, b = dy * 0.5f;
+  gm = sqrtf(a * a + b * b + 1e-6f);
+}
+
+__global__ __launch_bounds__(256) void image_loss_fwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt, int N,
+                                                             int C, int H, int W, int gradient, float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  long long total = (long long)N * C * H * W;
+  float sq = 0.f, ab = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float d = out[i] - tgt[i];
+    sq += d * d;
+    if (gradient) {
+      int w = (int)(i % W);
+      long long r = i / W;
+      int h = (int)(r % H);
+      r /= H;
+      int c = (int)(r % C);
+      if (c < 3) {
+        size_t plane = (size_t)r * H * W;
+        float g1, g2, t0, t1;
+        gradmag(out + plane, h, w, H, W, g1, t0, t1);
+        gradmag(tgt + plane, h, w, H, W, g2, t0, t1);
+        ab += fabsf(g1 - g2);
+      }
+    }
+  }
+  sq = wave_sum(sq);
+  ab = wave_sum(ab);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sq;
+    red[1][threadIdx.x >> 6] = ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+extern "C" int tpgsr_image_loss_fwd(const float* out, const float* tgt, int N, int C, int H, int W, int gradient, float* partial,
+                                    int nblk, void* stream) {
+  TPGSR_CHECK_ARG(out && tgt && partial && nblk > 0 && N > 0 && C > 0, "tpgsr_image_loss_fwd: bad arguments");
+  hipLaunchKernelGGL(image_loss_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, tgt, N, C, H, W, gradient,
+                     partial);
+  TPGSR_LAUNCH_CHECK("tpgsr_image_loss_fwd");
+}
+
+__global__ void image_loss_finalize_kernel(const float* __restrict__ partial, int nblk, long long n_mse, long long n_gp, float w0,
+                                           float w1, float* loss) {
+  double sq = 0.0, ab = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    sq += (double)partial[b * 2];
+    ab += (double)partial[b * 2 + 1];
+  }
+  sq = wave_sum_d(sq);
+  ab = wave_sum_d(ab);
+  if (threadIdx.x == 0) {
+    double l = (double)w0 * sq / (double)n_mse;
+    if (n_gp > 0) l += (double)w1 * ab / (double)n_gp;
+    loss[0] = (float)l;
+  }
+}
+
+extern "C" int tpgsr_image_loss_finalize(const float* partial, int nblk, long long n_mse, long long n_gp, float w0, float w1,
+                                         float* loss, void* stream) {
+  TPGSR_CHECK_ARG(partial && loss && nblk > 0 && n_mse > 0, "tpgsr_image_loss_finalize: bad arguments");
+  hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nblk, n_mse, n_gp, w0, w1,
+                     loss);
+  TPGSR_LAUNCH_CHECK("tpgsr_image_loss_finalize");
+}
+
+__global__ __launch_bounds__(256) void image_loss_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                             const float* __restrict__ dloss, int N, int C, int H, int W,
+                                                             int gradient, float cm, float cg, float* __restrict__ dout) {
+  long long total = (long long)N * C * H * W;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float dl = dloss[0];
+  float g = cm * 2.f * (out[i] - tgt[i]);
+  if (gradient) {
+    int w = (int)(i % W);
+    long long r = i / W;
+    int h = (int)(r % H);
+    r /= H;
+    int c = (int)(r % C);
+    if (c < 3) {
+      const float* po = out + (size_t)r * H * W;
+      const float* pt = tgt + (size_t)r * H * W;
+      float acc = 0.f;
+      // out[h][w] is the `r` neighbour of (h, w-1), the `l` neighbour of (h, w+1),
+      // the `t` neighbour of (h+1, w) and the `b` neighbour of (h-1, w)
+      auto contrib = [&](int qh, int qw, int which) {
+        if ((unsigned)qh >= (unsigned)H || (unsigned)qw >= (unsigned)W) return;
+        float go, gt, dx, dy, t0, t1;
+        gradmag(po, qh, qw, H, W, go, dx, dy);
+        gradmag(pt, qh, qw, H, W, gt, t0, t1);
+        float diff = go - gt;
+        float s = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        float d = (which == 0) ? dx : (which == 1) ? -dx : (which == 2) ? dy : -dy;
+        acc += s * d * 0.25f / go;
+      };
+      contrib(h, w - 1, 0);
+      contrib(h, w + 1, 1);
+      contrib(h + 1, w, 2);
+      contrib(h - 1, w, 3);
+      g += cg * acc;
+    }
+  }
+  dout[i] = dl * g;
+}
+
+extern "C" int tpgsr_image_loss_bwd(const float* out, const float* tgt, const float* dloss, int N, int C, int H, int W, int gradient,
+                                    float w0, float w1, float* dout, void* stream) {
+  TPGSR_CHECK_ARG(out && tgt && dloss && dout, "tpgsr_image_loss_bwd: null pointer");
+  long long total = (long long)N * C * H * W;
+  long long n_gp = (long long)N * (C < 3 ? C : 3) * H * W;
+  float cm = w0 / (float)total, cg = gradient ? w1 / (float)n_gp : 0.f;
+  hipLaunchKernelGGL(image_loss_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, tgt, dloss, N, C, H, W,
+                     gradient, cm, cg, dout);
+  TPGSR_LAUNCH_CHECK("tpgsr_image_loss_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// optimiser: global L2 norm, clip coefficient, Adam
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    s += (double)v * (double)v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int tpgsr_sumsq_partial(const float* x, long long n, float* partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(x && partial && n > 0 && nblk > 0, "tpgsr_sumsq_partial: bad arguments");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n, partial);
+  TPGSR_LAUNCH_CHECK("tpgsr_sumsq_partial");
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, float max_norm, float* coef, float* norm_out) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[b];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) {
+    float total = (float)sqrt(s);
+    float c = max_norm / (total + 1e-6f);
+    coef[0] = c < 1.f ? c : 1.f;
+    if (norm_out) norm_out[0] = total;
+  }
+}
+
+extern "C" int tpgsr_clip_coef(const float* partial, int nblk, float max_norm, float* coef, float* norm_out, void* stream) {
+  TPGSR_CHECK_ARG(partial && coef && nblk > 0, "tpgsr_clip_coef: bad arguments");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nblk, max_norm, coef, norm_out);
+  TPGSR_LAUNCH_CHECK("tpgsr_clip_coef");
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long long n, const float* __restrict__ gscale,
+                                                        float lr, float beta1, float beta2, float eps,
+                                                        const int* __restrict__ step_dev) {
+  __shared__ float s_step_size, s_bc2_sqrt;
+  if (threadIdx.x == 0) {
+    int t = step_dev[0];
+    double bc1 = 1.0 - pow((double)beta1, (double)t);
+    double bc2 = 1.0 - pow((double)beta2, (double)t);
+    s_step_size = (float)((double)lr / bc1);
+    s_bc2_sqrt = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = s_step_size, bc2s = s_bc2_sqrt;
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gs;
+    float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int tpgsr_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* gscale, float lr,
+                               float beta1, float beta2, float eps, const int* step_dev, void* stream) {
+  TPGSR_CHECK_ARG(p && g && m && v && step_dev && n > 0, "tpgsr_adam_step: bad arguments");
+  int grid = (int)min((long long)4096, (n + 255) / 256);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, gscale, lr, beta1, beta2, eps,
+                     step_dev);
+  TPGSR_LAUNCH_CHECK("tpgsr_adam_step");
+}
+
+__global__ void step_inc_kernel(int* s) { s[0] += 1; }
+extern "C" int tpgsr_step_inc(int* step_dev, void* stream) {
+  TPGSR_CHECK_ARG(step_dev, "tpgsr_step_inc: null pointer");
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  TPGSR_LAUNCH_CHECK("tpgsr_step_inc");
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* x, long long n, const float* coef) {
+  float c = coef[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= c;
+}
+extern "C" int tpgsr_scale_(float* x, long long n, const float* coef, void* stream) {
+  TPGSR_CHECK_ARG(x && coef && n > 0, "tpgsr_scale_: bad arguments");
+  int grid = (int)min((long long)4096, (n + 255) / 256);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, coef);
+  TPGSR_LAUNCH_CHECK("tpgsr_scale_");
+}

@@ -1,0 +1,619 @@
+"""Static execution plans for the TSRN super-resolution network (forward + hand-scheduled backward).
+
+The reference expresses the network as ~120 small nn.Modules whose forward/backward PyTorch turns into several hundred
+ATen/cuDNN launches plus permute/contiguous copies (model/tsrn.py:62-78, :373-394, :491-508).  Here the whole network
+is ONE recorded list of C-ABI kernel launches per (batch, height, width, mode): activations live in NHWC workspaces
+allocated once, train-mode BatchNorm / mish / residual adds ride on the consumer conv's tile loader, parameter
+gradients are written straight into a flat gradient arena (one RCCL all-reduce bucket, one fused Adam), and the plan
+replays with no Python tensor bookkeeping -- which also makes it capturable into a hipGraph.
+
+Module layout / parameter names stay the reference's (tpgsr_amd/model/tsrn.py), so checkpoints interchange.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import kernels as K
+from ._lib import PackDesc
+from .kernels import ConvGeom, Plan, recording
+
+F32 = torch.float32
+
+
+# =================================================================================================================
+# flat parameter / gradient arenas
+# =================================================================================================================
+class ParamArena:
+    """All parameters of a module as views of ONE flat fp32 buffer (and their .grad as views of a second one)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.flat: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+        self.offsets: Dict[str, int] = {}
+        self.numel = 0
+
+    def ensure(self, device) -> bool:
+        """(Re)build the arenas if the parameters are not (any more) views of them on `device`.  True if rebuilt."""
+        params = list(self.module.named_parameters())
+        ok = self.flat is not None and self.flat.device == device
+        if ok:
+            base = self.flat.data_ptr()
+            for name, p in params:
+                if name not in self.offsets or p.data_ptr() != base + 4 * self.offsets[name] or p.dtype != F32:
+                    ok = False
+                    break
+        if ok:
+            return False
+        off = 0
+        self.offsets = {}
+        for name, p in params:
+            if p.dtype != F32:
+                raise TypeError(f"tpgsr_amd runs fp32 parameters (got {p.dtype} for {name})")
+            self.offsets[name] = off
+            off += (p.numel() + 3) // 4 * 4  # every tensor stays 16-byte aligned
+        self.numel = off
+        flat = torch.zeros(off, dtype=F32, device=device)
+        grad = torch.zeros(off, dtype=F32, device=device)
+        with torch.no_grad():
+            for name, p in params:
+                o, n = self.offsets[name], p.numel()
+                flat[o:o + n].copy_(p.data.reshape(-1).to(device))
+                p.data = flat[o:o + n].view(p.shape)
+                p.grad = grad[o:o + n].view(p.shape)
+        self.flat, self.grad = flat, grad
+        return True
+
+    def attach_grads(self) -> bool:
+        """Re-attach .grad views after an optimizer.zero_grad(set_to_none=True); the arena is zeroed in that case."""
+        fresh = False
+        base = self.grad.data_ptr()
+        for name, p in self.module.named_parameters():
+            o, n = self.offsets[name], p.numel()
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                if not fresh:
+                    self.grad.zero_()
+                    fresh = True
+                p.grad = self.grad[o:o + n].view(p.shape)
+        return fresh
+
+
+class _Ws:
+    """Named workspace tensors (allocated once per plan set)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t: Dict[str, torch.Tensor] = {}
+
+    def __call__(self, name, *shape, dtype=F32):
+        t = self.t.get(name)
+        if t is None:
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
+            self.t[name] = t
+        assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), shape)
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+
+# =================================================================================================================
+# layers: parameters + packed operands + launch helpers
+# =================================================================================================================
+class ConvLayer:
+    def __init__(self, eng, wname: str, bname: Optional[str], KH=1, KW=1, pad_h=0, pad_w=0, wscale=1.0, tail=False,
+                 need_dgrad=True):
+        self.eng, self.wname, self.bname, self.tail, self.wscale = eng, wname, bname, tail, wscale
+        self.w = eng.P[wname]
+        self.b = eng.P[bname] if bname else None
+        dev = eng.device
+        if tail:  # folded 9x9 C->Co conv: a 9x1 conv with KS*Co output columns
+            Co, Cc, KS, _ = self.w.shape
+            self.Co, self.KS = Co, KS
+            self.Cout, self.Cin, self.KH, self.KW, self.pad_h, self.pad_w = KS * Co, Cc, KS, 1, KS // 2, 0
+        else:
+            self.Cout, self.Cin = self.w.shape[0], self.w.shape[1]
+            self.KH, self.KW, self.pad_h, self.pad_w = KH, KW, pad_h, pad_w
+        Kd = self.KH * self.KW * self.Cin
+        self.wt_f = torch.empty(Kd, self.Cout, dtype=F32, device=dev)
+        self.wt_d = torch.empty(self.KH * self.KW * self.Cout, self.Cin, dtype=F32, device=dev) if need_dgrad else None
+        if tail:
+            eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Co, Cin=self.Cin, KH=self.KS, KW=self.KS, kind=1)
+        else:
+            eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=KH, KW=KW, kind=0,
+                         f_ld=self.Cout, wscale=wscale)
+
+    def geom(self, N, H, W) -> ConvGeom:
+        return ConvGeom(N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.pad_h, self.pad_w)
+
+    def fwd(self, N, H, W, x, out, *, use_bias=True, **kw) -> ConvGeom:
+        g = self.geom(N, H, W)
+        K.conv_fwd(K.make_conv_args(g, x, self.wt_f, out, bias=self.b if (use_bias and not self.tail) else None, **kw))
+        return g
+
+    def dgrad(self, N, H, W, dy, dx, **kw):
+        """dx[N][H][W][Cin] = conv(dy[N][OH][OW][Cout], wt_d)"""
+        K.conv_fwd(K.make_conv_args(self.geom(N, H, W).dgrad(), dy, self.wt_d, dx, **kw))
+
+    def wgrad(self, N, H, W, x, dy, *, loader: dict = None, dy_kw: dict = None):
+        """dW += A^T dy and db += colsum(dy), straight into the gradient arena."""
+        eng = self.eng
+        g = self.geom(N, H, W)
+        Z = K.wgrad_splits(g.M, g.K, g.Cout)
+        part = eng.scratch("wgrad_part", Z * g.K * g.Cout)
+        has_b = self.b is not None and not self.tail
+        dbp = eng.scratch("wgrad_dbpart", Z * g.Cout) if has_b else None
+        ca = K.make_conv_args(g, x, **(loader or {}))
+        K.conv_wgrad(K.make_wgrad_args(ca, dy, part, dbp, **(dy_kw or {})))
+        K.wgrad_reduce(part, dbp, Z, g, eng.G[self.wname], eng.G[self.bname] if has_b else None,
+                       layout=2 if self.tail else 0, accumulate=True, gscale=self.wscale)
+
+
+class BNLayer:
+    def __init__(self, eng, prefix: str):
+        self.eng, self.prefix = eng, prefix
+        self.gamma, self.beta = eng.P[prefix + ".weight"], eng.P[prefix + ".bias"]
+        self.rm, self.rv = eng.B[prefix + ".running_mean"], eng.B[prefix + ".running_var"]
+        self.C = C_ = self.gamma.numel()
+        dev = eng.device
+        self.scale = torch.empty(C_, dtype=F32, device=dev)
+        self.shift = torch.empty(C_, dtype=F32, device=dev)
+        self.save_mean = torch.empty(C_, dtype=F32, device=dev)
+        self.save_rstd = torch.empty(C_, dtype=F32, device=dev)
+        self.coef = torch.empty(3, C_, dtype=F32, device=dev)
+
+    def partial(self, M):
+        """scratch for the producing conv's epilogue statistics"""
+        nblk = (M + 63) // 64
+        return self.eng.scratch("bn_partial", nblk * 2 * self.C), nblk
+
+    def finalize(self, M, conv_bias, training):
+        if training:
+            part, nblk = self.partial(M)
+            K.bn_finalize(part, nblk, self.C, M, conv_bias, self.gamma, self.beta, self.rm, self.rv, self.scale, self.shift,
+                          self.save_mean, self.save_rstd)
+        else:
+            K.bn_finalize(None, 0, self.C, 0, None, self.gamma, self.beta, self.rm, self.rv, self.scale, self.shift,
+                          eval_mode=True)
+
+    @property
+    def loader(self):
+        return dict(in_scale=self.scale, in_shift=self.shift)
+
+    def backward(self, da, da2, y, M, act, dy):
+        """dy = dL/d(pre-BN y) from da (+da2) = dL/d act(BN(y)); accumulates dgamma/dbeta into the arena."""
+        eng = self.eng
+        nblk = min(1024, max(1, M // 64))
+        part = eng.scratch("bnb_partial", nblk * 2 * self.C)
+        K.bn_bwd_reduce(da, da2, y, M, self.C, self.scale, self.shift, self.save_mean, self.save_rstd, act, part, nblk)
+        K.bn_bwd_finalize(part, nblk, self.C, M, self.gamma, self.save_mean, self.save_rstd, eng.G[self.prefix + ".weight"],
+                          eng.G[self.prefix + ".bias"], self.coef, accumulate=True)
+        K.bn_bwd_apply(da, da2, y, M, self.C, self.scale, self.shift, act, self.coef, dy)
+
+
+class GruLayer:
+    """GruBlock (model/tsrn.py:491-508): 1x1 conv -> bidirectional GRU(hidden 32) along one spatial axis.
+    axis 0: sequences along W (gru2); axis 1: along H (gru1, the reference's transpose(-1,-2))."""
+
+    def __init__(self, eng, prefix: str, axis: int):
+        self.eng, self.prefix, self.axis = eng, prefix, axis
+        self.conv = ConvLayer(eng, prefix + ".conv1.weight", prefix + ".conv1.bias")
+        P, dev = eng.P, eng.device
+        gp = prefix + ".gru."
+        self.gp = gp
+        hid = P[gp + "weight_hh_l0"].shape[1]
+        if hid != 32:
+            raise NotImplementedError("the fused BiGRU kernel is specialised for hidden_units=32 (the reference default)")
+        self.Cg = Cg = P[gp + "weight_ih_l0"].shape[1]
+        self.wih_f = torch.empty(Cg, 192, dtype=F32, device=dev)   # forward operand [K=Cg][192]
+        self.wih_d = torch.empty(192, Cg, dtype=F32, device=dev)   # dgrad operand  [K'=192][Cg]
+        self.bih = torch.empty(192, dtype=F32, device=dev)
+        self.whh = torch.empty(2, 96, 32, dtype=F32, device=dev)
+        self.bhh = torch.empty(2, 96, dtype=F32, device=dev)
+        for d, suf in enumerate(("", "_reverse")):
+            eng.add_pack(P[gp + "weight_ih_l0" + suf], self.wih_f, self.wih_d[d * 96:(d + 1) * 96], Cout=96, Cin=Cg, KH=1, KW=1,
+                         kind=0, f_ld=192, f_coff=d * 96)
+            eng.add_pack(P[gp + "bias_ih_l0" + suf], self.bih[d * 96:(d + 1) * 96], None, kind=2)
+            eng.add_pack(P[gp + "weight_hh_l0" + suf], self.whh[d], None, kind=2)
+            eng.add_pack(P[gp + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
+
+    def fwd(self, N, H, W, x, u, gi, h, **loader):
+        """u = conv1x1(loader(x)); gi = u W_ih^T + b_ih; h = BiGRU(gi)"""
+        self.conv.fwd(N, H, W, x, u, **loader)
+        g = ConvGeom(N, H, W, self.Cg, 192)
+        K.conv_fwd(K.make_conv_args(g, u, self.wih_f, gi, bias=self.bih))
+        K.bigru_fwd(gi, self.whh, self.bhh, N, H, W, self.axis, h)
+
+    def bwd(self, N, H, W, x, u, gi, h, dh, dh2, dgi, dgh, du, dx, **loader):
+        """all parameter gradients of the block + dx = dL/d loader(x)"""
+        eng, G, gp = self.eng, self.eng.G, self.gp
+        K.bigru_bwd(gi, h, dh, dh2, self.whh, self.bhh, N, H, W, self.axis, dgi, dgh)
+        M = N * H * W
+        for d, suf in enumerate(("", "_reverse")):
+            sgn = 1 if d == 0 else -1
+            # hidden side: dW_hh[d] = dgh[:, d]^T h_prev(d), h_prev = h shifted one step against the scan direction
+            gh = ConvGeom(N, H, W, 32, 96, 1, 1, sgn if self.axis == 1 else 0, sgn if self.axis == 0 else 0, H, W)
+            Z = K.wgrad_splits(gh.M, gh.K, 96)
+            part = eng.scratch("wgrad_part", Z * 32 * 96)
+            dbp = eng.scratch("wgrad_dbpart", Z * 96)
+            ca = K.make_conv_args(gh, h, in_ld=64, in_coff=32 * d)
+            K.conv_wgrad(K.make_wgrad_args(ca, dgh, part, dbp, dy_ld=192, dy_coff=96 * d))
+            K.wgrad_reduce(part, dbp, Z, gh, G[gp + "weight_hh_l0" + suf], G[gp + "bias_hh_l0" + suf], accumulate=True)
+            # input side: dW_ih[d] = dgi[:, d]^T u, db_ih[d] = colsum
+            gi_ = ConvGeom(N, H, W, self.Cg, 96)
+            Z = K.wgrad_splits(gi_.M, gi_.K, 96)
+            part = eng.scratch("wgrad_part", Z * self.Cg * 96)
+            dbp = eng.scratch("wgrad_dbpart", Z * 96)
+            ca = K.make_conv_args(gi_, u)
+            K.conv_wgrad(K.make_wgrad_args(ca, dgi, part, dbp, dy_ld=192, dy_coff=96 * d))
+            K.wgrad_reduce(part, dbp, Z, gi_, G[gp + "weight_ih_l0" + suf], G[gp + "bias_ih_l0" + suf], accumulate=True)
+        # du = dgi W_ih  (dgrad of the input projection), then the 1x1 conv
+        K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cg), dgi, self.wih_d, du))
+        self.conv.wgrad(N, H, W, x, du, loader=loader)
+        if dx is not None:
+            self.conv.dgrad(N, H, W, du, dx)
+
+
+# =================================================================================================================
+# TSRN engine
+# =================================================================================================================
+class TSRNEngine:
+    """Owns the arenas, packed operands, workspaces and the recorded plans of one TSRN module."""
+
+    STN_POOLS = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (1, 1)]
+
+    def __init__(self, module: torch.nn.Module, grid_align_corners: bool = False):
+        self.module = module
+        self.arena = ParamArena(module)
+        self.device = None
+        self.grid_align_corners = grid_align_corners
+        self._plans: Dict[tuple, dict] = {}
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self._pack: List[tuple] = []
+
+    # ---- scratch buffers live only between consecutive launches (stream-ordered reuse) ----------------------
+    def scratch(self, name, numel):
+        t = self._scratch.get(name)
+        if t is None or t.numel() < numel:
+            if K._REC is not None and getattr(K._REC, "final", False):
+                raise RuntimeError(f"scratch '{name}' would be re-allocated while recording the final plan")
+            t = torch.empty(max(int(numel), 1), dtype=F32, device=self.device)
+            self._scratch[name] = t
+        return t
+
+    def add_pack(self, src, dst_f, dst_d, Cout=0, Cin=0, KH=1, KW=1, kind=0, f_ld=0, f_coff=0, wscale=1.0):
+        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale))
+
+    def _finish_pack_table(self):
+        n = len(self._pack)
+        arr = (PackDesc * n)()
+        blk = 0
+        self._pack_keep = []
+        for i, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale) in enumerate(self._pack):
+            d = arr[i]
+            d.src, d.dst_f = src.data_ptr(), dst_f.data_ptr()
+            d.dst_d = dst_d.data_ptr() if dst_d is not None else None
+            d.Cout, d.Cin, d.KH, d.KW, d.kind, d.f_ld, d.f_coff, d.wscale = Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale
+            d.numel, d.blk0 = src.numel(), blk
+            blk += (src.numel() + 255) // 256
+            self._pack_keep += [src, dst_f, dst_d]
+        raw = bytes(arr)
+        self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._pack_n, self._pack_blocks = n, blk
+
+    def pack_all(self):
+        K.pack_program(self._pack_dev, self._pack_n, self._pack_blocks)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def bind(self, device):
+        rebuilt = self.arena.ensure(device)
+        if not rebuilt and self.device == device:
+            return
+        self.device = device
+        self._plans.clear()
+        self._scratch.clear()
+        self._pack = []
+        m = self.module
+        self.P = dict(m.named_parameters())
+        self.B = dict(m.named_buffers())
+        self.G = {}
+        for name, p in self.P.items():
+            o = self.arena.offsets[name]
+            self.G[name] = self.arena.grad[o:o + p.numel()]
+        for name, b in self.B.items():
+            if b.device != device:
+                raise RuntimeError(f"buffer {name} is on {b.device}, parameters on {device}: call module.to(device) first")
+        self._build_layers()
+        self._finish_pack_table()
+
+    def _build_layers(self):
+        m = self.module
+        self.in_planes = m.in_planes
+        self.srb = m.srb_nums
+        self.stn = bool(m.stn)
+        self.C = self.P["block1.0.weight"].shape[0]
+        self.block1 = ConvLayer(self, "block1.0.weight", "block1.0.bias", 9, 9, 4, 4, need_dgrad=self.stn)
+        self.rrb = []
+        for i in range(self.srb):
+            p = f"block{i + 2}"
+            self.rrb.append(dict(
+                conv1=ConvLayer(self, p + ".conv1.weight", p + ".conv1.bias", 3, 3, 1, 1), bn1=BNLayer(self, p + ".bn1"),
+                conv2=ConvLayer(self, p + ".conv2.weight", p + ".conv2.bias", 3, 3, 1, 1), bn2=BNLayer(self, p + ".bn2"),
+                gru1=GruLayer(self, p + ".gru1", axis=1), gru2=GruLayer(self, p + ".gru2", axis=0)))
+        k7 = f"block{self.srb + 2}"
+        self.conv7 = ConvLayer(self, k7 + ".0.weight", k7 + ".0.bias", 3, 3, 1, 1)
+        self.bn7 = BNLayer(self, k7 + ".1")
+        k8 = f"block{self.srb + 3}"
+        self.n_up = len([k for k in self.P if k.startswith(k8 + ".") and k.endswith(".conv.weight")])
+        if self.n_up != 1:
+            raise NotImplementedError("scale_factor != 2 is not on the TPGSR hot path (reference configs use 2)")
+        self.up = ConvLayer(self, k8 + ".0.conv.weight", k8 + ".0.conv.bias", 3, 3, 1, 1)
+        self.tail = ConvLayer(self, f"{k8}.{self.n_up}.weight", None, tail=True)
+        self.tail_bias = self.P[f"{k8}.{self.n_up}.bias"]
+        if self.stn:
+            self.stn_convs, self.stn_bns = [], []
+            for i in range(6):
+                cp = f"stn_head.stn_convnet.{2 * i}"
+                self.stn_convs.append(ConvLayer(self, cp + ".0.weight", cp + ".0.bias", 3, 3, 1, 1, need_dgrad=(i > 0)))
+                self.stn_bns.append(BNLayer(self, cp + ".1"))
+            # fc1 sees the NCHW flatten (c*2 + w) of a [N][256][1][2] map == a valid 1x2 conv over NHWC [N][1][2][256]
+            w1 = self.P["stn_head.stn_fc1.0.weight"]
+            self.fc1 = _FC1AsConv(self, "stn_head.stn_fc1.0.weight", "stn_head.stn_fc1.0.bias", w1.shape[0], w1.shape[1] // 2)
+            self.bnf = BNLayer(self, "stn_head.stn_fc1.1")
+            self.fc2 = ConvLayer(self, "stn_head.stn_fc2.weight", "stn_head.stn_fc2.bias", wscale=0.1)  # fc2(0.1*feat), stn_head.py:100
+            self.tps_inv = self.B["tps.inverse_kernel"]
+            self.tps_repr = self.B["tps.target_coordinate_repr"]
+            self.NC = self.B["tps.target_control_points"].shape[0]
+
+    # ------------------------------------------------------------------------------------------------------------
+    def plans(self, N, H, W, training):
+        key = (N, H, W, bool(training))
+        if key not in self._plans:
+            # pass 1 sizes the stream-ordered scratch buffers, pass 2 records against their final addresses
+            ws = _Ws(self.device)
+            self._record(N, H, W, training, ws, final=False)
+            self._plans[key] = self._record(N, H, W, training, ws, final=True)
+        return self._plans[key]
+
+    def _record(self, N, H, W, training, ws, final):
+        fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
+        fwd.final = bwd.final = final
+        with recording(fwd):
+            self._record_fwd(N, H, W, training, ws)
+        if training:
+            with recording(bwd):
+                self._record_bwd(N, H, W, ws)
+        return dict(fwd=fwd, bwd=bwd, ws=ws)
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def _record_fwd(self, N, H, W, training, ws):
+        Cc, Ci = self.C, self.in_planes
+        P1 = N * H * W
+        self.pack_all()
+        x = ws("x_nhwc", P1, Ci)
+        K.nchw_to_nhwc(K.DynPtr("x"), N, Ci, H, W, x)
+        xin = x
+        if self.stn and training:
+            xin = self._record_stn_fwd(N, H, W, x, ws)
+        c1 = ws("c1", P1, Cc)
+        b1 = ws("b1", P1, Cc)
+        self.block1.fwd(N, H, W, xin, c1)
+        K.prelu_fwd(c1, self.P["block1.1.weight"], P1 * Cc, b1)
+        cur = b1
+        for i, L in enumerate(self.rrb):
+            t = f"r{i}_"
+            y1, y2 = ws(t + "y1", P1, Cc), ws(t + "y2", P1, Cc)
+            u1, gi1, h1 = ws(t + "u1", P1, Cc), ws(t + "gi1", P1, 192), ws(t + "h1", P1, Cc)
+            u2, gi2, out = ws(t + "u2", P1, Cc), ws(t + "gi2", P1, 192), ws(t + "out", P1, Cc)
+            part, _ = L["bn1"].partial(P1)
+            L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None)
+            L["bn1"].finalize(P1, L["conv1"].b, training)
+            L["conv2"].fwd(N, H, W, y1, y2, in_act="mish", bn_partial=part if training else None, **L["bn1"].loader)
+            L["bn2"].finalize(P1, L["conv2"].b, training)
+            L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, **L["bn2"].loader)
+            L["gru2"].fwd(N, H, W, cur, u2, gi2, out, in2=h1)
+            cur = out
+        y7 = ws("y7", P1, Cc)
+        part, _ = self.bn7.partial(P1)
+        self.conv7.fwd(N, H, W, cur, y7, bn_partial=part if training else None)
+        self.bn7.finalize(P1, self.conv7.b, training)
+        ups = ws("ups", 4 * P1, Cc)                      # pre-mish, pixel-shuffled [N][2H][2W][C]
+        self.up.fwd(N, H, W, y7, ups, in2=b1, out_ps=True, **self.bn7.loader)
+        Pt = ws("Pt", 4 * P1, self.tail.Cout)
+        self.tail.fwd(N, 2 * H, 2 * W, ups, Pt, in_act="mish")
+        K.tail_shiftsum_tanh(Pt, self.tail_bias, N, 2 * H, 2 * W, self.tail.Co, self.tail.KS, K.DynPtr("sr"))
+
+    def _stn_dims(self, H, W):
+        dims = []
+        h, w = H, W
+        for ph, pw in self.STN_POOLS:
+            dims.append((h, w))
+            h, w = h // ph, w // pw
+        if (h, w) != (1, 2):
+            raise ValueError(f"STN head needs a {16}x{64} low-resolution input (got {H}x{W}): its fc1 expects a 1x2 map")
+        return dims
+
+    def _record_stn_fwd(self, N, H, W, x, ws):
+        dims = self._stn_dims(H, W)
+        cur = x
+        for i, (conv, bn, (h, w), (ph, pw)) in enumerate(zip(self.stn_convs, self.stn_bns, dims, self.STN_POOLS)):
+            M = N * h * w
+            s = ws(f"stn_s{i}", M, conv.Cout)
+            part, _ = bn.partial(M)
+            conv.fwd(N, h, w, cur, s, bn_partial=part)
+            bn.finalize(M, conv.b, True)
+            if i < 5:
+                a = ws(f"stn_a{i}", N * (h // ph) * (w // pw), conv.Cout)
+                K.affine_act_pool(s, N, h, w, conv.Cout, bn.scale, bn.shift, "relu", ph, pw, a)
+                cur = a
+            else:
+                cur = s  # relu(bn(.)) of the last stage rides on fc1's loader
+        f1 = ws("stn_f1", N, self.fc1.Cout)
+        part, _ = self.bnf.partial(N)
+        self.fc1.fwd(N, 1, 2, cur, f1, in_act="relu", bn_partial=part, **self.stn_bns[5].loader)
+        self.bnf.finalize(N, self.fc1.b, True)
+        ctrl = ws("stn_ctrl", N, 2 * self.NC)
+        self.fc2.fwd(N, 1, 1, f1, ctrl, in_act="relu", **self.bnf.loader)
+        grid, src = ws("stn_grid", N, H * W, 2), ws("stn_src", N, H * W, 2)
+        K.tps_grid_fwd(ctrl, self.tps_inv, self.tps_repr, N, H * W, self.NC, grid, src)
+        xr = ws("xr", N * H * W, self.in_planes)
+        K.grid_sample_fwd(x, grid, N, H, W, self.in_planes, H, W, self.grid_align_corners, xr)
+        return xr
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def _record_bwd(self, N, H, W, ws):
+        Cc, Ci = self.C, self.in_planes
+        P1, P4 = N * H * W, 4 * N * H * W
+        H2, W2 = 2 * H, 2 * W
+        t = ws.t
+        tl = self.tail
+        # tail: dP, bias grad, weight grad, d mish(ups)
+        nblk = K.tail_bwd_blocks(N, H2, W2, tl.Co, tl.KS)
+        dPt = ws("dPt", P4, tl.Cout)
+        dbp = self.scratch("tail_dbp", nblk * tl.Co)
+        K.tail_bwd(K.DynPtr("sr"), K.DynPtr("dsr"), N, H2, W2, tl.Co, tl.KS, dPt, dbp, nblk)
+        K.reduce_partials(dbp, nblk, tl.Co, self.G[tl.wname.replace(".weight", ".bias")], accumulate=True)
+        tl.wgrad(N, H2, W2, t["ups"], dPt, loader=dict(in_act="mish"))
+        dm = ws("d_ups", P4, Cc)
+        tl.dgrad(N, H2, W2, dPt, dm)
+        K.act_bwd(t["ups"], dm, P4 * Cc, "mish", dm)                      # in place: d(ups), pixel-shuffled layout
+        # upsample conv: input was bn7(y7) + b1
+        self.up.wgrad(N, H, W, t["y7"], dm, loader=dict(in2=t["b1"], **self.bn7.loader), dy_kw=dict(dy_ps=True))
+        d_s = ws("d_s", P1, Cc)                                           # = d(bn7 out) = one of b1's gradients
+        self.up.dgrad(N, H, W, dm, d_s, in_ps=True)
+        dy = ws("dy", P1, Cc)
+        self.bn7.backward(d_s, None, t["y7"], P1, "none", dy)
+        gA, gB = ws("gA", P1, Cc), ws("gB", P1, Cc)
+        last_out = t[f"r{self.srb - 1}_out"] if self.srb else t["b1"]
+        self.conv7.wgrad(N, H, W, last_out, dy)
+        self.conv7.dgrad(N, H, W, dy, gA)
+        have_B = False
+        dgi, dgh = ws("dgi", P1, 192), ws("dgh", P1, 192)
+        du, da = ws("du", P1, Cc), ws("da", P1, Cc)
+        for i in range(self.srb - 1, -1, -1):
+            L = self.rrb[i]
+            p = f"r{i}_"
+            X = t[f"r{i - 1}_out"] if i > 0 else t["b1"]
+            y1, y2, u1, gi1, h1, u2, gi2, out = (t[p + n] for n in ("y1", "y2", "u1", "gi1", "h1", "u2", "gi2", "out"))
+            # gru2 (input X + h1): parameter grads + d(X + h1) -> gA (incoming gA/gB are dead after the scan)
+            L["gru2"].bwd(N, H, W, X, u2, gi2, out, gA, gB if have_B else None, dgi, dgh, du, gA, in2=h1)
+            # gru1 (input bn2(y2)): dh = gA
+            L["gru1"].bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
+            L["bn2"].backward(da, None, y2, P1, "none", dy)
+            L["conv2"].wgrad(N, H, W, y1, dy, loader=dict(in_act="mish", **L["bn1"].loader))
+            L["conv2"].dgrad(N, H, W, dy, da)                              # d mish(bn1(y1))
+            L["bn1"].backward(da, None, y1, P1, "mish", dy)
+            L["conv1"].wgrad(N, H, W, X, dy)
+            L["conv1"].dgrad(N, H, W, dy, gB)                              # second gradient path into X
+            have_B = True
+        # b1 receives d_s (long skip) + gA (+ gB)
+        if have_B:
+            K.add(gA, gB, P1 * Cc, gA)
+        dc1 = ws("dc1", P1, Cc)
+        nb = 256
+        dap = self.scratch("prelu_dap", nb)
+        K.prelu_bwd(t["c1"], self.P["block1.1.weight"], gA, d_s, P1 * Cc, dc1, dap, nb)
+        K.reduce_partials(dap, nb, 1, self.G["block1.1.weight"], accumulate=True)
+        xin = t["xr"] if self.stn else t["x_nhwc"]
+        self.block1.wgrad(N, H, W, xin, dc1)
+        if self.stn:
+            self._record_stn_bwd(N, H, W, dc1, ws)
+
+    def _record_stn_bwd(self, N, H, W, dc1, ws):
+        t = ws.t
+        Ci = self.in_planes
+        dxr = ws("dxr", N * H * W, Ci)
+        self.block1.dgrad(N, H, W, dc1, dxr)
+        dgrid = ws("stn_dgrid", N, H * W, 2)
+        K.grid_sample_bwd(t["x_nhwc"], t["stn_grid"], dxr, N, H, W, Ci, H, W, self.grid_align_corners, None, dgrid)
+        dctrl = ws("stn_dctrl", N, 2 * self.NC)
+        K.tps_grid_bwd(dgrid, t["stn_src"], self.tps_inv, self.tps_repr, N, H * W, self.NC, dctrl)
+        f1 = t["stn_f1"]
+        self.fc2.wgrad(N, 1, 1, f1, dctrl, loader=dict(in_act="relu", **self.bnf.loader))
+        dfa = ws("stn_dfa", N, self.fc1.Cout)
+        self.fc2.dgrad(N, 1, 1, dctrl, dfa)                                # d relu(bn(f1))  (0.1 already in wt_d)
+        df1 = ws("stn_df1", N, self.fc1.Cout)
+        self.bnf.backward(dfa, None, f1, N, "relu", df1)
+        s5 = t["stn_s5"]
+        self.fc1.wgrad(N, 1, 2, s5, df1, loader=dict(in_act="relu", **self.stn_bns[5].loader))
+        dims = self._stn_dims(H, W)
+        dact = ws("stn_da5", N * 2, self.stn_convs[5].Cout)                # d relu(bn5(s5)), [N][1][2][256]
+        self.fc1.dgrad(N, 1, 2, df1, dact)
+        for i in range(5, -1, -1):
+            conv, bn = self.stn_convs[i], self.stn_bns[i]
+            h, w = dims[i]
+            ph, pw = self.STN_POOLS[i]
+            M = N * h * w
+            s = t[f"stn_s{i}"]
+            ds = ws(f"stn_ds{i}", M, conv.Cout)
+            if i == 5:
+                bn.backward(dact, None, s, M, "relu", ds)
+            else:
+                dz = ws(f"stn_dz{i}", M, conv.Cout)
+                K.affine_act_pool_bwd(s, dact, N, h, w, conv.Cout, bn.scale, bn.shift, "relu", ph, pw, dz)
+                bn.backward(dz, None, s, M, "none", ds)
+            xin = t[f"stn_a{i - 1}"] if i > 0 else t["x_nhwc"]
+            conv.wgrad(N, h, w, xin, ds)
+            if i > 0:
+                dact = ws(f"stn_da{i - 1}", N * h * w, self.stn_convs[i - 1].Cout)
+                conv.dgrad(N, h, w, ds, dact)
+
+    # ---- execution -----------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if prior is not None:
+            raise NotImplementedError("text-prior (TSRN_TL) plan: see engine_tl (round-1 scope is config C2 first)")
+        if x.dim() != 4 or x.shape[1] != self.module.in_planes:
+            raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
+        self.bind(x.device)
+        N, _, H, W = x.shape
+        pl = self.plans(N, H, W, training)
+        x = x.contiguous().float()
+        sr = torch.empty(N, self.in_planes, 2 * H, 2 * W, dtype=F32, device=x.device)
+        fwd = pl["fwd"]
+        fwd.set_ptr("x", x.data_ptr())
+        fwd.set_ptr("sr", sr.data_ptr())
+        fwd.run()
+        if training:
+            self._pending_batches += 1   # num_batches_tracked is bookkeeping only (momentum is fixed): flushed lazily
+        return sr
+
+    _pending_batches = 0
+
+    def flush_counters(self):
+        if self._pending_batches and self.device is not None:
+            for n, b in self.B.items():
+                if n.endswith("num_batches_tracked"):
+                    b += self._pending_batches
+        self._pending_batches = 0
+
+    def backward(self, x_shape, sr: torch.Tensor, dsr: torch.Tensor):
+        N, _, H, W = x_shape
+        pl = self.plans(N, H, W, True)
+        self.arena.attach_grads()
+        bwd = pl["bwd"]
+        dsr = dsr.contiguous().float()
+        bwd.set_ptr("sr", sr.data_ptr())
+        bwd.set_ptr("dsr", dsr.data_ptr())
+        bwd.run()
+        return None
+
+
+class _FC1AsConv(ConvLayer):
+    """STN fc1 (model/stn_head.py:48): Linear(2*256, 512) over the NCHW flatten of a [N][256][1][2] map, run as a valid
+    1x2 conv over the NHWC map: weight[:, c*2 + w] == conv_weight[:, c, 0, w]."""
+
+    def __init__(self, eng, wname, bname, Cout, Cin):
+        self.eng, self.wname, self.bname, self.tail, self.wscale = eng, wname, bname, False, 1.0
+        self.w = eng.P[wname]
+        self.b = eng.P[bname]
+        self.Cout, self.Cin, self.KH, self.KW, self.pad_h, self.pad_w = Cout, Cin, 1, 2, 0, 0
+        dev = eng.device
+        self.wt_f = torch.empty(2 * Cin, Cout, dtype=F32, device=dev)
+        self.wt_d = torch.empty(2 * Cout, Cin, dtype=F32, device=dev)
+        eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=Cout, Cin=Cin, KH=1, KW=2, kind=0, f_ld=Cout)

@@ -1,0 +1,338 @@
+"""Tensor-level wrappers over the C ABI (one Python function per kernel entry point).
+
+All tensors are fp32 CUDA tensors; activations are NHWC-contiguous (shape is informational only: the kernels get
+explicit geometry).  Launches go to the current torch stream, so they compose with torch ops and can be captured
+into a hipGraph (torch.cuda.graph).  No fallbacks: a failed/rejected launch raises TpgsrKernelError."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, WgradArgs, act_code, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Plan:
+    """A recorded, replayable list of kernel launches (static pointers + geometry).  Built once per shape by running
+    the wrappers below under ``with recording(plan)``; ``run()`` replays it on the current stream with no Python
+    argument marshalling beyond the ctypes call itself -- the host-side analogue of a hipGraph, and capturable into
+    one (torch.cuda.graph)."""
+
+    def __init__(self, name=""):
+        self.name = name
+        self.ops = []      # [name, cfunc, [args...]]
+        self.keep = []     # tensors / arg structs referenced by raw pointer
+        self.dyn = {}      # key -> [(op index, arg index)]
+
+    def mark_dynamic(self, key):
+        """The NEXT recorded pointer argument equal to the DynPtr placeholder `key` becomes patchable."""
+        return DynPtr(key)
+
+    def set_ptr(self, key, ptr):
+        for oi, ai in self.dyn[key]:
+            self.ops[oi][2][ai] = ptr
+
+    def run(self):
+        s = _stream()
+        for name, fn, args in self.ops:
+            rc = fn(*args, s)
+            if rc:
+                check(rc, f"{self.name}:{name}")
+
+    def __len__(self):
+        return len(self.ops)
+
+
+class DynPtr:
+    def __init__(self, key):
+        self.key = key
+
+
+_REC: Optional[Plan] = None
+
+
+class recording:
+    def __init__(self, plan: Plan):
+        self.plan = plan
+
+    def __enter__(self):
+        global _REC
+        assert _REC is None, "nested recording"
+        _REC = self.plan
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        return False
+
+
+def _launch(name, *args):
+    fn = getattr(_lib.load(), name)
+    if _REC is not None:
+        args = list(args)
+        oi = len(_REC.ops)
+        for ai, a in enumerate(args):
+            if isinstance(a, DynPtr):
+                _REC.dyn.setdefault(a.key, []).append((oi, ai))
+                args[ai] = None
+        _REC.ops.append([name, fn, args])
+        return
+    check(fn(*args, _stream()), name)
+
+
+def _p(t):
+    if t is None or isinstance(t, (int, DynPtr)):
+        return t
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8) and t.is_contiguous(), \
+        f"tpgsr kernels need contiguous fp32 CUDA tensors (got {t.dtype}, cuda={t.is_cuda}, contiguous={t.is_contiguous()})"
+    if _REC is not None:
+        _REC.keep.append(t)
+    return t.data_ptr()
+
+
+@dataclass
+class ConvGeom:
+    """Geometry of one stride-1 convolution call (see tpgsr_conv_args in include/tpgsr_hip.h)."""
+    N: int
+    H: int
+    W: int
+    Cin: int
+    Cout: int
+    KH: int = 1
+    KW: int = 1
+    pad_h: int = 0
+    pad_w: int = 0
+    OH: Optional[int] = None
+    OW: Optional[int] = None
+
+    def __post_init__(self):
+        if self.OH is None:
+            self.OH = self.H + 2 * self.pad_h - self.KH + 1
+        if self.OW is None:
+            self.OW = self.W + 2 * self.pad_w - self.KW + 1
+
+    @property
+    def M(self):
+        return self.N * self.OH * self.OW
+
+    @property
+    def K(self):
+        return self.KH * self.KW * self.Cin
+
+    def dgrad(self) -> "ConvGeom":
+        """Geometry of the data-gradient conv (input = dy, output = dx)."""
+        return ConvGeom(self.N, self.OH, self.OW, self.Cout, self.Cin, self.KH, self.KW,
+                        self.KH - 1 - self.pad_h, self.KW - 1 - self.pad_w, self.H, self.W)
+
+
+def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, in_scale=None, in_shift=None, in_act=None,
+                   in_ps=False, in_ld=None, in_coff=0, in2_ld=None, out_act=None, out_ps=False, out_ld=None, out_coff=0,
+                   bn_partial=None) -> ConvArgs:
+    a = ConvArgs()
+    a.in_, a.in2, a.in_scale, a.in_shift = _p(inp), _p(in2), _p(in_scale), _p(in_shift)
+    a.wt, a.bias, a.out, a.bn_partial = _p(wt), _p(bias), _p(out), _p(bn_partial)
+    a.N, a.H, a.W, a.Cin = g.N, g.H, g.W, g.Cin
+    a.in_ld = g.Cin if in_ld is None else in_ld
+    a.in_coff = in_coff
+    a.in2_ld = g.Cin if in2_ld is None else in2_ld
+    a.in_act = act_code(in_act)
+    a.in_ps = int(bool(in_ps))
+    a.Cout, a.KH, a.KW, a.pad_h, a.pad_w, a.OH, a.OW = g.Cout, g.KH, g.KW, g.pad_h, g.pad_w, g.OH, g.OW
+    a.out_ld = g.Cout if out_ld is None else out_ld
+    a.out_coff = out_coff
+    a.out_act = act_code(out_act)
+    a.out_ps = int(bool(out_ps))
+    return a
+
+
+def conv_fwd(args: ConvArgs):
+    _launch("tpgsr_conv_fwd", C.byref(args))
+
+
+def wgrad_splits(M, K, Cout) -> int:
+    return _lib.load().tpgsr_wgrad_splits(M, K, Cout)
+
+
+def make_wgrad_args(cargs: ConvArgs, dy, part, dbpart=None, *, dy_ld=None, dy_coff=0, dy_ps=False) -> WgradArgs:
+    w = WgradArgs()
+    w.c = cargs
+    w.dy = _p(dy)
+    w.dy_ld = cargs.Cout if dy_ld is None else dy_ld
+    w.dy_coff = dy_coff
+    w.dy_ps = int(bool(dy_ps))
+    w.part = _p(part)
+    w.dbpart = _p(dbpart)
+    return w
+
+
+def conv_wgrad(w: WgradArgs):
+    _launch("tpgsr_conv_wgrad", C.byref(w))
+
+
+def wgrad_reduce(part, dbpart, Z, g: ConvGeom, dw, db=None, *, layout=0, accumulate=True, gscale=1.0):
+    _launch("tpgsr_wgrad_reduce", _p(part), _p(dbpart), Z, g.K, g.Cin, g.Cout, g.KH, g.KW, layout, _p(dw), _p(db),
+                                         int(accumulate), gscale)
+
+
+def pack_conv_weight(w, Cout, Cin, KH, KW, wt_f=None, wt_d=None, *, transposed=False, wscale=1.0):
+    _launch("tpgsr_pack_conv_weight", _p(w), Cout, Cin, KH, KW, int(transposed), wscale, _p(wt_f), _p(wt_d))
+
+
+def pack_tail_weight(w, Co, Cc, KS, wt_f=None, wt_d=None):
+    _launch("tpgsr_pack_tail_weight", _p(w), Co, Cc, KS, _p(wt_f), _p(wt_d))
+
+
+def pack_program(descs_dev, ndesc, total_blocks):
+    _launch("tpgsr_pack_program", _p(descs_dev), ndesc, total_blocks)
+
+
+def copy(src, dst, n):
+    _launch("tpgsr_copy", _p(src), _p(dst), n)
+
+
+def zero(dst, n):
+    _launch("tpgsr_zero", _p(dst), n)
+
+
+# ---- BatchNorm ------------------------------------------------------------------------------------------------
+def bn_finalize(partial, nblk, C_, count, conv_bias, gamma, beta, running_mean, running_var, scale, shift, save_mean=None,
+                save_rstd=None, *, momentum=0.1, eps=1e-5, eval_mode=False):
+    _launch("tpgsr_bn_finalize", _p(partial), nblk, C_, count, _p(conv_bias), _p(gamma), _p(beta), _p(running_mean),
+                                        _p(running_var), momentum, eps, int(eval_mode), _p(scale), _p(shift), _p(save_mean),
+                                        _p(save_rstd))
+
+
+def bn_stats(x, M, C_, partial, nblk, ld=None):
+    _launch("tpgsr_bn_stats", _p(x), M, C_, C_ if ld is None else ld, _p(partial), nblk)
+
+
+def bn_bwd_reduce(da, da2, y, M, C_, scale, shift, save_mean, save_rstd, act, partial, nblk):
+    _launch("tpgsr_bn_bwd_reduce", _p(da), _p(da2), _p(y), M, C_, _p(scale), _p(shift), _p(save_mean), _p(save_rstd),
+                                          act_code(act), _p(partial), nblk)
+
+
+def bn_bwd_finalize(partial, nblk, C_, count, gamma, save_mean, save_rstd, dgamma, dbeta, coef, accumulate=True):
+    _launch("tpgsr_bn_bwd_finalize", _p(partial), nblk, C_, count, _p(gamma), _p(save_mean), _p(save_rstd), _p(dgamma),
+                                            _p(dbeta), int(accumulate), _p(coef))
+
+
+def bn_bwd_apply(da, da2, y, M, C_, scale, shift, act, coef, dy):
+    _launch("tpgsr_bn_bwd_apply", _p(da), _p(da2), _p(y), M, C_, _p(scale), _p(shift), act_code(act), _p(coef), _p(dy))
+
+
+def affine_act_pool(x, N, H, W, C_, scale, shift, act, ph, pw, out):
+    _launch("tpgsr_affine_act_pool", _p(x), N, H, W, C_, _p(scale), _p(shift), act_code(act), ph, pw, _p(out))
+
+
+def affine_act_pool_bwd(x, dout, N, H, W, C_, scale, shift, act, ph, pw, dz):
+    _launch("tpgsr_affine_act_pool_bwd", _p(x), _p(dout), N, H, W, C_, _p(scale), _p(shift), act_code(act), ph, pw, _p(dz))
+
+
+# ---- elementwise ----------------------------------------------------------------------------------------------
+def prelu_fwd(x, alpha, n, y):
+    _launch("tpgsr_prelu_fwd", _p(x), _p(alpha), n, _p(y))
+
+
+def prelu_bwd(x, alpha, dy, dy2, n, dx, dalpha_partial, nblk):
+    _launch("tpgsr_prelu_bwd", _p(x), _p(alpha), _p(dy), _p(dy2), n, _p(dx), _p(dalpha_partial), nblk)
+
+
+def add(a, b, n, out):
+    _launch("tpgsr_add", _p(a), _p(b), n, _p(out))
+
+
+def act_bwd(x, dy, n, act, dx):
+    _launch("tpgsr_act_bwd", _p(x), _p(dy), n, act_code(act), _p(dx))
+
+
+def nchw_to_nhwc(x, N, C_, H, W, out):
+    _launch("tpgsr_nchw_to_nhwc", _p(x), N, C_, H, W, _p(out))
+
+
+def nhwc_to_nchw(x, N, C_, H, W, out):
+    _launch("tpgsr_nhwc_to_nchw", _p(x), N, C_, H, W, _p(out))
+
+
+def reduce_partials(part, Z, n, out, accumulate=True):
+    _launch("tpgsr_reduce_partials", _p(part), Z, n, _p(out), int(accumulate))
+
+
+# ---- GRU ------------------------------------------------------------------------------------------------------
+def bigru_fwd(gi, w_hh, b_hh, N, H, W, axis, h_out):
+    _launch("tpgsr_bigru_fwd", _p(gi), _p(w_hh), _p(b_hh), N, H, W, axis, _p(h_out))
+
+
+def bigru_bwd(gi, h_out, dh_out, dh_out2, w_hh, b_hh, N, H, W, axis, dgi, dgh):
+    _launch("tpgsr_bigru_bwd", _p(gi), _p(h_out), _p(dh_out), _p(dh_out2), _p(w_hh), _p(b_hh), N, H, W, axis, _p(dgi),
+                                      _p(dgh))
+
+
+# ---- STN ------------------------------------------------------------------------------------------------------
+def tps_grid_fwd(ctrl, inv_kernel, coord_repr, N, HW, NC, grid, src=None):
+    _launch("tpgsr_tps_grid_fwd", _p(ctrl), _p(inv_kernel), _p(coord_repr), N, HW, NC, _p(grid), _p(src))
+
+
+def tps_grid_bwd(dgrid, src, inv_kernel, coord_repr, N, HW, NC, dctrl):
+    _launch("tpgsr_tps_grid_bwd", _p(dgrid), _p(src), _p(inv_kernel), _p(coord_repr), N, HW, NC, _p(dctrl))
+
+
+def grid_sample_fwd(inp, grid, N, H, W, C_, OH, OW, align_corners, out):
+    _launch("tpgsr_grid_sample_fwd", _p(inp), _p(grid), N, H, W, C_, OH, OW, int(align_corners), _p(out))
+
+
+def grid_sample_bwd(inp, grid, dout, N, H, W, C_, OH, OW, align_corners, din, dgrid):
+    _launch("tpgsr_grid_sample_bwd", _p(inp), _p(grid), _p(dout), N, H, W, C_, OH, OW, int(align_corners), _p(din),
+                                            _p(dgrid))
+
+
+# ---- tail / loss / optimiser ----------------------------------------------------------------------------------
+def tail_shiftsum_tanh(P, bias, N, H, W, Co, KS, out_nchw):
+    _launch("tpgsr_tail_shiftsum_tanh", _p(P), _p(bias), N, H, W, Co, KS, _p(out_nchw))
+
+
+def tail_bwd_blocks(N, H, W, Co, KS) -> int:
+    return _lib.load().tpgsr_tail_bwd_blocks(N, H, W, Co, KS)
+
+
+def tail_bwd(out_nchw, dout_nchw, N, H, W, Co, KS, dP, dbias_partial, nblk):
+    _launch("tpgsr_tail_bwd", _p(out_nchw), _p(dout_nchw), N, H, W, Co, KS, _p(dP), _p(dbias_partial), nblk)
+
+
+def image_loss_fwd(out, tgt, N, C_, H, W, gradient, partial, nblk):
+    _launch("tpgsr_image_loss_fwd", _p(out), _p(tgt), N, C_, H, W, int(gradient), _p(partial), nblk)
+
+
+def image_loss_finalize(partial, nblk, n_mse, n_gp, w0, w1, loss):
+    _launch("tpgsr_image_loss_finalize", _p(partial), nblk, n_mse, n_gp, w0, w1, _p(loss))
+
+
+def image_loss_bwd(out, tgt, dloss, N, C_, H, W, gradient, w0, w1, dout):
+    _launch("tpgsr_image_loss_bwd", _p(out), _p(tgt), _p(dloss), N, C_, H, W, int(gradient), w0, w1, _p(dout))
+
+
+def sumsq_partial(x, n, partial, nblk):
+    _launch("tpgsr_sumsq_partial", _p(x), n, _p(partial), nblk)
+
+
+def clip_coef(partial, nblk, max_norm, coef, norm_out=None):
+    _launch("tpgsr_clip_coef", _p(partial), nblk, max_norm, _p(coef), _p(norm_out))
+
+
+def adam_step(p, g, m, v, n, gscale, lr, beta1, beta2, eps, step_dev):
+    _launch("tpgsr_adam_step", _p(p), _p(g), _p(m), _p(v), n, _p(gscale), lr, beta1, beta2, eps, _p(step_dev))
+
+
+def step_inc(step_dev):
+    _launch("tpgsr_step_inc", _p(step_dev))
+
+
+def scale_(x, n, coef):
+    _launch("tpgsr_scale_", _p(x), n, _p(coef))

@@ -1,0 +1,60 @@
+"""ImageLoss / GradientPriorLoss with the reference's signatures (reference: loss/image_loss.py:10-51), computed by
+the fused tpgsr_image_loss_* kernels: one pass for MSE over all channels + L1 of gradient-magnitude maps over RGB,
+an analytic backward, NCHW tensors like the caller's."""
+import torch
+from torch import nn
+
+from .. import kernels as K
+
+_NBLK = 128
+
+
+class _ImageLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, tgt, gradient, w0, w1):
+        if not (out.is_cuda and tgt.is_cuda):
+            raise RuntimeError("tpgsr_amd losses run on the GPU only (no CPU fallback)")
+        out = out.contiguous().float()
+        tgt = tgt.contiguous().float()
+        N, C, H, W = out.shape
+        part = torch.empty(_NBLK, 2, device=out.device)
+        loss = torch.empty((), device=out.device)
+        K.image_loss_fwd(out, tgt, N, C, H, W, gradient, part, _NBLK)
+        n_gp = N * min(C, 3) * H * W if gradient else 0
+        K.image_loss_finalize(part, _NBLK, out.numel(), n_gp, float(w0), float(w1), loss)
+        ctx.save_for_backward(out, tgt)
+        ctx.cfg = (gradient, float(w0), float(w1))
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        out, tgt = ctx.saved_tensors
+        gradient, w0, w1 = ctx.cfg
+        N, C, H, W = out.shape
+        dout = torch.empty_like(out)
+        K.image_loss_bwd(out, tgt, dloss.contiguous().float().reshape(1), N, C, H, W, gradient, w0, w1, dout)
+        return dout, None, None, None, None
+
+
+class GradientPriorLoss(nn.Module):
+    """L1 between gradient-magnitude maps (reference :33-51)."""
+
+    def forward(self, out_images, target_images):
+        # w0 = 0 (no MSE term), w1 = 1 over all given channels: the kernel's gradient term covers the first 3 channels,
+        # which is how the reference always calls it (out[:, :3], target[:, :3])
+        if out_images.shape[1] > 3:
+            raise ValueError("GradientPriorLoss is defined on <= 3 channels (the reference passes x[:, :3])")
+        return _ImageLossFn.apply(out_images, target_images, True, 0.0, 1.0)
+
+
+class ImageLoss(nn.Module):
+    def __init__(self, gradient=True, loss_weight=[20, 1e-4]):
+        super().__init__()
+        self.gradient = gradient
+        self.loss_weight = loss_weight
+        if gradient:
+            self.GPLoss = GradientPriorLoss()
+
+    def forward(self, out_images, target_images, grad_mask=None):
+        return _ImageLossFn.apply(out_images, target_images, bool(self.gradient), self.loss_weight[0],
+                                  self.loss_weight[1] if self.gradient else 0.0)

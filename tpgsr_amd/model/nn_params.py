@@ -1,0 +1,107 @@
+"""Parameter-holder modules: the reference's layer objects WITHOUT an ATen forward.
+
+The reference builds its networks from nn.Conv2d / nn.BatchNorm2d / nn.GRU / nn.Linear / nn.PReLU instances; their
+only durable contract is the state_dict (names, shapes) and the default initialisation.  These holders register the
+same tensors under the same names with the same init, but deliberately have no forward(): compute goes through the
+HIP kernels (tpgsr_amd/engine.py), and nothing can silently fall back to a stock PyTorch kernel."""
+import math
+
+import torch
+from torch import nn
+
+
+def _uniform(t, bound):
+    with torch.no_grad():
+        return t.uniform_(-bound, bound)
+
+
+class _NoForward(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} only holds parameters; it is executed by the fused HIP plan of its "
+                           "parent network (tpgsr_amd.engine), not layer by layer")
+
+
+class Conv2dParams(_NoForward):
+    """nn.Conv2d(in, out, k, padding=p) parameters, default PyTorch init (kaiming_uniform(a=sqrt(5)))."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, bias=True):
+        super().__init__()
+        kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, (kh, kw)
+        self.padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kh, kw))
+        bound = 1.0 / math.sqrt(in_channels * kh * kw)
+        _uniform(self.weight, bound)
+        if bias:
+            self.bias = nn.Parameter(_uniform(torch.empty(out_channels), bound))
+        else:
+            self.register_parameter("bias", None)
+
+
+class ConvTranspose2dParams(_NoForward):
+    """nn.ConvTranspose2d(in, out, k, stride, padding, bias=False) parameters ([in][out][kh][kw])."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, bias=False):
+        super().__init__()
+        assert not bias
+        k = kernel_size
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, (k, k)
+        self.stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        self.padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, k, k))
+        _uniform(self.weight, 1.0 / math.sqrt(out_channels * k * k))
+
+
+class LinearParams(_NoForward):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        bound = 1.0 / math.sqrt(in_features)
+        self.weight = nn.Parameter(_uniform(torch.empty(out_features, in_features), bound))
+        self.bias = nn.Parameter(_uniform(torch.empty(out_features), bound))
+
+
+class BatchNormParams(_NoForward):
+    """nn.BatchNorm{1,2}d(C): weight 1, bias 0, running_mean 0, running_var 1, num_batches_tracked 0."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class PReLUParams(_NoForward):
+    def __init__(self, init=0.25):
+        super().__init__()
+        self.weight = nn.Parameter(torch.full((1,), float(init)))
+
+
+class _RNNParams(_NoForward):
+    GATES = 1
+
+    def __init__(self, input_size, hidden_size, bidirectional=True):
+        super().__init__()
+        assert bidirectional
+        self.input_size, self.hidden_size = input_size, hidden_size
+        bound = 1.0 / math.sqrt(hidden_size)
+        g = self.GATES * hidden_size
+        for suf in ("", "_reverse"):
+            self.register_parameter("weight_ih_l0" + suf, nn.Parameter(_uniform(torch.empty(g, input_size), bound)))
+            self.register_parameter("weight_hh_l0" + suf, nn.Parameter(_uniform(torch.empty(g, hidden_size), bound)))
+            self.register_parameter("bias_ih_l0" + suf, nn.Parameter(_uniform(torch.empty(g), bound)))
+            self.register_parameter("bias_hh_l0" + suf, nn.Parameter(_uniform(torch.empty(g), bound)))
+
+    def flatten_parameters(self):  # API parity with nn.GRU / nn.LSTM (model/tsrn.py:503); nothing to do
+        pass
+
+
+class GRUParams(_RNNParams):
+    GATES = 3
+
+
+class LSTMParams(_RNNParams):
+    GATES = 4

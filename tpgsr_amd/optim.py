@@ -1,0 +1,54 @@
+"""Fused optimiser over the flat arenas: clip_grad_norm_(0.25) per SR network + one Adam over SR nets and students
+(reference: interfaces/super_resolution.py:419-424, interfaces/base.py:449-450).  Three launches per module
+(sum-of-squares partials, clip coefficient, Adam) instead of ~4 per parameter tensor."""
+from typing import Iterable, Sequence
+
+import torch
+
+from . import kernels as K
+
+_NBLK = 256
+
+
+class FusedAdam:
+    def __init__(self, modules: Sequence[torch.nn.Module], lr=1e-3, betas=(0.5, 0.999), eps=1e-8,
+                 clip_modules: Iterable[torch.nn.Module] = (), max_norm=0.25):
+        self.modules = list(modules)
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.clip = set(id(m) for m in clip_modules)
+        self.state = {}
+
+    def _st(self, m):
+        eng = m._engine()
+        if eng.device is None:
+            dev = next(m.parameters()).device
+            eng.bind(dev)
+        a = eng.arena
+        st = self.state.get(id(m))
+        if st is None or st["n"] != a.numel or st["m"].device != a.flat.device:
+            dev = a.flat.device
+            st = dict(n=a.numel, m=torch.zeros(a.numel, device=dev), v=torch.zeros(a.numel, device=dev),
+                      step=torch.zeros(1, dtype=torch.int32, device=dev), part=torch.empty(_NBLK, device=dev),
+                      coef=torch.ones(1, device=dev), norm=torch.zeros(1, device=dev))
+            self.state[id(m)] = st
+        return a, st
+
+    def zero_grad(self):
+        for m in self.modules:
+            a, _ = self._st(m)
+            K.zero(a.grad, a.numel)
+
+    def step(self):
+        for m in self.modules:
+            a, st = self._st(m)
+            gscale = None
+            if id(m) in self.clip:
+                K.sumsq_partial(a.grad, a.numel, st["part"], _NBLK)
+                K.clip_coef(st["part"], _NBLK, self.max_norm, st["coef"], st["norm"])
+                gscale = st["coef"]
+            K.step_inc(st["step"])
+            K.adam_step(a.flat, a.grad, st["m"], st["v"], a.numel, gscale, self.lr, self.betas[0], self.betas[1], self.eps,
+                        st["step"])
+
+    def grad_norm(self, m):
+        return self.state[id(m)]["norm"]
