@@ -143,6 +143,10 @@ int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long long count
 /* pass 2: dy = coef0*dz + coef1*y + coef2 (dz recomputed from da(+da2), y) */
 int tpgsr_bn_bwd_apply(const float* da, const float* da2, const float* y, long long M, int C, const float* scale,
                        const float* shift, int act, const float* coef, float* dy, void* stream);
+/* out = act(scale[c]*x + shift[c]) over an [M][C] tensor (scale/shift optional, C % 4 == 0): materialises an activation
+ * once where re-applying it per filter tap in the consumer's loader would cost more (mish before a 3x3 / 9x1 conv). */
+int tpgsr_affine_act(const float* x, long long M, int C, const float* scale, const float* shift, int act, float* out,
+                     void* stream);
 /* Materialise act(scale*x+shift) (+ optional 2x2 / 1x2 max-pool, STN head model/stn_head.py:34-45) */
 int tpgsr_affine_act_pool(const float* x, int N, int H, int W, int C, const float* scale, const float* shift,
                           int act, int pool_h, int pool_w, float* out, void* stream);

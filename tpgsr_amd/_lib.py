@@ -5,6 +5,11 @@ raises.  The CPU oracle under oracle/ is test infrastructure and is never import
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It MUST be the one already
+# mapped when libtpgsr_hip.so (NEEDED libamdhip64.so.7) is dlopen'ed, otherwise the process ends up with two HIP
+# runtimes and every call on a torch stream fails with hipErrorNoDevice.  Importing torch first guarantees that.
+import torch  # noqa: F401  (load-order dependency, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtpgsr_hip.so")
 
@@ -51,6 +56,7 @@ _SIGS = {
     "tpgsr_bn_bwd_reduce": (ci, [vp, vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, ci, vp]),
     "tpgsr_bn_bwd_finalize": (ci, [vp, ci, ci, ll, vp, vp, vp, vp, vp, ci, vp, vp]),
     "tpgsr_bn_bwd_apply": (ci, [vp, vp, vp, ll, ci, vp, vp, ci, vp, vp, vp]),
+    "tpgsr_affine_act": (ci, [vp, ll, ci, vp, vp, ci, vp, vp]),
     "tpgsr_affine_act_pool": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp]),
     "tpgsr_affine_act_pool_bwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp]),
     "tpgsr_prelu_fwd": (ci, [vp, vp, ll, vp, vp]),

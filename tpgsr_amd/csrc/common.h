@@ -34,22 +34,38 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// ---- activations (fp32, matching ATen's formulas) -------------------------------------------------
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
+// ---- activations -----------------------------------------------------------------------------------------------
+// One hardware exponential (v_exp_f32 via __expf, ~2 ulp) + one reciprocal per value; every form below is
+// cancellation-free, so the results stay within a few fp32 ulp of ATen's softplus/tanh/sigmoid compositions:
+//   e = exp(x),  n = e*(e+2):   tanh(softplus(x)) = n/(n+2)        (softplus threshold 20 as in F.softplus)
+//   sigmoid(x) = 1/(1+exp(-x)),  tanh(x) = sign(x)*(1-q)/(1+q), q = exp(-2|x|)
+__device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+  float q = __expf(-2.f * fabsf(x));
+  float t = (1.f - q) * fast_rcp(1.f + q);
+  return copysignf(t, x);
+}
+__device__ __forceinline__ float mish_f(float x) {
+  if (x > 20.f) return x;   // softplus(x) = x and tanh(x) = 1 in fp32
+  float e = __expf(x);
+  float n = e * (e + 2.f);
+  return x * n * fast_rcp(n + 2.f);
+}
 // d/dx [x * tanh(sp(x))] = tanh(sp) + x * (1 - tanh(sp)^2) * sigmoid(x)
 __device__ __forceinline__ float mish_grad_f(float x) {
-  float sp = softplus_f(x);
-  float t = tanhf(sp);
-  float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+  if (x > 20.f) return 1.f;
+  float e = __expf(x);
+  float n = e * (e + 2.f);
+  float t = n * fast_rcp(n + 2.f);
+  float sg = e * fast_rcp(1.f + e);
   return t + x * (1.f - t * t) * sg;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == TPGSR_ACT_RELU) return fmaxf(x, 0.f);
   if (act == TPGSR_ACT_MISH) return mish_f(x);
-  if (act == TPGSR_ACT_TANH) return tanhf(x);
+  if (act == TPGSR_ACT_TANH) return tanh_f(x);
   return x;
 }
 // derivative w.r.t. the pre-activation value x
@@ -57,7 +73,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == TPGSR_ACT_RELU) return x > 0.f ? 1.f : 0.f;
   if (act == TPGSR_ACT_MISH) return mish_grad_f(x);
   if (act == TPGSR_ACT_TANH) {
-    float t = tanhf(x);
+    float t = tanh_f(x);
     return 1.f - t * t;
   }
   return 1.f;

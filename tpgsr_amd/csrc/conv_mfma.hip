@@ -54,26 +54,30 @@ __device__ __forceinline__ float load_a_scalar(const tpgsr_conv_args& a, const P
   return v;
 }
 
-// four consecutive k (one (tap, 4-channel) quad) of the A operand; requires Cin % 4 == 0
+// four consecutive k (one (tap, 4-channel) quad) of the A operand; requires Cin % 4 == 0.
+// Branch-free on purpose: an out-of-range tap / padding pixel loads from pixel 0 and is zeroed by a select, so the
+// compiler can issue the global loads early and wait for them only where the values are stored to LDS.
+// LD bits: 1 = per-channel affine, 2 = activation (a.in_act), 4 = residual add (in2), 8 = un-PixelShuffle gather
+template <int LD>
 __device__ __forceinline__ float4 load_a_quad(const tpgsr_conv_args& a, const PixelPos& p, int tap, int c, int ntaps) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!p.valid || tap >= ntaps) return v;
   int kh = tap / a.KW, kw = tap - kh * a.KW;
   int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
-  if ((unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) return v;
-  size_t pix = (size_t)(p.n * a.H + ih) * a.W + iw;
-  if (!a.in_ps) {
+  const bool ok = p.valid && tap < ntaps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+  const size_t pix = ok ? (size_t)(p.n * a.H + ih) * a.W + iw : 0;
+  float4 v;
+  if (!(LD & 8)) {
     v = *reinterpret_cast<const float4*>(a.in + pix * a.in_ld + a.in_coff + c);
   } else {
     int C4 = a.Cin >> 2, cs = c >> 2;
     size_t W2 = 2 * (size_t)a.W;
-    const float* b = a.in + ((size_t)(p.n * 2 * a.H + 2 * ih) * W2 + 2 * iw) * C4 + cs;
+    int n = ok ? p.n : 0, ih2 = ok ? ih : 0, iw2 = ok ? iw : 0;
+    const float* b = a.in + ((size_t)(n * 2 * a.H + 2 * ih2) * W2 + 2 * iw2) * C4 + cs;
     v.x = b[0];
     v.y = b[C4];
     v.z = b[W2 * C4];
     v.w = b[W2 * C4 + C4];
   }
-  if (a.in_scale) {
+  if (LD & 1) {
     float4 s = *reinterpret_cast<const float4*>(a.in_scale + c);
     float4 t = *reinterpret_cast<const float4*>(a.in_shift + c);
     v.x = v.x * s.x + t.x;
@@ -81,28 +85,42 @@ __device__ __forceinline__ float4 load_a_quad(const tpgsr_conv_args& a, const Pi
     v.z = v.z * s.z + t.z;
     v.w = v.w * s.w + t.w;
   }
-  if (a.in_act) {
+  if (LD & 2) {
     v.x = apply_act(v.x, a.in_act);
     v.y = apply_act(v.y, a.in_act);
     v.z = apply_act(v.z, a.in_act);
     v.w = apply_act(v.w, a.in_act);
   }
-  if (a.in2) {
+  if (LD & 4) {
     float4 r = *reinterpret_cast<const float4*>(a.in2 + pix * a.in2_ld + c);
     v.x += r.x;
     v.y += r.y;
     v.z += r.z;
     v.w += r.w;
   }
+  v.x = ok ? v.x : 0.f;
+  v.y = ok ? v.y : 0.f;
+  v.z = ok ? v.z : 0.f;
+  v.w = ok ? v.w : 0.f;
   return v;
 }
 
+// 4 consecutive columns of a row-major [rows][ld] operand; vec: 16-byte aligned full quads (branch-free)
 __device__ __forceinline__ float4 load_row4(const float* base, size_t row, int ld, int col, int ncols, bool rowvalid,
                                             bool vec) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec) {
+    const bool ok = rowvalid && col < ncols;
+    const float* p = base + (ok ? row * (size_t)ld + col : 0);
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v.x = ok ? t.x : 0.f;
+    v.y = ok ? t.y : 0.f;
+    v.z = ok ? t.z : 0.f;
+    v.w = ok ? t.w : 0.f;
+    return v;
+  }
   if (!rowvalid || col >= ncols) return v;
   const float* p = base + row * (size_t)ld + col;
-  if (vec) return *reinterpret_cast<const float4*>(p);
   v.x = p[0];
   if (col + 1 < ncols) v.y = p[1];
   if (col + 2 < ncols) v.z = p[2];
@@ -110,11 +128,88 @@ __device__ __forceinline__ float4 load_row4(const float* base, size_t row, int l
   return v;
 }
 
+// ---- buffer-resource loads: out-of-range offsets return 0 in hardware, so padding / ragged edges need no data-side
+// select and the loads can stay in flight across the MFMA loop (the prologue is applied when the tile is stored) ----
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, size_t nfloats) {
+  size_t bytes = nfloats * 4;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes > 0x7fffffffull ? 0x7fffffff : (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off_bytes) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off_bytes, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off_bytes) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off_bytes, 0, 0));
+}
+#define OOB_OFF 0x7ffffff0u
+
+struct ARaw {
+  float4 v, v2;
+  bool ok;
+};
+
+// issue the loads of one A quad (no dependent arithmetic); LD bits as in load_a_quad
+template <int LD>
+__device__ __forceinline__ ARaw load_a_raw(const tpgsr_conv_args& a, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rin2,
+                                           const PixelPos& p, int tap, int c, int ntaps) {
+  ARaw r;
+  int kh = tap / a.KW, kw = tap - kh * a.KW;
+  int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
+  r.ok = p.valid && tap < ntaps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+  const unsigned pix = (unsigned)((p.n * a.H + ih) * a.W + iw);
+  if (!(LD & 8)) {
+    r.v = buf_load4(rin, r.ok ? (pix * (unsigned)a.in_ld + (unsigned)(a.in_coff + c)) * 4u : OOB_OFF);
+  } else {
+    unsigned C4 = (unsigned)a.Cin >> 2, cs = (unsigned)c >> 2, W2 = 2u * (unsigned)a.W;
+    unsigned b = r.ok ? ((((unsigned)p.n * 2u * a.H + 2u * ih) * W2 + 2u * iw) * C4 + cs) * 4u : OOB_OFF;
+    r.v.x = buf_load1(rin, b);
+    r.v.y = buf_load1(rin, r.ok ? b + C4 * 4u : OOB_OFF);
+    r.v.z = buf_load1(rin, r.ok ? b + W2 * C4 * 4u : OOB_OFF);
+    r.v.w = buf_load1(rin, r.ok ? b + (W2 * C4 + C4) * 4u : OOB_OFF);
+  }
+  if (LD & 4) r.v2 = buf_load4(rin2, r.ok ? (pix * (unsigned)a.in2_ld + (unsigned)c) * 4u : OOB_OFF);
+  return r;
+}
+
+// apply the fused prologue to a landed quad (called right before the LDS store)
+template <int LD>
+__device__ __forceinline__ float4 finish_a(const tpgsr_conv_args& a, const ARaw& r, const float4& s, const float4& t) {
+  float4 v = r.v;
+  if (LD & 1) {
+    v.x = v.x * s.x + t.x;
+    v.y = v.y * s.y + t.y;
+    v.z = v.z * s.z + t.z;
+    v.w = v.w * s.w + t.w;
+  }
+  if (LD & 2) {
+    v.x = apply_act(v.x, a.in_act);
+    v.y = apply_act(v.y, a.in_act);
+    v.z = apply_act(v.z, a.in_act);
+    v.w = apply_act(v.w, a.in_act);
+  }
+  if (LD & 4) {
+    v.x += r.v2.x;
+    v.y += r.v2.y;
+    v.z += r.v2.z;
+    v.w += r.v2.w;
+  }
+  if (LD & 3) {  // affine / activation turn the hardware zero fill into f(0): re-zero padding explicitly
+    v.x = r.ok ? v.x : 0.f;
+    v.y = r.ok ? v.y : 0.f;
+    v.z = r.ok ? v.z : 0.f;
+    v.w = r.ok ? v.w : 0.f;
+  }
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------------
-template <bool VEC_A>
+template <int LD>   // LD >= 0: vector quad loader with compile-time prologue bits; LD < 0: generic scalar loader
 __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M, int K, int vecB) {
+  constexpr bool VEC_A = LD >= 0;
   __shared__ float As[KC][ALD];
   __shared__ float Bs[KC][BN];
   const int tid = threadIdx.x;
@@ -135,25 +230,44 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
   const int bc = (tid & 15) * 4;
 
   float4 ra0, ra1, rb0, rb1;
+  ARaw qa0, qa1;
+  float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int LDV = LD < 0 ? 0 : LD;
+  const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * a.W * a.in_ld;
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, in_floats);
+  const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
+  const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt, (size_t)K * a.Cout);
   auto load_chunk = [&](int ch) {
     if (VEC_A) {
       int kq = ch * (KC / 4) + aq;
       int tap = kq / cin4;
       int c = (kq - tap * cin4) * 4;
-      ra0 = load_a_quad(a, px0, tap, c, ntaps);
-      ra1 = load_a_quad(a, px1, tap, c, ntaps);
+      qa0 = load_a_raw<LDV>(a, rs_in, rs_in2, px0, tap, c, ntaps);
+      qa1 = load_a_raw<LDV>(a, rs_in, rs_in2, px1, tap, c, ntaps);
+      if (LDV & 1) {
+        qs = *reinterpret_cast<const float4*>(a.in_scale + c);
+        qt = *reinterpret_cast<const float4*>(a.in_shift + c);
+      }
+      int k0 = ch * KC + bk0, k1 = k0 + 16;
+      const bool cok = n0 + bc < a.Cout;   // rows k >= K fall outside the buffer: hardware zero fill
+      rb0 = buf_load4(rs_wt, cok ? ((unsigned)k0 * (unsigned)a.Cout + (unsigned)(n0 + bc)) * 4u : OOB_OFF);
+      rb1 = buf_load4(rs_wt, cok ? ((unsigned)k1 * (unsigned)a.Cout + (unsigned)(n0 + bc)) * 4u : OOB_OFF);
     } else {
       int k = ch * KC + aq * 4;
       ra0 = make_float4(load_a_scalar(a, px0, k, K), load_a_scalar(a, px0, k + 1, K), load_a_scalar(a, px0, k + 2, K),
                         load_a_scalar(a, px0, k + 3, K));
       ra1 = make_float4(load_a_scalar(a, px1, k, K), load_a_scalar(a, px1, k + 1, K), load_a_scalar(a, px1, k + 2, K),
                         load_a_scalar(a, px1, k + 3, K));
+      int k0 = ch * KC + bk0, k1 = k0 + 16;
+      rb0 = load_row4(a.wt, k0, a.Cout, n0 + bc, a.Cout, k0 < K, vecB);
+      rb1 = load_row4(a.wt, k1, a.Cout, n0 + bc, a.Cout, k1 < K, vecB);
     }
-    int k0 = ch * KC + bk0, k1 = k0 + 16;
-    rb0 = load_row4(a.wt, k0, a.Cout, n0 + bc, a.Cout, k0 < K, vecB);
-    rb1 = load_row4(a.wt, k1, a.Cout, n0 + bc, a.Cout, k1 < K, vecB);
   };
   auto store_chunk = [&]() {
+    if (VEC_A) {
+      ra0 = finish_a<LDV>(a, qa0, qs, qt);
+      ra1 = finish_a<LDV>(a, qa1, qs, qt);
+    }
     As[aq * 4 + 0][am0] = ra0.x;
     As[aq * 4 + 1][am0] = ra0.y;
     As[aq * 4 + 2][am0] = ra0.z;
@@ -184,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
       float bv = Bs[2 * kk + arow][bcol];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the prologue arithmetic / LDS stores of the next tile behind the MFMAs
     __syncthreads();
     if (ch + 1 < nchunks) {
       store_chunk();
@@ -250,6 +365,11 @@ static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
   return 0;
 }
 
+// compile-time loader variant: 1 affine, 2 activation, 4 residual add, 8 pixel-shuffle gather
+static int loader_bits(const tpgsr_conv_args* a) {
+  return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0);
+}
+
 extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   int rc = check_conv_args(a, "tpgsr_conv_fwd");
   if (rc) return rc;
@@ -263,10 +383,21 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   TPGSR_CHECK_ARG(M < (1ll << 31), "tpgsr_conv_fwd: M too large");
   dim3 grid(cdiv(M, BM), cdiv(a->Cout, BN));
   int vecB = ((a->Cout & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;
-  if ((a->Cin & 3) == 0)
-    hipLaunchKernelGGL(conv_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a, (int)M, K, vecB);
-  else
-    hipLaunchKernelGGL(conv_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a, (int)M, K, vecB);
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = loader_bits(a);
+#define TPGSR_FWD_CASE(B) case B: hipLaunchKernelGGL(conv_fwd_kernel<B>, grid, dim3(256), 0, st, *a, (int)M, K, vecB); break;
+  if ((a->Cin & 3) != 0 || !vecB) {
+    hipLaunchKernelGGL(conv_fwd_kernel<-1>, grid, dim3(256), 0, st, *a, (int)M, K, vecB);
+  } else {
+    switch (ld) {
+      TPGSR_FWD_CASE(0) TPGSR_FWD_CASE(1) TPGSR_FWD_CASE(3) TPGSR_FWD_CASE(4) TPGSR_FWD_CASE(5) TPGSR_FWD_CASE(7)
+      TPGSR_FWD_CASE(8) TPGSR_FWD_CASE(2)
+      default:
+        tpgsr_set_error("tpgsr_conv_fwd: unsupported loader combination %d", ld);
+        return TPGSR_ERR_ARG;
+    }
+  }
+#undef TPGSR_FWD_CASE
   TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd");
 }
 
@@ -280,8 +411,8 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
 __device__ __forceinline__ float4 load_dy4(const tpgsr_wgrad_args& w, const PixelPos& p, int m, int col, int vec) {
   const tpgsr_conv_args& a = w.c;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!w.dy_ps) return load_row4(w.dy + w.dy_coff, (size_t)m, w.dy_ld, col, a.Cout, p.valid, vec);
   if (!p.valid || col >= a.Cout) return v;
-  if (!w.dy_ps) return load_row4(w.dy + w.dy_coff, (size_t)m, w.dy_ld, col, a.Cout, true, vec);
   // logical channels col..col+3 = (cs = col/4, i, j) of a [N][2OH][2OW][Cout/4] tensor
   int C4 = a.Cout >> 2, cs = col >> 2;
   size_t W2 = 2 * (size_t)a.OW;
@@ -293,8 +424,9 @@ __device__ __forceinline__ float4 load_dy4(const tpgsr_wgrad_args& w, const Pixe
   return v;
 }
 
-template <bool VEC_A>
+template <int LD>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int M, int K, int MB, int vecY) {
+  constexpr bool VEC_A = LD >= 0;
   __shared__ float As[WK][WALD];
   __shared__ float Ys[WM][BN];
   const tpgsr_conv_args& a = w.c;
@@ -320,24 +452,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
   const int yc = (tid & 15) * 4;
 
   float4 ra0, ra1, ry0, ry1;
+  ARaw qa0, qa1;
+  float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int LDV = LD < 0 ? 0 : LD;
+  const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * a.W * a.in_ld;
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, in_floats);
+  const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(w.dy, w.dy_ps ? (size_t)M * a.Cout : (size_t)M * w.dy_ld);
+  if (VEC_A && (LDV & 1)) {
+    qs = *reinterpret_cast<const float4*>(a.in_scale + ac);
+    qt = *reinterpret_cast<const float4*>(a.in_shift + ac);
+  }
   auto load_chunk = [&](int mc) {
     int ma = mc + ap0, mb = mc + ap0 + 16;
     PixelPos p0 = decode_pixel(a, ma, mend);
     PixelPos p1 = decode_pixel(a, mb, mend);
     if (VEC_A) {
-      ra0 = load_a_quad(a, p0, atap, ac, ntaps);
-      ra1 = load_a_quad(a, p1, atap, ac, ntaps);
+      qa0 = load_a_raw<LDV>(a, rs_in, rs_in2, p0, atap, ac, ntaps);
+      qa1 = load_a_raw<LDV>(a, rs_in, rs_in2, p1, atap, ac, ntaps);
+      if (!w.dy_ps) {
+        const bool cok = n0 + yc < a.Cout;
+        ry0 = buf_load4(rs_dy, (p0.valid && cok) ? ((unsigned)ma * (unsigned)w.dy_ld + (unsigned)(w.dy_coff + n0 + yc)) * 4u : OOB_OFF);
+        ry1 = buf_load4(rs_dy, (p1.valid && cok) ? ((unsigned)mb * (unsigned)w.dy_ld + (unsigned)(w.dy_coff + n0 + yc)) * 4u : OOB_OFF);
+      } else {
+        ry0 = load_dy4(w, p0, ma, n0 + yc, 1);
+        ry1 = load_dy4(w, p1, mb, n0 + yc, 1);
+      }
     } else {
       int k = k0 + aq * 4;
       ra0 = make_float4(load_a_scalar(a, p0, k, K), load_a_scalar(a, p0, k + 1, K), load_a_scalar(a, p0, k + 2, K),
                         load_a_scalar(a, p0, k + 3, K));
       ra1 = make_float4(load_a_scalar(a, p1, k, K), load_a_scalar(a, p1, k + 1, K), load_a_scalar(a, p1, k + 2, K),
                         load_a_scalar(a, p1, k + 3, K));
+      ry0 = load_dy4(w, p0, ma, n0 + yc, vecY);
+      ry1 = load_dy4(w, p1, mb, n0 + yc, vecY);
     }
-    ry0 = load_dy4(w, p0, ma, n0 + yc, vecY);
-    ry1 = load_dy4(w, p1, mb, n0 + yc, vecY);
   };
   auto store_chunk = [&]() {
+    if (VEC_A) {
+      ra0 = finish_a<LDV>(a, qa0, qs, qt);
+      ra1 = finish_a<LDV>(a, qa1, qs, qt);
+    }
     As[aq * 4 + 0][ap0] = ra0.x;
     As[aq * 4 + 1][ap0] = ra0.y;
     As[aq * 4 + 2][ap0] = ra0.z;
@@ -377,6 +532,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
 #pragma unroll 8
       for (int r = 0; r < WM; ++r) dbacc += Ys[r][tid];
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (more) {
       store_chunk();
@@ -397,9 +553,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
 
 static void wgrad_plan(long long M, int K, int Cout, int* Z, int* MB) {
   int kb = cdiv(K, WK), nb = cdiv(Cout, BN);
-  long long target = 1536;  // ~6 blocks per CU
+  long long target = 1024;  // ~4 blocks per CU
   long long z = (target + (long long)kb * nb - 1) / ((long long)kb * nb);
-  long long maxz = (M + 127) / 128;  // at least 128 pixels per split
+  long long maxz = (M + 255) / 256;  // at least 256 pixels per split
+  if (maxz > 256) maxz = 256;
   if (z > maxz) z = maxz;
   if (z < 1) z = 1;
   long long mb = (M + z - 1) / z;
@@ -430,49 +587,84 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   dim3 grid(cdiv(K, WK), cdiv(a->Cout, BN), Z);
   int vecY = (!w->dy_ps && (a->Cout & 3) == 0 && (w->dy_ld & 3) == 0 && (w->dy_coff & 3) == 0 &&
               ((uintptr_t)w->dy & 15) == 0) ? 1 : 0;
-  if ((a->Cin & 3) == 0)
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *w, (int)M, K, MB, vecY);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *w, (int)M, K, MB, vecY);
+  hipStream_t st = (hipStream_t)stream;
+  const int ld = loader_bits(a);
+#define TPGSR_WG_CASE(B) case B: hipLaunchKernelGGL(conv_wgrad_kernel<B>, grid, dim3(256), 0, st, *w, (int)M, K, MB, vecY); break;
+  if ((a->Cin & 3) != 0 || (!vecY && !w->dy_ps)) {
+    hipLaunchKernelGGL(conv_wgrad_kernel<-1>, grid, dim3(256), 0, st, *w, (int)M, K, MB, vecY);
+  } else {
+    switch (ld) {
+      TPGSR_WG_CASE(0) TPGSR_WG_CASE(1) TPGSR_WG_CASE(3) TPGSR_WG_CASE(4) TPGSR_WG_CASE(5) TPGSR_WG_CASE(7) TPGSR_WG_CASE(2)
+      default:
+        tpgsr_set_error("tpgsr_conv_wgrad: unsupported loader combination %d", ld);
+        return TPGSR_ERR_ARG;
+    }
+  }
+#undef TPGSR_WG_CASE
   TPGSR_LAUNCH_CHECK("tpgsr_conv_wgrad");
 }
 
-// dw (+)= sum_z part[z][k][co], scattered into the PyTorch layout
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart, int Z, int K,
-                                    int Cin, int Cout, int KH, int KW, int layout, float* dw, float* db, int accumulate, float gscale) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)K * Cout;
-  if (idx < total) {
-    float s = 0.f;
-    for (int z = 0; z < Z; ++z) s += part[(size_t)z * total + idx];
-    s *= gscale;
-    int k = (int)(idx / Cout), co = (int)(idx - (size_t)k * Cout);
-    int tap = k / Cin, ci = k - tap * Cin;
-    int kh = tap / KW, kw = tap - kh * KW;
-    size_t o;
-    if (layout == 0) {
-      o = (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
-    } else if (layout == 1) {  // ConvTranspose2d weight wT[ci][co][KH-1-kh][KW-1-kw] == equivalent-conv w_eq[co][ci][kh][kw]
-      o = (((size_t)ci * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
-    } else {  // layout 2: folded tail conv (KH = KS, KW = 1, Cout = KS*Co, n' = kw*Co + co) -> w[co][ci][kh][kw]
-      int Co = Cout / KH;
-      int tkw = co / Co, tco = co - tkw * Co;
-      o = (((size_t)tco * Cin + ci) * KH + kh) * KH + tkw;
+// dw (+)= sum_z part[z][k][co], scattered into the PyTorch layout.  256 threads = 32 outputs x 8 z-lanes: the Z partial
+// slabs are summed by 8 lanes in parallel (independent, unrolled loads) and combined through LDS in a fixed order.
+__device__ __forceinline__ size_t wgrad_out_index(int k, int co, int Cin, int Cout, int KH, int KW, int layout) {
+  int tap = k / Cin, ci = k - tap * Cin;
+  int kh = tap / KW, kw = tap - kh * KW;
+  if (layout == 0) return (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
+  if (layout == 1)  // ConvTranspose2d weight wT[ci][co][KH-1-kh][KW-1-kw] == equivalent-conv w_eq[co][ci][kh][kw]
+    return (((size_t)ci * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
+  // layout 2: folded tail conv (KH = KS, KW = 1, Cout = KS*Co, n' = kw*Co + co) -> w[co][ci][kh][kw]
+  int Co = Cout / KH;
+  int tkw = co / Co, tco = co - tkw * Co;
+  return (((size_t)tco * Cin + ci) * KH + kh) * KH + tkw;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                           int Z, int K, int Cin, int Cout, int KH, int KW, int layout,
+                                                           float* dw, float* db, int accumulate, float gscale) {
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const size_t total = (size_t)K * Cout;
+  const size_t ndb = (db && dbpart) ? (size_t)Cout : 0;
+  // logical index space: [0, total) = weight entries, [total, total + ndb) = bias entries
+  size_t idx = (size_t)blockIdx.x * 32 + tx;
+  const bool is_w = idx < total;
+  const bool is_b = !is_w && idx < total + ndb;
+  const float* src = is_w ? part + idx : dbpart + (idx - total);
+  const size_t stride = is_w ? total : (size_t)Cout;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (is_w || is_b) {
+    int z = zl;
+    for (; z + 24 < Z; z += 32) {
+      s0 += src[(size_t)z * stride];
+      s1 += src[(size_t)(z + 8) * stride];
+      s2 += src[(size_t)(z + 16) * stride];
+      s3 += src[(size_t)(z + 24) * stride];
     }
-    dw[o] = accumulate ? dw[o] + s : s;
+    for (; z < Z; z += 8) s0 += src[(size_t)z * stride];
   }
-  if (db && dbpart && idx < (size_t)Cout) {
-    float s = 0.f;
-    for (int z = 0; z < Z; ++z) s += dbpart[(size_t)z * Cout + idx];
-    db[idx] = accumulate ? db[idx] + s : s;
+  red[zl][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zl == 0 && (is_w || is_b)) {
+    float s = red[0][tx];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i][tx];
+    if (is_w) {
+      int k = (int)(idx / Cout), co = (int)(idx - (size_t)k * Cout);
+      size_t o = wgrad_out_index(k, co, Cin, Cout, KH, KW, layout);
+      s *= gscale;
+      dw[o] = accumulate ? dw[o] + s : s;
+    } else {
+      size_t o = idx - total;
+      db[o] = accumulate ? db[o] + s : s;
+    }
   }
 }
 
 extern "C" int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
                                   int layout, float* dw, float* db, int accumulate, float gscale, void* stream) {
   TPGSR_CHECK_ARG(part && dw && Z > 0 && K == KH * KW * Cin, "tpgsr_wgrad_reduce: bad arguments");
-  size_t total = (size_t)K * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, part, dbpart, Z, K,
+  size_t total = (size_t)K * Cout + ((db && dbpart) ? (size_t)Cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, (hipStream_t)stream, part, dbpart, Z, K,
                      Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale);
   TPGSR_LAUNCH_CHECK("tpgsr_wgrad_reduce");
 }

@@ -3,6 +3,8 @@
 // All tensors are [M][C] row-major (NHWC flattened); channel loops are float4-vectorised when C % 4 == 0.
 #include "common.h"
 
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
 // ------------------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ------------------------------------------------------------------------------------------------------
@@ -36,9 +38,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* running_mean, float* running_var, float momentum,
                                                           float eps, int eval, float* scale, float* shift,
                                                           float* save_mean, float* save_rstd) {
-  __shared__ double red[2][8][32];
-  int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][16][16];
+  int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  int c = blockIdx.x * 16 + cl;
   if (eval) {
     if (sl == 0 && c < C) {
       float rstd = 1.f / sqrtf(running_var[c] + eps);
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
   double s = 0.0, ss = 0.0;
   if (c < C)
-    for (int b = sl; b < nblk; b += 8) {
+    for (int b = sl; b < nblk; b += 16) {
       s += (double)partial[((size_t)b * 2 + 0) * C + c];
       ss += (double)partial[((size_t)b * 2 + 1) * C + c];
     }
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   red[1][sl][cl] = ss;
   __syncthreads();
   if (sl == 0 && c < C) {
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 1; i < 16; ++i) {
       s += red[0][i][cl];
       ss += red[1][i][cl];
     }
@@ -87,7 +89,7 @@ extern "C" int tpgsr_bn_finalize(const float* partial, int nblk, int C, long lon
   TPGSR_CHECK_ARG(gamma && beta && scale && shift && C > 0, "tpgsr_bn_finalize: null pointer");
   TPGSR_CHECK_ARG(eval || (partial && nblk > 0 && count > 0), "tpgsr_bn_finalize: training mode needs partial statistics");
   TPGSR_CHECK_ARG(!eval || (running_mean && running_var), "tpgsr_bn_finalize: eval mode needs running statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
                      conv_bias, gamma, beta, running_mean, running_var, momentum, eps, eval, scale, shift, save_mean,
                      save_rstd);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_finalize");
@@ -100,8 +102,6 @@ extern "C" int tpgsr_bn_finalize(const float* partial, int nblk, int C, long lon
 //   pass 2: dy = coef0*dz + coef1*y + coef2
 // thread layout: C4 = C/4 channel quads across threads, 256/C4 row lanes; requires C%4==0, 256%(C/4)==0
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ da2,
                                                             const float* __restrict__ y, long long M, int C,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_rstd, float* dgamma,
                                                               float* dbeta, int accumulate, float* coef) {
-  __shared__ double red[2][8][32];
-  int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][16][16];
+  int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  int c = blockIdx.x * 16 + cl;
   double s = 0.0, sx = 0.0;
   if (c < C)
-    for (int b = sl; b < nblk; b += 8) {
+    for (int b = sl; b < nblk; b += 16) {
       s += (double)partial[((size_t)b * 2 + 0) * C + c];
       sx += (double)partial[((size_t)b * 2 + 1) * C + c];
     }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   red[1][sl][cl] = sx;
   __syncthreads();
   if (sl == 0 && c < C) {
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 1; i < 16; ++i) {
       s += red[0][i][cl];
       sx += red[1][i][cl];
     }
@@ -198,7 +198,7 @@ extern "C" int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long
                                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                      int accumulate, float* coef, void* stream) {
   TPGSR_CHECK_ARG(partial && gamma && save_mean && save_rstd && coef && nblk > 0 && count > 0, "tpgsr_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
                      gamma, save_mean, save_rstd, dgamma, dbeta, accumulate, coef);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_finalize");
 }
@@ -242,6 +242,34 @@ extern "C" int tpgsr_bn_bwd_apply(const float* da, const float* da2, const float
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, da, da2, y, total4, C, scale, shift,
                      act, coef, dy);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_apply");
+}
+
+// out = act(scale[c]*x + shift[c]) materialised once (float4-vectorised): used where the consumer would otherwise
+// re-apply an expensive activation per filter tap (mish in front of a 3x3 / 9x1 conv)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, long long total4, int C,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int act, float* __restrict__ out) {
+  const int C4 = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = ld4(x + i * 4);
+    if (scale) {
+      int c = (int)(i % C4) * 4;
+      float4 s = ld4(scale + c), t = ld4(shift + c);
+      v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+    }
+    v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+  }
+}
+
+extern "C" int tpgsr_affine_act(const float* x, long long M, int C, const float* scale, const float* shift, int act, float* out,
+                                void* stream) {
+  TPGSR_CHECK_ARG(x && out && M > 0 && C > 0 && (C & 3) == 0, "tpgsr_affine_act: bad arguments (C must be a multiple of 4)");
+  TPGSR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "tpgsr_affine_act: scale/shift must come together");
+  long long total4 = M * C / 4;
+  int grid = (int)min((long long)8192, (total4 + 255) / 256);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, total4, C, scale, shift, act, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_affine_act");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -417,15 +445,22 @@ extern "C" int tpgsr_add(const float* a, const float* b, long long n, float* out
   TPGSR_LAUNCH_CHECK("tpgsr_add");
 }
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long long n,
-                                                      int act, float* __restrict__ dx) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* x, const float* dy, long long n, int act, float* dx) {
+  long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 xv = ld4(x + i * 4), g = ld4(dy + i * 4);
+    g.x *= act_grad(xv.x, act); g.y *= act_grad(xv.y, act); g.z *= act_grad(xv.z, act); g.w *= act_grad(xv.w, act);
+    *reinterpret_cast<float4*>(dx + i * 4) = g;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long long i = n4 * 4 + threadIdx.x;
     dx[i] = dy[i] * act_grad(x[i], act);
+  }
 }
 
 extern "C" int tpgsr_act_bwd(const float* x, const float* dy, long long n, int act, float* dx, void* stream) {
   TPGSR_CHECK_ARG(x && dy && dx && n > 0, "tpgsr_act_bwd: bad arguments");
-  int grid = (int)min((long long)8192, (n + 255) / 256);
+  int grid = (int)max((long long)1, min((long long)8192, (n / 4 + 255) / 256));
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dy, n, act, dx);
   TPGSR_LAUNCH_CHECK("tpgsr_act_bwd");
 }
@@ -468,18 +503,24 @@ extern "C" int tpgsr_nhwc_to_nchw(const float* in, int N, int C, int H, int W, f
   TPGSR_LAUNCH_CHECK("tpgsr_nhwc_to_nchw");
 }
 
+// one block per output: 256 lanes stride over the Z partials, fixed-order tree combine (deterministic)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int Z, int n, float* out,
                                                               int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ double red[4];
+  const int i = blockIdx.x;
   double s = 0.0;
-  for (int z = 0; z < Z; ++z) s += (double)part[(size_t)z * n + i];
-  out[i] = accumulate ? out[i] + (float)s : (float)s;
+  for (int z = threadIdx.x; z < Z; z += 256) s += (double)part[(size_t)z * n + i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    out[i] = accumulate ? out[i] + v : v;
+  }
 }
 
 extern "C" int tpgsr_reduce_partials(const float* part, int Z, int n, float* out, int accumulate, void* stream) {
   TPGSR_CHECK_ARG(part && out && Z > 0 && n > 0, "tpgsr_reduce_partials: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, Z, n, out,
-                     accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, part, Z, n, out, accumulate);
   TPGSR_LAUNCH_CHECK("tpgsr_reduce_partials");
 }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void bigru_fwd_kernel(const float* __restrict_
     }
     float r = sigmoid_f(gr + ar);
     float z = sigmoid_f(gz + az);
-    float n = tanhf(gn + r * an);
+    float n = tanh_f(gn + r * an);
     h = (1.f - z) * n + z * h;
     __syncthreads();  // every lane has consumed the old state
     hs[wave][lane] = h;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void bigru_bwd_kernel(const float* __restrict_
     }
     float r = sigmoid_f(gr + ar);
     float z = sigmoid_f(gz + az);
-    float n = tanhf(gn + r * an);
+    float n = tanh_f(gn + r * an);
     float dn_pre = dh * (1.f - z) * (1.f - n * n);
     float dz_pre = dh * (hprev - n) * z * (1.f - z);
     float dr_pre = dn_pre * an * r * (1.f - r);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void tail_shiftsum_tanh_kernel(const float* __
     int x = w + kw - half;
     if ((unsigned)x < (unsigned)W) s += row[(size_t)x * NP + kw * Co + co];
   }
-  out[i] = tanhf(s);
+  out[i] = tanh_f(s);
 }
 
 extern "C" int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,

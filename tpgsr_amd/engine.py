@@ -412,7 +412,9 @@ class TSRNEngine:
             part, _ = L["bn1"].partial(P1)
             L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None)
             L["bn1"].finalize(P1, L["conv1"].b, training)
-            L["conv2"].fwd(N, H, W, y1, y2, in_act="mish", bn_partial=part if training else None, **L["bn1"].loader)
+            a1 = ws(t + "a1", P1, Cc)                   # mish(bn1(y1)) once: a 3x3 consumer would re-apply it 9x per element
+            K.affine_act(y1, P1, Cc, L["bn1"].scale, L["bn1"].shift, "mish", a1)
+            L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None)
             L["bn2"].finalize(P1, L["conv2"].b, training)
             L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, **L["bn2"].loader)
             L["gru2"].fwd(N, H, W, cur, u2, gi2, out, in2=h1)
@@ -423,8 +425,10 @@ class TSRNEngine:
         self.bn7.finalize(P1, self.conv7.b, training)
         ups = ws("ups", 4 * P1, Cc)                      # pre-mish, pixel-shuffled [N][2H][2W][C]
         self.up.fwd(N, H, W, y7, ups, in2=b1, out_ps=True, **self.bn7.loader)
+        mu = ws("mups", 4 * P1, Cc)                      # mish(ups) once (the 9-tap tail conv and its wgrad both read it)
+        K.affine_act(ups, 4 * P1, Cc, None, None, "mish", mu)
         Pt = ws("Pt", 4 * P1, self.tail.Cout)
-        self.tail.fwd(N, 2 * H, 2 * W, ups, Pt, in_act="mish")
+        self.tail.fwd(N, 2 * H, 2 * W, mu, Pt)
         K.tail_shiftsum_tanh(Pt, self.tail_bias, N, 2 * H, 2 * W, self.tail.Co, self.tail.KS, K.DynPtr("sr"))
 
     def _stn_dims(self, H, W):
@@ -477,7 +481,7 @@ class TSRNEngine:
         dbp = self.scratch("tail_dbp", nblk * tl.Co)
         K.tail_bwd(K.DynPtr("sr"), K.DynPtr("dsr"), N, H2, W2, tl.Co, tl.KS, dPt, dbp, nblk)
         K.reduce_partials(dbp, nblk, tl.Co, self.G[tl.wname.replace(".weight", ".bias")], accumulate=True)
-        tl.wgrad(N, H2, W2, t["ups"], dPt, loader=dict(in_act="mish"))
+        tl.wgrad(N, H2, W2, t["mups"], dPt)
         dm = ws("d_ups", P4, Cc)
         tl.dgrad(N, H2, W2, dPt, dm)
         K.act_bwd(t["ups"], dm, P4 * Cc, "mish", dm)                      # in place: d(ups), pixel-shuffled layout
@@ -504,7 +508,7 @@ class TSRNEngine:
             # gru1 (input bn2(y2)): dh = gA
             L["gru1"].bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
             L["bn2"].backward(da, None, y2, P1, "none", dy)
-            L["conv2"].wgrad(N, H, W, y1, dy, loader=dict(in_act="mish", **L["bn1"].loader))
+            L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
             L["conv2"].dgrad(N, H, W, dy, da)                              # d mish(bn1(y1))
             L["bn1"].backward(da, None, y1, P1, "mish", dy)
             L["conv1"].wgrad(N, H, W, X, dy)

@@ -36,13 +36,10 @@ class TSRNTrainStep:
                                 inv_world=torch.full((1,), 1.0 / self.world, device=dev))
         return self._static
 
-    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
-        """Returns the (device) loss scalar = ImageLoss(sr, hr).mean() * 100 of this step."""
+    def _phase_a(self, lr_img, hr_img):
+        """zero_grad + forward + loss + backward (everything before the gradient exchange)"""
         model = self.model
-        if not model.training:
-            raise RuntimeError("TSRNTrainStep.step needs model.train()")
         eng = model._engine()
-        eng.bind(lr_img.device)
         st = self._buffers(lr_img)
         N, C, H, W = lr_img.shape
         self.opt.zero_grad()
@@ -54,20 +51,44 @@ class TSRNTrainStep:
         K.image_loss_finalize(st["part"], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["loss"])
         K.image_loss_bwd(sr, hr, st["dloss"], N, C, H2, W2, self.gradient, self.w0, self.w1, st["dsr"])
         eng.backward(tuple(lr_img.shape), sr, st["dsr"])
-        if self.world > 1:
-            # one flat bucket: RCCL all-reduce over xGMI, then the 1/world average
-            torch.distributed.all_reduce(eng.arena.grad, group=self.pg)
-            K.scale_(eng.arena.grad, eng.arena.numel, st["inv_world"])
-        self.opt.step()
         self.last_sr = sr
         return st["loss"]
 
+    def _exchange(self):
+        """ONE flat bucket: RCCL all-reduce (sum) of the gradient arena over xGMI; the 1/world average is in phase B"""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.model._engine().arena.grad, group=self.pg)
+
+    def _phase_b(self):
+        eng = self.model._engine()
+        if self.world > 1:
+            K.scale_(eng.arena.grad, eng.arena.numel, self._static["inv_world"])
+        self.opt.step()
+
+    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
+        """Returns the (device) loss scalar = ImageLoss(sr, hr).mean() * 100 of this step (this rank's shard)."""
+        if not self.model.training:
+            raise RuntimeError("TSRNTrainStep.step needs model.train()")
+        self.model._engine().bind(lr_img.device)
+        loss = self._phase_a(lr_img, hr_img)
+        self._exchange()
+        self._phase_b()
+        return loss
+
+    def broadcast_parameters(self, src: int = 0):
+        """DDP start-up: every rank adopts rank `src`'s parameters and BN buffers (one flat broadcast + buffers)."""
+        if self.world > 1:
+            eng = self.model._engine()
+            eng.bind(next(self.model.parameters()).device)
+            torch.distributed.broadcast(eng.arena.flat, src, group=self.pg)
+            for b in self.model.buffers():
+                torch.distributed.broadcast(b, src, group=self.pg)
+
     # -- hipGraph replay ----------------------------------------------------------------------------------------
     def capture(self, lr_img: torch.Tensor, hr_img: torch.Tensor, warmup: int = 2):
-        """Capture one full step on static input buffers; afterwards `replay(lr, hr)` copies new data in and launches
-        the graph.  (Collectives are kept outside graphs: with world_size > 1 use step().)"""
-        if self.world > 1:
-            raise RuntimeError("graph capture is single-process; multi-GPU steps run eagerly around the RCCL call")
+        """Capture the step on static input buffers: one graph for world_size 1; two graphs (before / after the RCCL
+        all-reduce, which stays an ordinary stream-ordered call between them) for world_size > 1.
+        `replay(lr, hr)` copies new data into the static buffers and launches the graph(s)."""
         self._lr = lr_img.clone()
         self._hr = hr_img.clone()
         s = torch.cuda.Stream()
@@ -76,11 +97,20 @@ class TSRNTrainStep:
             for _ in range(warmup):
                 self.step(self._lr, self._hr)
         torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._graph_loss = self.step(self._lr, self._hr)
-        self._graph = g
-        return g
+        torch.cuda.synchronize()
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._graph_loss = self._phase_a(self._lr, self._hr)
+            if self.world == 1:
+                self._phase_b()
+        self._graph = ga
+        self._graph_b = None
+        if self.world > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                self._phase_b()
+            self._graph_b = gb
+        return ga
 
     def replay(self, lr_img: Optional[torch.Tensor] = None, hr_img: Optional[torch.Tensor] = None) -> torch.Tensor:
         if lr_img is not None:
@@ -88,4 +118,7 @@ class TSRNTrainStep:
         if hr_img is not None:
             self._hr.copy_(hr_img)
         self._graph.replay()
+        if self._graph_b is not None:
+            self._exchange()
+            self._graph_b.replay()
         return self._graph_loss

@@ -228,6 +228,10 @@ def bn_bwd_apply(da, da2, y, M, C_, scale, shift, act, coef, dy):
     _launch("tpgsr_bn_bwd_apply", _p(da), _p(da2), _p(y), M, C_, _p(scale), _p(shift), act_code(act), _p(coef), _p(dy))
 
 
+def affine_act(x, M, C_, scale, shift, act, out):
+    _launch("tpgsr_affine_act", _p(x), M, C_, _p(scale), _p(shift), act_code(act), _p(out))
+
+
 def affine_act_pool(x, N, H, W, C_, scale, shift, act, ph, pw, out):
     _launch("tpgsr_affine_act_pool", _p(x), N, H, W, C_, _p(scale), _p(shift), act_code(act), ph, pw, _p(out))
 
