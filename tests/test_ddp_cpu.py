@@ -1,0 +1,87 @@
+"""CPU / gloo, world_size 2: the data-parallel exchange logic and its semantics:
+two ranks x batch b with summed-then-averaged flat gradients == one rank accumulating two micro-batches of b with
+per-micro-batch BatchNorm statistics, and identical parameters on every rank after the step."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _flat(grads):
+    return torch.cat([g.reshape(-1) for g in grads])
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import tpgsr_oracle as O
+    from tpgsr_amd.distributed import broadcast_state, exchange_gradients, shard_seed
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=False, mask=True, srb_nums=1), 5 + rank)   # ranks start DIFFERENT on purpose
+    p = O.as_params(sd)
+    keys = O.trainable_keys(p)
+    flat = _flat([p[k].detach() for k in keys])
+    bufs = [v for k, v in p.items() if "running_" in k]
+    broadcast_state(flat, bufs, 0)                                  # rank 0's parameters everywhere
+    ofs = 0
+    with torch.no_grad():
+        for k in keys:
+            n = p[k].numel()
+            p[k].copy_(flat[ofs:ofs + n].view_as(p[k]))
+            ofs += n
+    lr, hr = O.synthetic_batch(2, shard_seed(1234, rank))
+    sr = O.tsrn_forward(p, lr, training=True, stn=False, srb_nums=1)
+    loss = O.image_loss(sr, hr).mean() * 100
+    grads = torch.autograd.grad(loss, [p[k] for k in keys])
+    g = _flat(grads)
+    exchange_gradients(g)                                            # ONE flat all-reduce
+    g /= world
+    opt = O.AdamState([p[k] for k in keys])
+    gl, ofs = [], 0
+    for k in keys:
+        n = p[k].numel()
+        gl.append(g[ofs:ofs + n].view_as(p[k]).clone())
+        ofs += n
+    O.clip_grad_norm_(gl, 0.25)
+    opt.step(gl)
+    q.put((rank, _flat([p[k].detach() for k in keys]), g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_exchange_matches_gradient_accumulation():
+    sys.path.insert(0, ROOT)
+    from oracle import tpgsr_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+    (_, p0, g0), (_, p1, g1) = res
+    assert torch.equal(p0, p1), "ranks diverged after an identical update"
+    assert torch.equal(g0, g1)
+    # single-process reference: two micro-batches (BN statistics per micro-batch), gradients averaged
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=False, mask=True, srb_nums=1), 5)
+    p = O.as_params(sd)
+    keys = O.trainable_keys(p)
+    acc = None
+    for r in range(2):
+        lr, hr = O.synthetic_batch(2, 1234 + r)
+        sr = O.tsrn_forward(p, lr, training=True, stn=False, srb_nums=1)
+        loss = O.image_loss(sr, hr).mean() * 100
+        gr = torch.cat([x.reshape(-1) for x in torch.autograd.grad(loss, [p[k] for k in keys])])
+        acc = gr if acc is None else acc + gr
+    acc /= 2
+    assert (acc - g0).abs().max() <= 1e-5 * acc.abs().max()

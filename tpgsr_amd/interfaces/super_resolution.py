@@ -10,6 +10,7 @@ from typing import Optional
 import torch
 
 from .. import kernels as K
+from ..distributed import broadcast_state, exchange_gradients
 from ..optim import FusedAdam
 
 _NBLK = 128
@@ -57,7 +58,7 @@ class TSRNTrainStep:
     def _exchange(self):
         """ONE flat bucket: RCCL all-reduce (sum) of the gradient arena over xGMI; the 1/world average is in phase B"""
         if self.world > 1:
-            torch.distributed.all_reduce(self.model._engine().arena.grad, group=self.pg)
+            exchange_gradients(self.model._engine().arena.grad, self.pg)
 
     def _phase_b(self):
         eng = self.model._engine()
@@ -80,9 +81,7 @@ class TSRNTrainStep:
         if self.world > 1:
             eng = self.model._engine()
             eng.bind(next(self.model.parameters()).device)
-            torch.distributed.broadcast(eng.arena.flat, src, group=self.pg)
-            for b in self.model.buffers():
-                torch.distributed.broadcast(b, src, group=self.pg)
+            broadcast_state(eng.arena.flat, self.model.buffers(), src, self.pg)
 
     # -- hipGraph replay ----------------------------------------------------------------------------------------
     def capture(self, lr_img: torch.Tensor, hr_img: torch.Tensor, warmup: int = 2):
