@@ -15,6 +15,15 @@
 #define KC 32
 #define ALD (BM + 1)
 
+// XCD-aware block order (MI355X: block b runs on XCD b % 8, each XCD has a private L2): give every XCD a CONTIGUOUS
+// range of logical tiles so neighbouring tiles (which share halo rows / the same pixel chunk) hit the same L2.
+// Bijective for any total (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int L, int total) {
+  int q = total >> 3, r = total & 7;
+  int xcd = L & 7, j = L >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 struct PixelPos {
   int n, oh, ow;
   bool valid;
@@ -215,7 +224,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int nbn = (a.Cout + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = tile / nbn;
+  const int m0 = mblk * BM, n0 = (tile - mblk * nbn) * BN;
   const int ntaps = a.KH * a.KW;
   const int cin4 = a.Cin >> 2;
   const int nchunks = (K + KC - 1) / KC;
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
     }
     __syncthreads();
     if (tid < BN && n0 + tid < a.Cout) {
-      float* dst = a.bn_partial + (size_t)blockIdx.x * 2 * a.Cout;
+      float* dst = a.bn_partial + (size_t)mblk * 2 * a.Cout;
       dst[n0 + tid] = red[0 * BN + tid] + red[2 * BN + tid];
       dst[a.Cout + n0 + tid] = red[1 * BN + tid] + red[3 * BN + tid];
     }
@@ -381,7 +393,7 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   long long M = (long long)a->N * a->OH * a->OW;
   int K = a->KH * a->KW * a->Cin;
   TPGSR_CHECK_ARG(M < (1ll << 31), "tpgsr_conv_fwd: M too large");
-  dim3 grid(cdiv(M, BM), cdiv(a->Cout, BN));
+  dim3 grid(cdiv(M, BM) * cdiv(a->Cout, BN));
   int vecB = ((a->Cout & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
@@ -433,8 +445,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wn = wave >> 1;
-  const int k0 = blockIdx.x * WK, n0 = blockIdx.y * BN;
-  const int mbeg = blockIdx.z * MB;
+  const int nkb = (K + WK - 1) / WK, nnb = (a.Cout + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);       // k-block fastest: the k-blocks of one pixel split share an L2
+  const int kblk = tile % nkb, nblk = (tile / nkb) % nnb, zblk = tile / (nkb * nnb);
+  const int k0 = kblk * WK, n0 = nblk * BN;
+  const int mbeg = zblk * MB;
   const int mend = min(M, mbeg + MB);
   const int ntaps = a.KH * a.KW;
   const int cin4 = a.Cin >> 2;
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float dbacc = 0.f;
-  const bool want_db = (w.dbpart != nullptr) && blockIdx.x == 0 && tid < BN;
+  const bool want_db = (w.dbpart != nullptr) && kblk == 0 && tid < BN;
 
   if (mbeg < mend) {
     load_chunk(mbeg);
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
     }
   }
   const int n = n0 + bcol;
-  float* dst = w.part + (size_t)blockIdx.z * K * a.Cout;
+  float* dst = w.part + (size_t)zblk * K * a.Cout;
   if (n < a.Cout) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
       if (k < K) dst[(size_t)k * a.Cout + n] = acc[r];
     }
   }
-  if (want_db && n0 + tid < a.Cout) w.dbpart[(size_t)blockIdx.z * a.Cout + n0 + tid] = dbacc;
+  if (want_db && n0 + tid < a.Cout) w.dbpart[(size_t)zblk * a.Cout + n0 + tid] = dbacc;
 }
 
 static void wgrad_plan(long long M, int K, int Cout, int* Z, int* MB) {
@@ -584,7 +599,7 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   int K = a->KH * a->KW * a->Cin;
   int Z, MB;
   wgrad_plan(M, K, a->Cout, &Z, &MB);
-  dim3 grid(cdiv(K, WK), cdiv(a->Cout, BN), Z);
+  dim3 grid(cdiv(K, WK) * cdiv(a->Cout, BN) * Z);
   int vecY = (!w->dy_ps && (a->Cout & 3) == 0 && (w->dy_ld & 3) == 0 && (w->dy_coff & 3) == 0 &&
               ((uintptr_t)w->dy & 15) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
