@@ -9,7 +9,7 @@
 #include "common.h"
 
 #define GRU_H 32
-#define WAVES_PER_BLOCK 4
+#define WAVES_PER_BLOCK 1   // one wavefront per workgroup: the per-step barriers degenerate to wave-local ordering
 
 struct SeqGeom {
   long long base;    // pixel index of t = 0
@@ -50,7 +50,7 @@ __device__ __forceinline__ void load_rows(const float* w_hh, int d, int j, float
   }
 }
 
-__global__ __launch_bounds__(256) void bigru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+__global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                         const float* __restrict__ b_hh, int N, int H, int W, int axis,
                                                         float* __restrict__ h_out) {
   __shared__ __attribute__((aligned(16))) float hs[WAVES_PER_BLOCK][64];
@@ -77,17 +77,24 @@ __global__ __launch_bounds__(256) void bigru_fwd_kernel(const float* __restrict_
       const float* p = gi + pix_of(step + 1) * 192 + d * 96 + j;
       ngr = p[0]; ngz = p[32]; ngn = p[64];
     }
-    float ar = br, az = bz, an = bn;
-    const float4* hp = reinterpret_cast<const float4*>(&hs[wave][d * 32]);
+    // W_hh h: 4 independent FMA chains per gate (the serial recurrence is latency-bound: one wave per SIMD)
+    float ar, az, an;
+    {
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+      const float4* hp = reinterpret_cast<const float4*>(&hs[wave][d * 32]);
 #pragma unroll
-    for (int k = 0; k < GRU_H / 4; ++k) {
-      float4 hv = hp[k];
-      ar = fmaf(wr[4 * k], hv.x, ar); ar = fmaf(wr[4 * k + 1], hv.y, ar);
-      ar = fmaf(wr[4 * k + 2], hv.z, ar); ar = fmaf(wr[4 * k + 3], hv.w, ar);
-      az = fmaf(wz[4 * k], hv.x, az); az = fmaf(wz[4 * k + 1], hv.y, az);
-      az = fmaf(wz[4 * k + 2], hv.z, az); az = fmaf(wz[4 * k + 3], hv.w, az);
-      an = fmaf(wn[4 * k], hv.x, an); an = fmaf(wn[4 * k + 1], hv.y, an);
-      an = fmaf(wn[4 * k + 2], hv.z, an); an = fmaf(wn[4 * k + 3], hv.w, an);
+      for (int k = 0; k < GRU_H / 4; ++k) {
+        float4 hv = hp[k];
+        r0 = fmaf(wr[4 * k], hv.x, r0); r1 = fmaf(wr[4 * k + 1], hv.y, r1);
+        r2 = fmaf(wr[4 * k + 2], hv.z, r2); r3 = fmaf(wr[4 * k + 3], hv.w, r3);
+        z0 = fmaf(wz[4 * k], hv.x, z0); z1 = fmaf(wz[4 * k + 1], hv.y, z1);
+        z2 = fmaf(wz[4 * k + 2], hv.z, z2); z3 = fmaf(wz[4 * k + 3], hv.w, z3);
+        n0 = fmaf(wn[4 * k], hv.x, n0); n1 = fmaf(wn[4 * k + 1], hv.y, n1);
+        n2 = fmaf(wn[4 * k + 2], hv.z, n2); n3 = fmaf(wn[4 * k + 3], hv.w, n3);
+      }
+      ar = br + ((r0 + r1) + (r2 + r3));
+      az = bz + ((z0 + z1) + (z2 + z3));
+      an = bn + ((n0 + n1) + (n2 + n3));
     }
     float r = sigmoid_f(gr + ar);
     float z = sigmoid_f(gz + az);
@@ -106,7 +113,7 @@ extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* 
   TPGSR_CHECK_ARG(gi && w_hh && b_hh && h_out, "tpgsr_bigru_fwd: null pointer");
   TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "tpgsr_bigru_fwd: bad geometry");
   int nseq = axis == 0 ? N * H : N * W;
-  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(cdiv(nseq, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, gi, w_hh, b_hh,
+  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(cdiv(nseq, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t)stream, gi, w_hh, b_hh,
                      N, H, W, axis, h_out);
   TPGSR_LAUNCH_CHECK("tpgsr_bigru_fwd");
 }
@@ -117,7 +124,7 @@ extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* 
 //   outputs: dgi [P][192]  = (dr_pre, dz_pre, dn_pre)   -> dW_ih, db_ih, d(input) by GEMM
 //            dgh [P][192]  = (dr_pre, dz_pre, dn_pre*r) -> dW_hh, db_hh by GEMM against the shifted states
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bigru_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ h_out,
+__global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ h_out,
                                                         const float* __restrict__ dh_out, const float* __restrict__ dh_out2,
                                                         const float* __restrict__ w_hh, const float* __restrict__ b_hh,
                                                         int N, int H, int W, int axis, float* __restrict__ dgi,
@@ -139,31 +146,48 @@ __global__ __launch_bounds__(256) void bigru_bwd_kernel(const float* __restrict_
   const float br = b_hh[d * 96 + j], bz = b_hh[d * 96 + 32 + j], bn = b_hh[d * 96 + 64 + j];
   const int T = g.T;
   float dh_carry = 0.f;
+  // operands of one step: previous state, input projections, incoming gradient -- prefetched one step ahead so the
+  // global loads never sit on the serial dependency chain
+  auto fetch = [&](int step, float& hprev, float& gr, float& gz, float& gn, float& dho) {
+    hprev = gr = gz = gn = dho = 0.f;
+    if (!g.active || step < 0) return;
+    const int t = d == 0 ? step : T - 1 - step;
+    const int tprev = d == 0 ? t - 1 : t + 1;
+    const long long pix = g.base + (long long)t * g.stride;
+    if (step > 0) hprev = h_out[(g.base + (long long)tprev * g.stride) * 64 + d * 32 + j];
+    const float* p = gi + pix * 192 + d * 96 + j;
+    gr = p[0]; gz = p[32]; gn = p[64];
+    dho = dh_out[pix * 64 + d * 32 + j];
+    if (dh_out2) dho += dh_out2[pix * 64 + d * 32 + j];
+  };
+  float n_hprev, n_gr, n_gz, n_gn, n_dho;
+  fetch(T - 1, n_hprev, n_gr, n_gz, n_gn, n_dho);
   for (int step = T - 1; step >= 0; --step) {   // `step` = position in the direction's own forward order
     const int t = d == 0 ? step : T - 1 - step;
-    const int tprev = d == 0 ? t - 1 : t + 1;   // time index that produced h_prev
     const long long pix = g.base + (long long)t * g.stride;
-    float hprev = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, dh = dh_carry;
-    if (g.active) {
-      if (step > 0) hprev = h_out[(g.base + (long long)tprev * g.stride) * 64 + d * 32 + j];
-      const float* p = gi + pix * 192 + d * 96 + j;
-      gr = p[0]; gz = p[32]; gn = p[64];
-      dh += dh_out[pix * 64 + d * 32 + j];
-      if (dh_out2) dh += dh_out2[pix * 64 + d * 32 + j];
-    }
+    const float hprev = n_hprev, gr = n_gr, gz = n_gz, gn = n_gn;
+    const float dh = dh_carry + n_dho;
+    fetch(step - 1, n_hprev, n_gr, n_gz, n_gn, n_dho);
     hs[wave][lane] = hprev;
     __syncthreads();
-    float ar = br, az = bz, an = bn;
-    const float4* hp = reinterpret_cast<const float4*>(&hs[wave][d * 32]);
+    // W_hh h: 4 independent FMA chains per gate (the serial recurrence is latency-bound: one wave per SIMD)
+    float ar, az, an;
+    {
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+      const float4* hp = reinterpret_cast<const float4*>(&hs[wave][d * 32]);
 #pragma unroll
-    for (int k = 0; k < GRU_H / 4; ++k) {
-      float4 hv = hp[k];
-      ar = fmaf(wr[4 * k], hv.x, ar); ar = fmaf(wr[4 * k + 1], hv.y, ar);
-      ar = fmaf(wr[4 * k + 2], hv.z, ar); ar = fmaf(wr[4 * k + 3], hv.w, ar);
-      az = fmaf(wz[4 * k], hv.x, az); az = fmaf(wz[4 * k + 1], hv.y, az);
-      az = fmaf(wz[4 * k + 2], hv.z, az); az = fmaf(wz[4 * k + 3], hv.w, az);
-      an = fmaf(wn[4 * k], hv.x, an); an = fmaf(wn[4 * k + 1], hv.y, an);
-      an = fmaf(wn[4 * k + 2], hv.z, an); an = fmaf(wn[4 * k + 3], hv.w, an);
+      for (int k = 0; k < GRU_H / 4; ++k) {
+        float4 hv = hp[k];
+        r0 = fmaf(wr[4 * k], hv.x, r0); r1 = fmaf(wr[4 * k + 1], hv.y, r1);
+        r2 = fmaf(wr[4 * k + 2], hv.z, r2); r3 = fmaf(wr[4 * k + 3], hv.w, r3);
+        z0 = fmaf(wz[4 * k], hv.x, z0); z1 = fmaf(wz[4 * k + 1], hv.y, z1);
+        z2 = fmaf(wz[4 * k + 2], hv.z, z2); z3 = fmaf(wz[4 * k + 3], hv.w, z3);
+        n0 = fmaf(wn[4 * k], hv.x, n0); n1 = fmaf(wn[4 * k + 1], hv.y, n1);
+        n2 = fmaf(wn[4 * k + 2], hv.z, n2); n3 = fmaf(wn[4 * k + 3], hv.w, n3);
+      }
+      ar = br + ((r0 + r1) + (r2 + r3));
+      az = bz + ((z0 + z1) + (z2 + z3));
+      an = bn + ((n0 + n1) + (n2 + n3));
     }
     float r = sigmoid_f(gr + ar);
     float z = sigmoid_f(gz + az);
@@ -182,20 +206,21 @@ __global__ __launch_bounds__(256) void bigru_bwd_kernel(const float* __restrict_
     gs[wave][1][lane] = dz_pre;
     gs[wave][2][lane] = dghn;
     __syncthreads();
-    float acc = dh * z;
     const float4* pr = reinterpret_cast<const float4*>(&gs[wave][0][d * 32]);
     const float4* pz = reinterpret_cast<const float4*>(&gs[wave][1][d * 32]);
     const float4* pn = reinterpret_cast<const float4*>(&gs[wave][2][d * 32]);
+    float c0 = dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll
     for (int k = 0; k < GRU_H / 4; ++k) {
       float4 a = pr[k], b = pz[k], c = pn[k];
-      acc = fmaf(tr[4 * k], a.x, acc); acc = fmaf(tr[4 * k + 1], a.y, acc);
-      acc = fmaf(tr[4 * k + 2], a.z, acc); acc = fmaf(tr[4 * k + 3], a.w, acc);
-      acc = fmaf(tz[4 * k], b.x, acc); acc = fmaf(tz[4 * k + 1], b.y, acc);
-      acc = fmaf(tz[4 * k + 2], b.z, acc); acc = fmaf(tz[4 * k + 3], b.w, acc);
-      acc = fmaf(tn[4 * k], c.x, acc); acc = fmaf(tn[4 * k + 1], c.y, acc);
-      acc = fmaf(tn[4 * k + 2], c.z, acc); acc = fmaf(tn[4 * k + 3], c.w, acc);
+      c0 = fmaf(tr[4 * k], a.x, c0); c1 = fmaf(tr[4 * k + 1], a.y, c1);
+      c2 = fmaf(tr[4 * k + 2], a.z, c2); c3 = fmaf(tr[4 * k + 3], a.w, c3);
+      c0 = fmaf(tz[4 * k], b.x, c0); c1 = fmaf(tz[4 * k + 1], b.y, c1);
+      c2 = fmaf(tz[4 * k + 2], b.z, c2); c3 = fmaf(tz[4 * k + 3], b.w, c3);
+      c0 = fmaf(tn[4 * k], c.x, c0); c1 = fmaf(tn[4 * k + 1], c.y, c1);
+      c2 = fmaf(tn[4 * k + 2], c.z, c2); c3 = fmaf(tn[4 * k + 3], c.w, c3);
     }
+    const float acc = (c0 + c1) + (c2 + c3);
     dh_carry = acc;
     // next iteration's hs write is ordered behind this iteration's hs reads by the barrier above;
     // its gs write is ordered behind these gs reads by the next hs barrier.
@@ -208,7 +233,7 @@ extern "C" int tpgsr_bigru_bwd(const float* gi, const float* h_out, const float*
   TPGSR_CHECK_ARG(gi && h_out && dh_out && w_hh && b_hh && dgi && dgh, "tpgsr_bigru_bwd: null pointer");
   TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "tpgsr_bigru_bwd: bad geometry");
   int nseq = axis == 0 ? N * H : N * W;
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(cdiv(nseq, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, gi, h_out,
+  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(cdiv(nseq, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t)stream, gi, h_out,
                      dh_out, dh_out2, w_hh, b_hh, N, H, W, axis, dgi, dgh);
   TPGSR_LAUNCH_CHECK("tpgsr_bigru_bwd");
 }
