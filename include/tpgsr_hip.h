@@ -32,6 +32,8 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc): a binding can verify its mirror */
+int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), stride 1.
@@ -63,6 +65,14 @@ typedef struct {
   int out_ld, out_coff;
   int out_act;            /* NONE / RELU / TANH */
   int out_ps;             /* 1: store pixel-shuffled (nn.PixelShuffle(2), model/tsrn.py:469): [N][2OH][2OW][Cout/4] */
+  /* --- text-prior path (TSRN_TL, model/tsrn.py:81-108, :411-426) --- */
+  const float* in_b;      /* optional second channel source: channels c >= cin_a come from this [N][W][Cin - cin_a]
+                             strip, broadcast over H (torch.cat([residual, text_emb], 1) without materialising it) */
+  int cin_a, in_b_ld;
+  int in_dil_w;           /* >1: `in` is zero-dilated along W by this factor (logical W = (Wreal-1)*dil+1): the
+                             stride-s ConvTranspose2d of InfoGen run as a stride-1 conv over the dilated strip */
+  int wt_ld, wt_coff;     /* row stride / column offset of `wt` (0 = Cout / 0): lets a dgrad run on a column block */
+  int stride_w;           /* output stride along W (0/1 = dense): iw = ow*stride_w + kw - pad_w (dgrad of a ConvTranspose2d) */
 } tpgsr_conv_args;
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);
@@ -87,6 +97,7 @@ int tpgsr_conv_wgrad(const tpgsr_wgrad_args* a, void* stream);
  *   layout 0: conv / linear weight [Cout][Cin][KH][KW]
  *   layout 1: ConvTranspose2d weight [Cin][Cout][KH][KW] run as its equivalent conv (flipped taps)
  *   layout 2: the folded tail conv (KH = KS, KW = 1, Cout = KS*Co) back to [Co][Cin][KS][KS]
+ *   layout 3: InfoGen's ConvTranspose2d on an H=1 strip (1x3 conv, flipped taps) back to [Cin][Cout][3][3], row kh=1
  * and db (+)= sum_z dbpart[z].  accumulate != 0 adds to the existing gradient (autograd semantics). */
 int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
                        int layout, float* dw, float* db, int accumulate, float gscale /* multiplies dw only */,
@@ -106,6 +117,7 @@ int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, f
  *   kind 0: conv/linear weight [Cout][Cin][KH][KW] -> dst_f[k*f_ld + f_coff + co] and/or dst_d (dgrad operand)
  *   kind 1: tail conv [Co][C][KS][KS] folded (Cout = Co, KH = KW = KS)     kind 2: plain copy of numel floats
  *   kind 3: ConvTranspose2d weight [Cin][Cout][KH][KW] as its equivalent conv
+ *   kind 4: ConvTranspose2d weight [Cin][Cout][3][3] on an H=1 strip -> 1x3 conv operand (kh=1 slice, taps flipped)
  * blk0 = prefix sum of ceil(numel/256) over the preceding descriptors; total_blocks = the full sum. */
 typedef struct {
   const float* src;
@@ -203,6 +215,18 @@ int tpgsr_grid_sample_fwd(const float* in, const float* grid, int N, int H, int 
 int tpgsr_grid_sample_bwd(const float* in, const float* grid, const float* dout, int N, int H, int W, int C,
                           int OH, int OW, int align_corners, float* din /* optional; zero-filled by callee */,
                           float* dgrid /* optional */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Text-prior strip (TSRN_TL): F.interpolate(strip, (H, W), bilinear, align_corners=True) of a [N][1][Win][C] strip
+ * (model/tsrn.py:196) is a 1-D resample along W (rows are copies): out [N][Wout][C] = lerp of relu(scale*in+shift).
+ * ---------------------------------------------------------------------------------------------- */
+int tpgsr_strip_resample_fwd(const float* in, const float* scale, const float* shift, int act, int N, int Win, int Wout,
+                             int C, float* out, void* stream);
+/* d(pre-activation in) from dout [N][Wout][C] (dz = d relu(scale*in+shift) wrt its argument; BN backward follows) */
+int tpgsr_strip_resample_bwd(const float* in, const float* scale, const float* shift, int act, const float* dout, int N,
+                             int Win, int Wout, int C, float* dz, void* stream);
+/* dstrip[n][w][c] (+)= sum_h d[n][h][w][c]  (gradient of the H-broadcast) */
+int tpgsr_hsum(const float* d, int N, int H, int W, int C, float* dstrip, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tail: out = tanh(bias + sum_kw P[h][w+kw-4][kw][co])  (model/tsrn.py:159,213), NCHW output

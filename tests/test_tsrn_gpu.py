@@ -162,3 +162,70 @@ def test_stn_stage_by_stage_vs_oracle():
           f"  sr err {(sr.cpu() - y).abs().max().item():.3e}")
     assert e_ctrl < 2e-5        # STN head (6 conv+BN+ReLU+pool stages, fc1+BN1d, fc2) is exact to fp32 noise
     assert e_src < 5e-5 and e_xr2 < 2e-3
+
+
+def _build_tl(stn=True, seed=102):
+    from tpgsr_amd.model import tsrn
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=stn, mask=True, text_prior=True), seed, tps_hw=(16, 64))
+    net = tsrn.TSRN_TL(STN=stn, mask=True)
+    net.load_state_dict(sd, strict=True)
+    return net.to(DEV), sd
+
+
+def test_tsrn_tl_vs_golden(golden_dir):
+    """TSRN_TL (text-prior fusion: InfoGen strip + concat loader) against the reference fixture."""
+    g = np.load(os.path.join(golden_dir, "model_tsrn_tl.npz"))
+    net, sd = _build_tl()
+    lr, hr, prior = (torch.tensor(g[k]).to(DEV) for k in ("lr", "hr", "extra0"))
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    net.train()
+    sr = net(lr, prior)
+    err = (sr.detach().cpu() - torch.tensor(g["y_train"])).abs().max().item()
+    print("TL train fwd max err", err)
+    assert err < 5e-3
+    loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr).mean() * 100
+    assert abs(loss.item() - float(g["loss"])) < 3e-4 * float(g["loss"])
+    loss.backward()
+    P = dict(net.named_parameters())
+    gmax = g["grad_norms"].max()
+    for n, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        e = abs(P[n].grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-3 * gmax)
+        assert e < 2e-2, (n, e, ref_norm)
+    net2, _ = _build_tl()
+    net2.eval()
+    with torch.no_grad():
+        y = net2(lr, prior)
+    err = (y.cpu() - torch.tensor(g["y_eval"])).abs().max().item()
+    print("TL eval fwd max err", err)
+    assert err < 5e-5
+
+
+def test_tsrn_tl_gradients_vs_oracle_nostn():
+    """all parameter gradients AND the gradient w.r.t. the text prior, element-wise vs oracle autograd"""
+    net, sd = _build_tl(stn=False, seed=9)
+    lr, hr = O.synthetic_batch(3, 6)
+    g = torch.Generator().manual_seed(4)
+    prior = torch.softmax(torch.randn(3, 37, 1, 26, generator=g) * 2, 1)
+    p = O.as_params(sd)
+    pr = prior.clone().requires_grad_(True)
+    y = O.tsrn_forward(p, lr, pr, training=True, stn=False, text_prior=True)
+    loss_ref = O.image_loss(y, hr).mean() * 100
+    loss_ref.backward()
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    net.train()
+    pd = prior.to(DEV).requires_grad_(True)
+    sr = net(lr.to(DEV), pd)
+    loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.to(DEV)).mean() * 100
+    loss.backward()
+    assert (sr.detach().cpu() - y.detach()).abs().max() < 5e-5
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    bad = []
+    for n, q in net.named_parameters():
+        ref = p[n].grad
+        rel = (q.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-3 * gmax)
+        if rel > 2e-3:
+            bad.append((n, rel))
+    assert not bad, bad[:10]
+    rel = (pd.grad.cpu() - pr.grad).norm().item() / pr.grad.norm().item()
+    print("dprior rel err", rel)
+    assert rel < 2e-3

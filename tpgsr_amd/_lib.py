@@ -28,7 +28,8 @@ class ConvArgs(C.Structure):
                 ("N", ci), ("H", ci), ("W", ci), ("Cin", ci),
                 ("in_ld", ci), ("in_coff", ci), ("in2_ld", ci), ("in_act", ci), ("in_ps", ci),
                 ("Cout", ci), ("KH", ci), ("KW", ci), ("pad_h", ci), ("pad_w", ci), ("OH", ci), ("OW", ci),
-                ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci)]
+                ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci),
+                ("in_b", vp), ("cin_a", ci), ("in_b_ld", ci), ("in_dil_w", ci), ("wt_ld", ci), ("wt_coff", ci), ("stride_w", ci)]
 
 
 class WgradArgs(C.Structure):
@@ -45,6 +46,7 @@ _SIGS = {
     "tpgsr_copy": (ci, [vp, vp, ll, vp]),
     "tpgsr_zero": (ci, [vp, ll, vp]),
     "tpgsr_version": (ci, []),
+    "tpgsr_sizeof": (ci, [ci]),
     "tpgsr_conv_fwd": (ci, [C.POINTER(ConvArgs), vp]),
     "tpgsr_wgrad_splits": (ci, [ci, ci, ci]),
     "tpgsr_conv_wgrad": (ci, [C.POINTER(WgradArgs), vp]),
@@ -72,6 +74,9 @@ _SIGS = {
     "tpgsr_tps_grid_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "tpgsr_grid_sample_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_grid_sample_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_strip_resample_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_strip_resample_bwd": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_hsum": (ci, [vp, ci, ci, ci, ci, vp, ci, vp]),
     "tpgsr_tail_shiftsum_tanh": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_tail_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]),
     "tpgsr_tail_bwd_blocks": (ci, [ci, ci, ci, ci, ci]),
@@ -110,6 +115,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc)):
+        if lib.tpgsr_sizeof(which) != C.sizeof(st):
+            raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
+                                   f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")
     _lib = lib
     return lib
 

@@ -41,16 +41,27 @@ __device__ __forceinline__ PixelPos decode_pixel(const tpgsr_conv_args& a, int m
   return p;
 }
 
+// real (stored) input width: `a.W` is the logical width, zero-dilated by in_dil_w for transposed convs
+__device__ __forceinline__ int real_w(const tpgsr_conv_args& a) { return a.in_dil_w > 1 ? (a.W - 1) / a.in_dil_w + 1 : a.W; }
+__device__ __forceinline__ int stride_w(const tpgsr_conv_args& a) { return a.stride_w > 1 ? a.stride_w : 1; }
+
 // one float of the A operand: logical input element (n, ih, iw, c) after the fused prologue
 __device__ __forceinline__ float load_a_scalar(const tpgsr_conv_args& a, const PixelPos& p, int k, int K) {
   if (!p.valid || k >= K) return 0.f;
   int tap = k / a.Cin;
   int c = k - tap * a.Cin;
   int kh = tap / a.KW, kw = tap - kh * a.KW;
-  int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
+  int ih = p.oh + kh - a.pad_h, iw = p.ow * stride_w(a) + kw - a.pad_w;
   if ((unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) return 0.f;
+  int Wr = a.W;
+  if (a.in_dil_w > 1) {
+    if (iw % a.in_dil_w) return 0.f;
+    iw /= a.in_dil_w;
+    Wr = real_w(a);
+  }
   float v;
-  size_t pix = (size_t)(p.n * a.H + ih) * a.W + iw;
+  size_t pix = (size_t)(p.n * a.H + ih) * Wr + iw;
+  if (a.in_b && c >= a.cin_a) return a.in_b[((size_t)p.n * Wr + iw) * a.in_b_ld + (c - a.cin_a)];
   if (!a.in_ps) {
     v = a.in[pix * a.in_ld + a.in_coff + c];
   } else {
@@ -156,7 +167,7 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned of
 
 struct ARaw {
   float4 v, v2;
-  bool ok;
+  bool ok, raw;   // raw: value comes from the concatenated strip (no affine / activation / residual)
 };
 
 // issue the loads of one A quad (no dependent arithmetic); LD bits as in load_a_quad
@@ -165,9 +176,22 @@ __device__ __forceinline__ ARaw load_a_raw(const tpgsr_conv_args& a, __amdgpu_bu
                                            const PixelPos& p, int tap, int c, int ntaps) {
   ARaw r;
   int kh = tap / a.KW, kw = tap - kh * a.KW;
-  int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
+  int ih = p.oh + kh - a.pad_h, iw = p.ow * stride_w(a) + kw - a.pad_w;
   r.ok = p.valid && tap < ntaps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-  const unsigned pix = (unsigned)((p.n * a.H + ih) * a.W + iw);
+  int Wr = a.W;
+  if (a.in_dil_w > 1) {
+    r.ok = r.ok && (iw % a.in_dil_w) == 0;
+    iw /= a.in_dil_w;
+    Wr = real_w(a);
+  }
+  const unsigned pix = (unsigned)((p.n * a.H + ih) * Wr + iw);
+  if ((LD & 16) && c >= a.cin_a) {   // concatenated second source: an [N][W][Cb] strip broadcast over H, no prologue
+    r.v = buf_load4(rin2, r.ok ? (((unsigned)p.n * (unsigned)Wr + (unsigned)iw) * (unsigned)a.in_b_ld + (unsigned)(c - a.cin_a)) * 4u : OOB_OFF);
+    r.v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.raw = true;
+    return r;
+  }
+  r.raw = false;
   if (!(LD & 8)) {
     r.v = buf_load4(rin, r.ok ? (pix * (unsigned)a.in_ld + (unsigned)(a.in_coff + c)) * 4u : OOB_OFF);
   } else {
@@ -186,6 +210,7 @@ __device__ __forceinline__ ARaw load_a_raw(const tpgsr_conv_args& a, __amdgpu_bu
 template <int LD>
 __device__ __forceinline__ float4 finish_a(const tpgsr_conv_args& a, const ARaw& r, const float4& s, const float4& t) {
   float4 v = r.v;
+  if ((LD & 16) && r.raw) return v;   // hardware zero fill already handled padding
   if (LD & 1) {
     v.x = v.x * s.x + t.x;
     v.y = v.y * s.y + t.y;
@@ -245,10 +270,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
   ARaw qa0, qa1;
   float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int LDV = LD < 0 ? 0 : LD;
-  const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * a.W * a.in_ld;
+  const int Wr_ = real_w(a);
+  const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * Wr_ * a.in_ld;
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, in_floats);
-  const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
-  const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt, (size_t)K * a.Cout);
+  const __amdgpu_buffer_rsrc_t rs_in2 = (LDV & 16) ? make_rsrc(a.in_b, (size_t)a.N * Wr_ * a.in_b_ld)
+                                                   : make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * Wr_ * a.in2_ld);
+  const int wld = a.wt_ld > 0 ? a.wt_ld : a.Cout;
+  const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt, (size_t)K * wld);
   auto load_chunk = [&](int ch) {
     if (VEC_A) {
       int kq = ch * (KC / 4) + aq;
@@ -262,8 +290,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
       }
       int k0 = ch * KC + bk0, k1 = k0 + 16;
       const bool cok = n0 + bc < a.Cout;   // rows k >= K fall outside the buffer: hardware zero fill
-      rb0 = buf_load4(rs_wt, cok ? ((unsigned)k0 * (unsigned)a.Cout + (unsigned)(n0 + bc)) * 4u : OOB_OFF);
-      rb1 = buf_load4(rs_wt, cok ? ((unsigned)k1 * (unsigned)a.Cout + (unsigned)(n0 + bc)) * 4u : OOB_OFF);
+      rb0 = buf_load4(rs_wt, cok ? ((unsigned)k0 * (unsigned)wld + (unsigned)(a.wt_coff + n0 + bc)) * 4u : OOB_OFF);
+      rb1 = buf_load4(rs_wt, cok ? ((unsigned)k1 * (unsigned)wld + (unsigned)(a.wt_coff + n0 + bc)) * 4u : OOB_OFF);
     } else {
       int k = ch * KC + aq * 4;
       ra0 = make_float4(load_a_scalar(a, px0, k, K), load_a_scalar(a, px0, k + 1, K), load_a_scalar(a, px0, k + 2, K),
@@ -271,8 +299,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
       ra1 = make_float4(load_a_scalar(a, px1, k, K), load_a_scalar(a, px1, k + 1, K), load_a_scalar(a, px1, k + 2, K),
                         load_a_scalar(a, px1, k + 3, K));
       int k0 = ch * KC + bk0, k1 = k0 + 16;
-      rb0 = load_row4(a.wt, k0, a.Cout, n0 + bc, a.Cout, k0 < K, vecB);
-      rb1 = load_row4(a.wt, k1, a.Cout, n0 + bc, a.Cout, k1 < K, vecB);
+      rb0 = load_row4(a.wt + a.wt_coff, k0, wld, n0 + bc, a.Cout, k0 < K, vecB);
+      rb1 = load_row4(a.wt + a.wt_coff, k1, wld, n0 + bc, a.Cout, k1 < K, vecB);
     }
   };
   auto store_chunk = [&]() {
@@ -366,8 +394,12 @@ static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
   TPGSR_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0,
                   "%s: non-positive dimension", who);
   TPGSR_CHECK_ARG(a->OH > 0 && a->OW > 0, "%s: non-positive output size", who);
-  TPGSR_CHECK_ARG(a->in_ld >= a->Cin + a->in_coff || a->in_ps, "%s: in_ld %d < Cin %d + coff %d", who, a->in_ld, a->Cin,
-                  a->in_coff);
+  TPGSR_CHECK_ARG(a->in_ld >= (a->in_b ? a->cin_a : a->Cin) + a->in_coff || a->in_ps, "%s: in_ld %d < Cin %d + coff %d", who,
+                  a->in_ld, a->Cin, a->in_coff);
+  if (a->in_b)
+    TPGSR_CHECK_ARG(a->cin_a > 0 && a->cin_a < a->Cin && (a->cin_a & 3) == 0 && a->in_b_ld >= a->Cin - a->cin_a && !a->in_ps &&
+                    !a->in2 && ((a->Cin & 3) || (a->in_b_ld & 3) == 0), "%s: bad concat description", who);
+  if (a->in_dil_w > 1) TPGSR_CHECK_ARG((a->W - 1) % a->in_dil_w == 0 && !a->in_ps, "%s: bad input dilation", who);
   if (a->in_ps) TPGSR_CHECK_ARG((a->Cin & 3) == 0 && a->in_coff == 0, "%s: in_ps needs Cin %% 4 == 0", who);
   if ((a->Cin & 3) == 0 && !a->in_ps)
     TPGSR_CHECK_ARG((a->in_ld & 3) == 0 && (a->in_coff & 3) == 0 && ((uintptr_t)a->in & 15) == 0,
@@ -379,7 +411,7 @@ static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
 
 // compile-time loader variant: 1 affine, 2 activation, 4 residual add, 8 pixel-shuffle gather
 static int loader_bits(const tpgsr_conv_args* a) {
-  return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0);
+  return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0);
 }
 
 extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
@@ -398,12 +430,13 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
 #define TPGSR_FWD_CASE(B) case B: hipLaunchKernelGGL(conv_fwd_kernel<B>, grid, dim3(256), 0, st, *a, (int)M, K, vecB); break;
+  vecB = vecB && ((a->wt_ld & 3) == 0) && ((a->wt_coff & 3) == 0);
   if ((a->Cin & 3) != 0 || !vecB) {
     hipLaunchKernelGGL(conv_fwd_kernel<-1>, grid, dim3(256), 0, st, *a, (int)M, K, vecB);
   } else {
     switch (ld) {
       TPGSR_FWD_CASE(0) TPGSR_FWD_CASE(1) TPGSR_FWD_CASE(3) TPGSR_FWD_CASE(4) TPGSR_FWD_CASE(5) TPGSR_FWD_CASE(7)
-      TPGSR_FWD_CASE(8) TPGSR_FWD_CASE(2)
+      TPGSR_FWD_CASE(8) TPGSR_FWD_CASE(2) TPGSR_FWD_CASE(17)
       default:
         tpgsr_set_error("tpgsr_conv_fwd: unsupported loader combination %d", ld);
         return TPGSR_ERR_ARG;
@@ -470,9 +503,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
   ARaw qa0, qa1;
   float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int LDV = LD < 0 ? 0 : LD;
-  const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * a.W * a.in_ld;
+  const int Wr_ = real_w(a);
+  const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * Wr_ * a.in_ld;
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, in_floats);
-  const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
+  const __amdgpu_buffer_rsrc_t rs_in2 = (LDV & 16) ? make_rsrc(a.in_b, (size_t)a.N * Wr_ * a.in_b_ld)
+                                                   : make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * Wr_ * a.in2_ld);
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(w.dy, w.dy_ps ? (size_t)M * a.Cout : (size_t)M * w.dy_ld);
   if (VEC_A && (LDV & 1)) {
     qs = *reinterpret_cast<const float4*>(a.in_scale + ac);
@@ -609,7 +644,7 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
     hipLaunchKernelGGL(conv_wgrad_kernel<-1>, grid, dim3(256), 0, st, *w, (int)M, K, MB, vecY);
   } else {
     switch (ld) {
-      TPGSR_WG_CASE(0) TPGSR_WG_CASE(1) TPGSR_WG_CASE(3) TPGSR_WG_CASE(4) TPGSR_WG_CASE(5) TPGSR_WG_CASE(7) TPGSR_WG_CASE(2)
+      TPGSR_WG_CASE(0) TPGSR_WG_CASE(1) TPGSR_WG_CASE(3) TPGSR_WG_CASE(4) TPGSR_WG_CASE(5) TPGSR_WG_CASE(7) TPGSR_WG_CASE(2) TPGSR_WG_CASE(17)
       default:
         tpgsr_set_error("tpgsr_conv_wgrad: unsupported loader combination %d", ld);
         return TPGSR_ERR_ARG;
@@ -627,6 +662,8 @@ __device__ __forceinline__ size_t wgrad_out_index(int k, int co, int Cin, int Co
   if (layout == 0) return (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
   if (layout == 1)  // ConvTranspose2d weight wT[ci][co][KH-1-kh][KW-1-kw] == equivalent-conv w_eq[co][ci][kh][kw]
     return (((size_t)ci * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
+  if (layout == 3)  // InfoGen strip: 1x3 conv tap kw' of the dilated strip == wT[ci][co][1][2 - kw']
+    return (((size_t)ci * Cout + co) * 3 + 1) * 3 + (KW - 1 - kw);
   // layout 2: folded tail conv (KH = KS, KW = 1, Cout = KS*Co, n' = kw*Co + co) -> w[co][ci][kh][kw]
   int Co = Cout / KH;
   int tkw = co / Co, tco = co - tkw * Co;
@@ -777,6 +814,15 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
     int NP = d.KH * d.Cout, np = kw * d.Cout + co;  // here Cout = Co, KH = KW = KS
     if (d.dst_f) d.dst_f[((size_t)kh * d.Cin + ci) * NP + np] = v;
     if (d.dst_d) d.dst_d[((size_t)(d.KH - 1 - kh) * NP + np) * d.Cin + ci] = v;
+    return;
+  }
+  if (d.kind == 4) {  // ConvTranspose2d weight [Cin][Cout][3][3] on an H=1 strip: only the kh=1 row ever meets data
+    int co = r % d.Cout;
+    int ci = (int)(r / d.Cout);
+    if (kh != 1) return;
+    int kwp = d.KW - 1 - kw;  // tap of the equivalent stride-1 conv over the zero-dilated strip
+    if (d.dst_f) d.dst_f[((size_t)kwp * d.Cin + ci) * d.f_ld + d.f_coff + co] = v;
+    if (d.dst_d) d.dst_d[((size_t)kw * d.Cout + co) * d.Cin + ci] = v;   // strided-conv operand of the data gradient
     return;
   }
   int co, ci;

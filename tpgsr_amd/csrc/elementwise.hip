@@ -367,6 +367,98 @@ extern "C" int tpgsr_affine_act_pool_bwd(const float* x, const float* dout, int 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// text-prior strip: bilinear (align_corners=True) resample along W of act(scale*in+shift), and its backward
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void strip_src(int ow, int Win, int Wout, int& x0, int& x1, float& l) {
+  float sx = Wout > 1 ? (float)ow * ((float)(Win - 1) / (float)(Wout - 1)) : 0.f;
+  x0 = (int)sx;
+  if (x0 > Win - 1) x0 = Win - 1;
+  x1 = x0 + 1 < Win ? x0 + 1 : x0;
+  l = sx - (float)x0;
+}
+
+__global__ __launch_bounds__(256) void strip_resample_fwd_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int act, int N, int Win,
+                                                                 int Wout, int C, float* __restrict__ out) {
+  long long total = (long long)N * Wout * C;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = (int)(i % C);
+  long long r = i / C;
+  int ow = (int)(r % Wout);
+  int n = (int)(r / Wout);
+  int x0, x1;
+  float l;
+  strip_src(ow, Win, Wout, x0, x1, l);
+  float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  float a = apply_act(in[((size_t)n * Win + x0) * C + c] * sc + sh, act);
+  float b = apply_act(in[((size_t)n * Win + x1) * C + c] * sc + sh, act);
+  out[i] = a * (1.f - l) + b * l;
+}
+
+extern "C" int tpgsr_strip_resample_fwd(const float* in, const float* scale, const float* shift, int act, int N, int Win, int Wout,
+                                        int C, float* out, void* stream) {
+  TPGSR_CHECK_ARG(in && out && N > 0 && Win > 0 && Wout > 0 && C > 0, "tpgsr_strip_resample_fwd: bad arguments");
+  long long total = (long long)N * Wout * C;
+  hipLaunchKernelGGL(strip_resample_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, scale, shift, act, N,
+                     Win, Wout, C, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_strip_resample_fwd");
+}
+
+// gather form (deterministic): every input column sums the output columns that sampled it
+__global__ __launch_bounds__(256) void strip_resample_bwd_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int act,
+                                                                 const float* __restrict__ dout, int N, int Win, int Wout, int C,
+                                                                 float* __restrict__ dz) {
+  long long total = (long long)N * Win * C;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = (int)(i % C);
+  long long r = i / C;
+  int iw = (int)(r % Win);
+  int n = (int)(r / Win);
+  float g = 0.f;
+  for (int ow = 0; ow < Wout; ++ow) {
+    int x0, x1;
+    float l;
+    strip_src(ow, Win, Wout, x0, x1, l);
+    float d = dout[((size_t)n * Wout + ow) * C + c];
+    if (x0 == iw) g += d * (1.f - l);
+    if (x1 == iw) g += d * l;
+  }
+  float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  dz[i] = g * act_grad(in[i] * sc + sh, act);
+}
+
+extern "C" int tpgsr_strip_resample_bwd(const float* in, const float* scale, const float* shift, int act, const float* dout, int N,
+                                        int Win, int Wout, int C, float* dz, void* stream) {
+  TPGSR_CHECK_ARG(in && dout && dz && N > 0 && Win > 0 && Wout > 0 && C > 0, "tpgsr_strip_resample_bwd: bad arguments");
+  long long total = (long long)N * Win * C;
+  hipLaunchKernelGGL(strip_resample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, scale, shift, act,
+                     dout, N, Win, Wout, C, dz);
+  TPGSR_LAUNCH_CHECK("tpgsr_strip_resample_bwd");
+}
+
+__global__ __launch_bounds__(256) void hsum_kernel(const float* __restrict__ d, int N, int H, int W, int C, float* dstrip,
+                                                   int accumulate) {
+  long long total = (long long)N * W * C;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  long long wc = i % ((long long)W * C);
+  int n = (int)(i / ((long long)W * C));
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) s += d[((size_t)n * H + h) * W * C + wc];
+  dstrip[i] = accumulate ? dstrip[i] + s : s;
+}
+
+extern "C" int tpgsr_hsum(const float* d, int N, int H, int W, int C, float* dstrip, int accumulate, void* stream) {
+  TPGSR_CHECK_ARG(d && dstrip && N > 0 && H > 0 && W > 0 && C > 0, "tpgsr_hsum: bad arguments");
+  long long total = (long long)N * W * C;
+  hipLaunchKernelGGL(hsum_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, d, N, H, W, C, dstrip, accumulate);
+  TPGSR_LAUNCH_CHECK("tpgsr_hsum");
+}
+
+// ------------------------------------------------------------------------------------------------------
 // PReLU (single shared slope), add, activation backward, transposes, small reductions
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,

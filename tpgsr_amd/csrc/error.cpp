@@ -14,3 +14,13 @@ void tpgsr_set_error(const char* fmt, ...) {
 
 extern "C" const char* tpgsr_last_error(void) { return g_err; }
 extern "C" int tpgsr_version(void) { return 1; }
+
+// struct sizes as the C compiler lays them out: lets a foreign-language binding (ctypes / cgo / JNI) verify its mirror
+extern "C" int tpgsr_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(tpgsr_conv_args);
+    case 1: return (int)sizeof(tpgsr_wgrad_args);
+    case 2: return (int)sizeof(tpgsr_pack_desc);
+    default: return -1;
+  }
+}

@@ -154,14 +154,15 @@ class ConvLayer:
 
 
 class BNLayer:
-    def __init__(self, eng, prefix: str):
+    def __init__(self, eng, prefix: str, pad_to: int = 0):
         self.eng, self.prefix = eng, prefix
         self.gamma, self.beta = eng.P[prefix + ".weight"], eng.P[prefix + ".bias"]
         self.rm, self.rv = eng.B[prefix + ".running_mean"], eng.B[prefix + ".running_var"]
         self.C = C_ = self.gamma.numel()
         dev = eng.device
-        self.scale = torch.empty(C_, dtype=F32, device=dev)
-        self.shift = torch.empty(C_, dtype=F32, device=dev)
+        # pad_to > C: identity (1, 0) tail so a concatenated loader can index scale/shift past this BN's channels
+        self.scale = torch.ones(max(C_, pad_to), dtype=F32, device=dev)
+        self.shift = torch.zeros(max(C_, pad_to), dtype=F32, device=dev)
         self.save_mean = torch.empty(C_, dtype=F32, device=dev)
         self.save_rstd = torch.empty(C_, dtype=F32, device=dev)
         self.coef = torch.empty(3, C_, dtype=F32, device=dev)
@@ -258,6 +259,48 @@ class GruLayer:
             self.conv.dgrad(N, H, W, du, dx)
 
 
+class TConvStrip:
+    """ConvTranspose2d(Cin, Cout, 3, stride (s_h, s_w), padding (1, p_w), bias=False) on an H=1 strip (InfoGen,
+    model/tsrn.py:81-108): only the kh=1 kernel row meets data, so it is a 1-D transposed conv along W, run as a
+    stride-1 1x3 conv over the zero-dilated strip (forward / weight gradient) and as a stride-s_w conv over dy
+    (data gradient)."""
+
+    def __init__(self, eng, wname: str, stride_w: int, pad_w: int):
+        self.eng, self.wname, self.sw, self.pw = eng, wname, stride_w, pad_w
+        self.w = eng.P[wname]
+        self.Cin, self.Cout = self.w.shape[0], self.w.shape[1]
+        assert tuple(self.w.shape[2:]) == (3, 3)
+        dev = eng.device
+        self.wt_f = torch.empty(3 * self.Cin, self.Cout, dtype=F32, device=dev)
+        self.wt_d = torch.empty(3 * self.Cout, self.Cin, dtype=F32, device=dev)
+        eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=3, KW=3, kind=4, f_ld=self.Cout)
+
+    def out_w(self, Win):
+        return (Win - 1) * self.sw - 2 * self.pw + 3
+
+    def geom(self, N, Win) -> ConvGeom:
+        return ConvGeom(N, 1, (Win - 1) * self.sw + 1, self.Cin, self.Cout, 1, 3, 0, 2 - self.pw)
+
+    def fwd(self, N, Win, x, out, **kw):
+        g = self.geom(N, Win)
+        assert g.OW == self.out_w(Win)
+        K.conv_fwd(K.make_conv_args(g, x, self.wt_f, out, in_dil_w=self.sw, **kw))
+        return g
+
+    def wgrad(self, N, Win, x, dy, loader=None):
+        eng, g = self.eng, self.geom(N, Win)
+        Z = K.wgrad_splits(g.M, g.K, g.Cout)
+        part = eng.scratch("wgrad_part", Z * g.K * g.Cout)
+        ca = K.make_conv_args(g, x, in_dil_w=self.sw, **(loader or {}))
+        K.conv_wgrad(K.make_wgrad_args(ca, dy, part, None))
+        K.wgrad_reduce(part, None, Z, g, eng.G[self.wname], None, layout=3, accumulate=True)
+
+    def dgrad(self, N, Win, dy, dx):
+        """dx[N][1][Win][Cin] = strided conv of dy[N][1][OW][Cout] with the un-flipped taps"""
+        g = ConvGeom(N, 1, self.out_w(Win), self.Cout, self.Cin, 1, 3, 0, self.pw, 1, Win)
+        K.conv_fwd(K.make_conv_args(g, dy, self.wt_d, dx, stride_w=self.sw))
+
+
 # =================================================================================================================
 # TSRN engine
 # =================================================================================================================
@@ -337,13 +380,22 @@ class TSRNEngine:
         self.stn = bool(m.stn)
         self.C = self.P["block1.0.weight"].shape[0]
         self.block1 = ConvLayer(self, "block1.0.weight", "block1.0.bias", 9, 9, 4, 4, need_dgrad=self.stn)
+        self.tl = hasattr(m, "infoGen")
         self.rrb = []
         for i in range(self.srb):
             p = f"block{i + 2}"
+            g1 = GruLayer(self, p + ".gru1", axis=1)
             self.rrb.append(dict(
                 conv1=ConvLayer(self, p + ".conv1.weight", p + ".conv1.bias", 3, 3, 1, 1), bn1=BNLayer(self, p + ".bn1"),
-                conv2=ConvLayer(self, p + ".conv2.weight", p + ".conv2.bias", 3, 3, 1, 1), bn2=BNLayer(self, p + ".bn2"),
-                gru1=GruLayer(self, p + ".gru1", axis=1), gru2=GruLayer(self, p + ".gru2", axis=0)))
+                conv2=ConvLayer(self, p + ".conv2.weight", p + ".conv2.bias", 3, 3, 1, 1),
+                bn2=BNLayer(self, p + ".bn2", pad_to=g1.conv.Cin),
+                gru1=g1, gru2=GruLayer(self, p + ".gru2", axis=0)))
+        if self.tl:
+            cfg = [(2, 1), (2, 1), (2, 1), (1, 0)]       # (stride_w, pad_w) of tconv1..4 (model/tsrn.py:89-98)
+            self.ig = [TConvStrip(self, f"infoGen.tconv{i + 1}.weight", sw, pw) for i, (sw, pw) in enumerate(cfg)]
+            self.ig_bn = [BNLayer(self, f"infoGen.bn{i + 1}") for i in range(4)]
+            self.Ct = self.ig[3].Cout
+            self.emb_cls = self.ig[0].Cin
         k7 = f"block{self.srb + 2}"
         self.conv7 = ConvLayer(self, k7 + ".0.weight", k7 + ".0.bias", 3, 3, 1, 1)
         self.bn7 = BNLayer(self, k7 + ".1")
@@ -403,6 +455,7 @@ class TSRNEngine:
         b1 = ws("b1", P1, Cc)
         self.block1.fwd(N, H, W, xin, c1)
         K.prelu_fwd(c1, self.P["block1.1.weight"], P1 * Cc, b1)
+        temb = self._record_infogen_fwd(N, W, training, ws) if self.tl else None
         cur = b1
         for i, L in enumerate(self.rrb):
             t = f"r{i}_"
@@ -416,7 +469,10 @@ class TSRNEngine:
             K.affine_act(y1, P1, Cc, L["bn1"].scale, L["bn1"].shift, "mish", a1)
             L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None)
             L["bn2"].finalize(P1, L["conv2"].b, training)
-            L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, **L["bn2"].loader)
+            if self.tl:   # torch.cat([bn2(y2), text strip], 1) inside the 1x1 conv's loader (model/tsrn.py:419-423)
+                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
+            else:
+                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, **L["bn2"].loader)
             L["gru2"].fwd(N, H, W, cur, u2, gi2, out, in2=h1)
             cur = out
         y7 = ws("y7", P1, Cc)
@@ -430,6 +486,48 @@ class TSRNEngine:
         Pt = ws("Pt", 4 * P1, self.tail.Cout)
         self.tail.fwd(N, 2 * H, 2 * W, mu, Pt)
         K.tail_shiftsum_tanh(Pt, self.tail_bias, N, 2 * H, 2 * W, self.tail.Co, self.tail.KS, K.DynPtr("sr"))
+
+    def _ig_widths(self, Wp):
+        ws_ = [Wp]
+        for tc in self.ig:
+            ws_.append(tc.out_w(ws_[-1]))
+        return ws_
+
+    def _record_infogen_fwd(self, N, W, training, ws, Wp=26):
+        """InfoGen (4 x ConvTranspose2d+BN+ReLU on the H=1 strip) + F.interpolate(..., bilinear, align_corners=True)
+        -> text strip [N][W][Ct] (all H rows of the reference's spatial_t_emb are identical)."""
+        pri = ws("prior_nhwc", N * Wp, self.emb_cls)
+        K.nchw_to_nhwc(K.DynPtr("prior"), N, self.emb_cls, 1, Wp, pri)
+        widths = self._ig_widths(Wp)
+        cur, loader = pri, {}
+        for i, (tc, bn) in enumerate(zip(self.ig, self.ig_bn)):
+            out = ws(f"ig_t{i}", N * widths[i + 1], tc.Cout)
+            part, _ = bn.partial(N * widths[i + 1])
+            tc.fwd(N, widths[i], cur, out, bn_partial=part if training else None, **loader)
+            bn.finalize(N * widths[i + 1], None, training)
+            cur, loader = out, dict(in_act="relu", **bn.loader)
+        temb = ws("temb", N * W, self.Ct)
+        K.strip_resample_fwd(cur, self.ig_bn[3].scale, self.ig_bn[3].shift, "relu", N, widths[4], W, self.Ct, temb)
+        return temb
+
+    def _record_infogen_bwd(self, N, W, ws, Wp=26):
+        t = ws.t
+        widths = self._ig_widths(Wp)
+        dz = ws("ig_dz3", N * widths[4], self.Ct)
+        K.strip_resample_bwd(t["ig_t3"], self.ig_bn[3].scale, self.ig_bn[3].shift, "relu", t["dtemb"], N, widths[4], W, self.Ct, dz)
+        da, act = dz, "none"
+        for i in range(3, -1, -1):
+            tc, bn = self.ig[i], self.ig_bn[i]
+            M = N * widths[i + 1]
+            dy = ws(f"ig_dy{i}", M, tc.Cout)
+            bn.backward(da, None, t[f"ig_t{i}"], M, act, dy)
+            xin = t[f"ig_t{i - 1}"] if i > 0 else t["prior_nhwc"]
+            loader = dict(in_act="relu", **self.ig_bn[i - 1].loader) if i > 0 else {}
+            tc.wgrad(N, widths[i], xin, dy, loader=loader)
+            da = ws(f"ig_da{i}", N * widths[i], tc.Cin)
+            tc.dgrad(N, widths[i], dy, da)
+            act = "relu"
+        K.nhwc_to_nchw(da, N, self.emb_cls, 1, Wp, K.DynPtr("dprior"))
 
     def _stn_dims(self, H, W):
         dims = []
@@ -505,8 +603,17 @@ class TSRNEngine:
             y1, y2, u1, gi1, h1, u2, gi2, out = (t[p + n] for n in ("y1", "y2", "u1", "gi1", "h1", "u2", "gi2", "out"))
             # gru2 (input X + h1): parameter grads + d(X + h1) -> gA (incoming gA/gB are dead after the scan)
             L["gru2"].bwd(N, H, W, X, u2, gi2, out, gA, gB if have_B else None, dgi, dgh, du, gA, in2=h1)
-            # gru1 (input bn2(y2)): dh = gA
-            L["gru1"].bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
+            # gru1 (input bn2(y2) [+ text strip]): dh = gA
+            if self.tl:
+                g1 = L["gru1"]
+                g1.bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
+                # data gradient of the 96->64 1x1 conv in two column blocks: image features and text strip
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, Cc, Cc), du, g1.conv.wt_d, da, wt_ld=g1.conv.Cin, wt_coff=0))
+                dtb = ws("d_tb", P1, self.Ct)
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, Cc, self.Ct), du, g1.conv.wt_d, dtb, wt_ld=g1.conv.Cin, wt_coff=Cc))
+                K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
+            else:
+                L["gru1"].bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
             L["bn2"].backward(da, None, y2, P1, "none", dy)
             L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
             L["conv2"].dgrad(N, H, W, dy, da)                              # d mish(bn1(y1))
@@ -526,6 +633,8 @@ class TSRNEngine:
         self.block1.wgrad(N, H, W, xin, dc1)
         if self.stn:
             self._record_stn_bwd(N, H, W, dc1, ws)
+        if self.tl:
+            self._record_infogen_bwd(N, W, ws)
 
     def _record_stn_bwd(self, N, H, W, dc1, ws):
         t = ws.t
@@ -568,8 +677,6 @@ class TSRNEngine:
 
     # ---- execution -----------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if prior is not None:
-            raise NotImplementedError("text-prior (TSRN_TL) plan: see engine_tl (round-1 scope is config C2 first)")
         if x.dim() != 4 or x.shape[1] != self.module.in_planes:
             raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
         if not x.is_cuda:
@@ -582,6 +689,13 @@ class TSRNEngine:
         fwd = pl["fwd"]
         fwd.set_ptr("x", x.data_ptr())
         fwd.set_ptr("sr", sr.data_ptr())
+        if self.tl:
+            if prior is None or tuple(prior.shape) != (N, self.emb_cls, 1, 26) or not prior.is_cuda:
+                raise ValueError(f"TSRN_TL needs a CUDA text prior of shape ({N}, {self.emb_cls}, 1, 26)")
+            prior = prior.contiguous().float()
+            fwd.set_ptr("prior", prior.data_ptr())
+        elif prior is not None:
+            raise ValueError("this network takes no text prior")
         fwd.run()
         if training:
             self._pending_batches += 1   # num_batches_tracked is bookkeeping only (momentum is fixed): flushed lazily
@@ -604,8 +718,12 @@ class TSRNEngine:
         dsr = dsr.contiguous().float()
         bwd.set_ptr("sr", sr.data_ptr())
         bwd.set_ptr("dsr", dsr.data_ptr())
+        dprior = None
+        if self.tl:
+            dprior = torch.empty(N, self.emb_cls, 1, 26, dtype=F32, device=dsr.device)
+            bwd.set_ptr("dprior", dprior.data_ptr())
         bwd.run()
-        return None
+        return dprior
 
 
 class _FC1AsConv(ConvLayer):

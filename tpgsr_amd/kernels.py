@@ -135,12 +135,12 @@ class ConvGeom:
 
 def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, in_scale=None, in_shift=None, in_act=None,
                    in_ps=False, in_ld=None, in_coff=0, in2_ld=None, out_act=None, out_ps=False, out_ld=None, out_coff=0,
-                   bn_partial=None) -> ConvArgs:
+                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1) -> ConvArgs:
     a = ConvArgs()
     a.in_, a.in2, a.in_scale, a.in_shift = _p(inp), _p(in2), _p(in_scale), _p(in_shift)
     a.wt, a.bias, a.out, a.bn_partial = _p(wt), _p(bias), _p(out), _p(bn_partial)
     a.N, a.H, a.W, a.Cin = g.N, g.H, g.W, g.Cin
-    a.in_ld = g.Cin if in_ld is None else in_ld
+    a.in_ld = (cin_a if in_b is not None else g.Cin) if in_ld is None else in_ld
     a.in_coff = in_coff
     a.in2_ld = g.Cin if in2_ld is None else in2_ld
     a.in_act = act_code(in_act)
@@ -150,6 +150,12 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
     a.out_coff = out_coff
     a.out_act = act_code(out_act)
     a.out_ps = int(bool(out_ps))
+    a.in_b = _p(in_b)
+    a.cin_a = cin_a if in_b is not None else 0
+    a.in_b_ld = (g.Cin - cin_a) if in_b_ld is None else in_b_ld
+    a.in_dil_w = in_dil_w
+    a.wt_ld, a.wt_coff = wt_ld, wt_coff
+    a.stride_w = stride_w
     return a
 
 
@@ -295,6 +301,18 @@ def grid_sample_fwd(inp, grid, N, H, W, C_, OH, OW, align_corners, out):
 def grid_sample_bwd(inp, grid, dout, N, H, W, C_, OH, OW, align_corners, din, dgrid):
     _launch("tpgsr_grid_sample_bwd", _p(inp), _p(grid), _p(dout), N, H, W, C_, OH, OW, int(align_corners), _p(din),
                                             _p(dgrid))
+
+
+def strip_resample_fwd(inp, scale, shift, act, N, Win, Wout, C_, out):
+    _launch("tpgsr_strip_resample_fwd", _p(inp), _p(scale), _p(shift), act_code(act), N, Win, Wout, C_, _p(out))
+
+
+def strip_resample_bwd(inp, scale, shift, act, dout, N, Win, Wout, C_, dz):
+    _launch("tpgsr_strip_resample_bwd", _p(inp), _p(scale), _p(shift), act_code(act), _p(dout), N, Win, Wout, C_, _p(dz))
+
+
+def hsum(d, N, H, W, C_, dstrip, accumulate=True):
+    _launch("tpgsr_hsum", _p(d), N, H, W, C_, _p(dstrip), int(accumulate))
 
 
 # ---- tail / loss / optimiser ----------------------------------------------------------------------------------
