@@ -229,6 +229,35 @@ int tpgsr_strip_resample_bwd(const float* in, const float* scale, const float* s
 int tpgsr_hsum(const float* d, int N, int H, int W, int C, float* dstrip, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Text-prior generator (CRNN) pieces -- model/crnn/crnn.py:29-90, interfaces/base.py:806-829,
+ * loss/semantic_loss.py:21-39, interfaces/super_resolution.py:316-321,372-382
+ * ---------------------------------------------------------------------------------------------- */
+/* parse_crnn_data: F.interpolate(x[:, :3], (OH, OW), 'bicubic') (A=-0.75, align_corners False) + 0.299R+0.587G+0.114B.
+ * in: NCHW [N][Ctot>=3][H][W]  ->  out [N][OH][OW] (= NHWC with C = 1).  bwd: adjoint into din (NCHW, zero-filled here). */
+int tpgsr_bicubic_gray_fwd(const float* in_nchw, int N, int Ctot, int H, int W, int OH, int OW, float* out, void* stream);
+int tpgsr_bicubic_gray_bwd(const float* dout, int N, int Ctot, int H, int W, int OH, int OW, float* din_nchw, void* stream);
+/* nn.MaxPool2d((KH,KW),(SH,SW),(PH,PW)) of act(scale*x+shift), NHWC; bwd returns d(pre-activation) (first arg-max wins) */
+int tpgsr_pool2d_fwd(const float* x, int N, int H, int W, int C, const float* scale, const float* shift, int act, int KH,
+                     int KW, int SH, int SW, int PH, int PW, float* out, void* stream);
+int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale, const float* shift,
+                     int act, int KH, int KW, int SH, int SW, int PH, int PW, float* dz, void* stream);
+/* One BiLSTM time step for both directions (gate order i,f,g,o).  G [N][T][2][4Hh]: input projections in, activated
+ * gates out (fwd) / gate gradients out (bwd); gh [2][N][4Hh] = W_hh h_prev of this step (MFMA GEMM, unused at step 0);
+ * Cst [N][T][2][Hh]; out [N][T][2Hh].  bwd: dhc [2][N][Hh] = W_hh^T dG of the previous backward step, dcc [N][2][Hh]. */
+int tpgsr_lstm_step_fwd(float* G, const float* gh, const float* bhh /* [2][4Hh], optional */, float* Cst, float* out, int N,
+                        int T, int Hh, int step, void* stream);
+int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, float* dcc, int N, int T, int Hh,
+                        int step, void* stream);
+/* p = softmax(logits [N][T][C]); prior (N,C,1,T) = p with samples [0, drop_n) zeroed (prior dropout); with q: partial
+ * sums of SemanticLoss = mean|q-p| + KLDivLoss('mean')(log(p+1e-20), q+1e-20).  bwd: dlogits from dprior (+dp_in) and
+ * the semantic loss weighted by wsem. */
+int tpgsr_softmax_prior_fwd(const float* logits, const float* q, int N, int T, int C, int drop_n, float* p, float* prior_nchw,
+                            float* partial, int nblk, void* stream);
+int tpgsr_semantic_loss_finalize(const float* partial, int nblk, long long count, float w, float* loss, void* stream);
+int tpgsr_softmax_prior_bwd(const float* p, const float* q, const float* dprior_nchw, const float* dp_in, int N, int T, int C,
+                            int drop_n, float wsem, float* dlogits, int nblk, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Tail: out = tanh(bias + sum_kw P[h][w+kw-4][kw][co])  (model/tsrn.py:159,213), NCHW output
  * ---------------------------------------------------------------------------------------------- */
 int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,

@@ -77,6 +77,15 @@ _SIGS = {
     "tpgsr_strip_resample_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_strip_resample_bwd": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
     "tpgsr_hsum": (ci, [vp, ci, ci, ci, ci, vp, ci, vp]),
+    "tpgsr_bicubic_gray_fwd": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_bicubic_gray_bwd": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_pool2d_fwd": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_pool2d_bwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_lstm_step_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "tpgsr_lstm_step_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "tpgsr_softmax_prior_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]),
+    "tpgsr_semantic_loss_finalize": (ci, [vp, ci, ll, cf, vp, vp]),
+    "tpgsr_softmax_prior_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, ci, vp]),
     "tpgsr_tail_shiftsum_tanh": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_tail_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]),
     "tpgsr_tail_bwd_blocks": (ci, [ci, ci, ci, ci, ci]),

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtpgsr_hip.so")
-SOURCES = ["conv_mfma.hip", "elementwise.hip", "gru.hip", "stn.hip", "loss_optim.hip", "error.cpp"]
+SOURCES = ["conv_mfma.hip", "elementwise.hip", "gru.hip", "stn.hip", "loss_optim.hip", "crnn.hip", "error.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

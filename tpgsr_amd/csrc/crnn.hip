@@ -1,0 +1,421 @@
+// Text-prior generator pieces (CRNN, model/crnn/crnn.py:29-90, and its callers in interfaces/):
+//   * parse_crnn_data (interfaces/base.py:806-829): bicubic resize of RGB to 32x100 + luminance, forward / backward
+//   * general max-pool with the producer's BN affine + ReLU folded in (crnn.py:56-66 pooling0..3)
+//   * BiLSTM time-step gate kernels (nn.LSTM, crnn.py:10); the recurrent GEMMs run on the MFMA conv kernel
+//   * softmax over the 37 classes + SemanticLoss (loss/semantic_loss.py:21-39) + the (N,37,1,26) prior with the
+//     deterministic prior dropout of interfaces/super_resolution.py:376-382
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// bicubic (A = -0.75, align_corners = False, no antialias) + luminance
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  float x = t + 1.f;
+  w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t;
+  w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t;
+  w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t;
+  w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+
+__device__ __forceinline__ void bicubic_src(int o, int in_size, int out_size, int& i0, float (&w)[4]) {
+  float scale = (float)in_size / (float)out_size;
+  float x = ((float)o + 0.5f) * scale - 0.5f;
+  float fx = floorf(x);
+  i0 = (int)fx;
+  cubic_coeffs(x - fx, w);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void bicubic_gray_fwd_kernel(const float* __restrict__ in, int N, int Ctot, int H, int W, int OH,
+                                                               int OW, float* __restrict__ out) {
+  long long total = (long long)N * OH * OW;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int ow = (int)(i % OW);
+  long long r = i / OW;
+  int oh = (int)(r % OH);
+  int n = (int)(r / OH);
+  int y0, x0;
+  float wy[4], wx[4];
+  bicubic_src(oh, H, OH, y0, wy);
+  bicubic_src(ow, W, OW, x0, wx);
+  const float lum[3] = {0.299f, 0.587f, 0.114f};
+  float g = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float* p = in + ((size_t)n * Ctot + c) * H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = clampi(y0 - 1 + a, 0, H - 1);
+      float rowv = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rowv += p[(size_t)yy * W + clampi(x0 - 1 + b, 0, W - 1)] * wx[b];
+      acc += rowv * wy[a];
+    }
+    g += lum[c] * acc;
+  }
+  out[i] = g;
+}
+
+extern "C" int tpgsr_bicubic_gray_fwd(const float* in_nchw, int N, int Ctot, int H, int W, int OH, int OW, float* out, void* stream) {
+  TPGSR_CHECK_ARG(in_nchw && out && N > 0 && Ctot >= 3 && H > 0 && W > 0 && OH > 0 && OW > 0, "tpgsr_bicubic_gray_fwd: bad arguments");
+  long long total = (long long)N * OH * OW;
+  hipLaunchKernelGGL(bicubic_gray_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in_nchw, N, Ctot, H, W, OH, OW, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_bicubic_gray_fwd");
+}
+
+// scatter form of the adjoint (din must be zero-filled for channels 0..2; other channels receive no gradient)
+__global__ __launch_bounds__(256) void bicubic_gray_bwd_kernel(const float* __restrict__ dout, int N, int Ctot, int H, int W, int OH,
+                                                               int OW, float* din) {
+  long long total = (long long)N * OH * OW;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int ow = (int)(i % OW);
+  long long r = i / OW;
+  int oh = (int)(r % OH);
+  int n = (int)(r / OH);
+  int y0, x0;
+  float wy[4], wx[4];
+  bicubic_src(oh, H, OH, y0, wy);
+  bicubic_src(ow, W, OW, x0, wx);
+  const float lum[3] = {0.299f, 0.587f, 0.114f};
+  float g = dout[i];
+  for (int c = 0; c < 3; ++c) {
+    float* p = din + ((size_t)n * Ctot + c) * H * W;
+    for (int a = 0; a < 4; ++a) {
+      int yy = clampi(y0 - 1 + a, 0, H - 1);
+      for (int b = 0; b < 4; ++b) atomicAdd(p + (size_t)yy * W + clampi(x0 - 1 + b, 0, W - 1), g * lum[c] * wy[a] * wx[b]);
+    }
+  }
+}
+
+extern "C" int tpgsr_bicubic_gray_bwd(const float* dout, int N, int Ctot, int H, int W, int OH, int OW, float* din_nchw, void* stream) {
+  TPGSR_CHECK_ARG(dout && din_nchw && N > 0 && Ctot >= 3, "tpgsr_bicubic_gray_bwd: bad arguments");
+  hipError_t e = hipMemsetAsync(din_nchw, 0, (size_t)N * Ctot * H * W * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) {
+    tpgsr_set_error("tpgsr_bicubic_gray_bwd: memset failed: %s", hipGetErrorString(e));
+    return TPGSR_ERR_LAUNCH;
+  }
+  long long total = (long long)N * OH * OW;
+  hipLaunchKernelGGL(bicubic_gray_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, N, Ctot, H, W, OH, OW, din_nchw);
+  TPGSR_LAUNCH_CHECK("tpgsr_bicubic_gray_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// general max-pool (kernel KHxKW, stride SHxSW, zero... -inf padding PHxPW) of act(scale*x+shift), NHWC
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                         int KH, int KW, int SH, int SW, int PH, int PW, int OH, int OW,
+                                                         float* __restrict__ out) {
+  long long total = (long long)N * OH * OW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int ow = (int)(p % OW);
+    p /= OW;
+    int oh = (int)(p % OH);
+    int n = (int)(p / OH);
+    float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    float best = -INFINITY;
+    for (int a = 0; a < KH; ++a) {
+      int h = oh * SH - PH + a;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int b = 0; b < KW; ++b) {
+        int w = ow * SW - PW + b;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v = apply_act(x[((size_t)(n * H + h) * W + w) * C + c] * sc + sh, act);
+        if (v > best || v != v) best = v;
+      }
+    }
+    out[i] = best;
+  }
+}
+
+extern "C" int tpgsr_pool2d_fwd(const float* x, int N, int H, int W, int C, const float* scale, const float* shift, int act, int KH,
+                                int KW, int SH, int SW, int PH, int PW, float* out, void* stream) {
+  TPGSR_CHECK_ARG(x && out && KH > 0 && KW > 0 && SH > 0 && SW > 0 && PH >= 0 && PW >= 0, "tpgsr_pool2d_fwd: bad arguments");
+  int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
+  TPGSR_CHECK_ARG(OH > 0 && OW > 0, "tpgsr_pool2d_fwd: empty output");
+  long long total = (long long)N * OH * OW * C;
+  int grid = (int)min((long long)8192, (total + 255) / 256);
+  hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, scale, shift, act, KH, KW, SH, SW,
+                     PH, PW, OH, OW, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_pool2d_fwd");
+}
+
+// gather form: dz[n][h][w][c] = act'(pre) * sum over windows that contain (h,w) and whose FIRST arg-max is (h,w) of dout
+__global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, int N, int H,
+                                                         int W, int C, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int act, int KH, int KW, int SH, int SW, int PH, int PW, int OH, int OW,
+                                                         float* __restrict__ dz) {
+  long long total = (long long)N * H * W * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int w = (int)(p % W);
+    p /= W;
+    int h = (int)(p % H);
+    int n = (int)(p / H);
+    float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    float pre = x[i] * sc + sh;
+    float mine = apply_act(pre, act);
+    float g = 0.f;
+    // windows (oh, ow) with oh*SH - PH <= h < oh*SH - PH + KH
+    int oh_lo = (h + PH - KH + SH) / SH;
+    if (h + PH - KH + 1 <= 0) oh_lo = 0;
+    int oh_hi = min(OH - 1, (h + PH) / SH);
+    int ow_lo = (w + PW - KW + SW) / SW;
+    if (w + PW - KW + 1 <= 0) ow_lo = 0;
+    int ow_hi = min(OW - 1, (w + PW) / SW);
+    for (int oh = max(oh_lo, 0); oh <= oh_hi; ++oh)
+      for (int ow = max(ow_lo, 0); ow <= ow_hi; ++ow) {
+        // is (h, w) the first arg-max of window (oh, ow)?
+        bool first = true;
+        for (int a = 0; a < KH && first; ++a) {
+          int hh = oh * SH - PH + a;
+          if ((unsigned)hh >= (unsigned)H) continue;
+          for (int b = 0; b < KW; ++b) {
+            int ww = ow * SW - PW + b;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            if (hh == h && ww == w) continue;
+            float v = apply_act(x[((size_t)(n * H + hh) * W + ww) * C + c] * sc + sh, act);
+            bool before = (hh < h) || (hh == h && ww < w);
+            if (v > mine || (before && v == mine)) {
+              first = false;
+              break;
+            }
+          }
+        }
+        if (first) g += dout[((size_t)(n * OH + oh) * OW + ow) * C + c];
+      }
+    dz[i] = g * act_grad(pre, act);
+  }
+}
+
+extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale, const float* shift,
+                                int act, int KH, int KW, int SH, int SW, int PH, int PW, float* dz, void* stream) {
+  TPGSR_CHECK_ARG(x && dout && dz && KH > 0 && KW > 0 && SH > 0 && SW > 0, "tpgsr_pool2d_bwd: bad arguments");
+  int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
+  long long total = (long long)N * H * W * C;
+  int grid = (int)min((long long)8192, (total + 255) / 256);
+  hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dout, N, H, W, C, scale, shift, act, KH, KW, SH,
+                     SW, PH, PW, OH, OW, dz);
+  TPGSR_LAUNCH_CHECK("tpgsr_pool2d_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BiLSTM time step (gate order i, f, g, o).  Layouts (batch-major, T = sequence length, Hh = hidden):
+//   G   [N][T][2][4*Hh]  input projections (+b_ih+b_hh) on entry, ACTIVATED gates on exit (saved for backward)
+//   gh  [2][N][4*Hh]     this step's recurrent projections W_hh h_{prev} (ignored at step 0)
+//   Cst [N][T][2][Hh]    cell states,   out [N][T][2*Hh]  hidden states (direction d in columns d*Hh..)
+// step s processes t = s for the forward direction and t = T-1-s for the reverse direction.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ G, const float* __restrict__ gh,
+                                                            const float* __restrict__ bhh, float* __restrict__ Cst,
+                                                            float* __restrict__ out, int N, int T, int Hh, int s) {
+  int total = N * 2 * Hh;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int j = i % Hh;
+  int d = (i / Hh) & 1;
+  int n = i / (2 * Hh);
+  int t = d == 0 ? s : T - 1 - s;
+  int tp = d == 0 ? t - 1 : t + 1;
+  float* g = G + (((size_t)n * T + t) * 2 + d) * 4 * Hh;
+  float pi = g[j], pf = g[Hh + j], pg = g[2 * Hh + j], po = g[3 * Hh + j];
+  if (bhh) {   // b_hh [2][4Hh] applies at every step (also at step 0 where h_prev = 0)
+    const float* b = bhh + (size_t)d * 4 * Hh;
+    pi += b[j];
+    pf += b[Hh + j];
+    pg += b[2 * Hh + j];
+    po += b[3 * Hh + j];
+  }
+  float cprev = 0.f;
+  if (s > 0) {
+    const float* r = gh + ((size_t)d * N + n) * 4 * Hh;
+    pi += r[j];
+    pf += r[Hh + j];
+    pg += r[2 * Hh + j];
+    po += r[3 * Hh + j];
+    cprev = Cst[(((size_t)n * T + tp) * 2 + d) * Hh + j];
+  }
+  float ig = sigmoid_f(pi), fg = sigmoid_f(pf), gg = tanh_f(pg), og = sigmoid_f(po);
+  float c = fg * cprev + ig * gg;
+  float h = og * tanh_f(c);
+  g[j] = ig;
+  g[Hh + j] = fg;
+  g[2 * Hh + j] = gg;
+  g[3 * Hh + j] = og;
+  Cst[(((size_t)n * T + t) * 2 + d) * Hh + j] = c;
+  out[((size_t)n * T + t) * 2 * Hh + d * Hh + j] = h;
+}
+
+extern "C" int tpgsr_lstm_step_fwd(float* G, const float* gh, const float* bhh, float* Cst, float* out, int N, int T, int Hh, int step,
+                                   void* stream) {
+  TPGSR_CHECK_ARG(G && Cst && out && (gh || step == 0) && N > 0 && T > 0 && Hh > 0 && step >= 0 && step < T, "tpgsr_lstm_step_fwd: bad arguments");
+  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(cdiv((long long)N * 2 * Hh, 256)), dim3(256), 0, (hipStream_t)stream, G, gh, bhh, Cst, out, N, T, Hh, step);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_step_fwd");
+}
+
+// backward step s' (reverse of the forward order): t = T-1-s' (forward dir), t = s' (reverse dir).
+//   dout [N][T][2*Hh] gradient w.r.t. the hidden states,  dhc [2][N][Hh] recurrent gradient W_hh^T dG[t_next] (ignored at s' = 0)
+//   dcc [N][2][Hh] running cell-state gradient (in/out),  G: activated gates in, dG (pre-activation gate gradients) out
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(float* __restrict__ G, const float* __restrict__ Cst,
+                                                            const float* __restrict__ dout, const float* __restrict__ dhc,
+                                                            float* __restrict__ dcc, int N, int T, int Hh, int s) {
+  int total = N * 2 * Hh;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int j = i % Hh;
+  int d = (i / Hh) & 1;
+  int n = i / (2 * Hh);
+  int t = d == 0 ? T - 1 - s : s;
+  int tp = d == 0 ? t - 1 : t + 1;   // time index of the previous state in this direction's forward order
+  bool has_prev = d == 0 ? t > 0 : t < T - 1;
+  float* g = G + (((size_t)n * T + t) * 2 + d) * 4 * Hh;
+  float ig = g[j], fg = g[Hh + j], gg = g[2 * Hh + j], og = g[3 * Hh + j];
+  float c = Cst[(((size_t)n * T + t) * 2 + d) * Hh + j];
+  float cprev = has_prev ? Cst[(((size_t)n * T + tp) * 2 + d) * Hh + j] : 0.f;
+  float dh = dout[((size_t)n * T + t) * 2 * Hh + d * Hh + j];
+  float dc = 0.f;
+  if (s > 0) {
+    dh += dhc[((size_t)d * N + n) * Hh + j];
+    dc = dcc[((size_t)n * 2 + d) * Hh + j];
+  }
+  float tc = tanh_f(c);
+  float dog = dh * tc * og * (1.f - og);
+  dc += dh * og * (1.f - tc * tc);
+  float dig = dc * gg * ig * (1.f - ig);
+  float dfg = dc * cprev * fg * (1.f - fg);
+  float dgg = dc * ig * (1.f - gg * gg);
+  dcc[((size_t)n * 2 + d) * Hh + j] = dc * fg;
+  g[j] = dig;
+  g[Hh + j] = dfg;
+  g[2 * Hh + j] = dgg;
+  g[3 * Hh + j] = dog;
+}
+
+extern "C" int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, float* dcc, int N, int T, int Hh,
+                                   int step, void* stream) {
+  TPGSR_CHECK_ARG(G && Cst && dout && dcc && (dhc || step == 0) && N > 0 && T > 0 && Hh > 0 && step >= 0 && step < T,
+                  "tpgsr_lstm_step_bwd: bad arguments");
+  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(cdiv((long long)N * 2 * Hh, 256)), dim3(256), 0, (hipStream_t)stream, G, Cst, dout, dhc, dcc, N,
+                     T, Hh, step);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_step_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// softmax over classes + SemanticLoss partials + (N, C, 1, T) prior with prior dropout
+//   logits [N][T][C] -> p [N][T][C];  prior[n][c][0][t] = (n < drop_n ? 0 : p[n][t][c])
+//   if q: partial[blk][0] = sum |q - p|, partial[blk][1] = sum q' (log q' - log p'),  p' = p + 1e-20, q' = q + 1e-20
+// one wavefront per (n, t) row
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_prior_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ q, int N, int T,
+                                                                int C, int drop_n, float* __restrict__ p, float* __restrict__ prior,
+                                                                float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = N * T;
+  float l1 = 0.f, kl = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* x = logits + (size_t)row * C;
+    float v = lane < C ? x[lane] : -INFINITY;
+    float m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float e = lane < C ? expf(v - m) : 0.f;
+    float ssum = wave_sum(e);
+    float pv = e / ssum;
+    if (lane < C) {
+      p[(size_t)row * C + lane] = pv;
+      int n = row / T, t = row - n * T;
+      if (prior) prior[((size_t)n * C + lane) * T + t] = n < drop_n ? 0.f : pv;
+      if (q) {
+        float qv = q[(size_t)row * C + lane];
+        l1 += fabsf(qv - pv);
+        float qp = qv + 1e-20f;
+        kl += qp * (logf(qp) - logf(pv + 1e-20f));
+      }
+    }
+  }
+  if (partial) {
+    l1 = wave_sum(l1);
+    kl = wave_sum(kl);
+    if (lane == 0) {
+      red[0][wave] = l1;
+      red[1][wave] = kl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      partial[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+  }
+}
+
+extern "C" int tpgsr_softmax_prior_fwd(const float* logits, const float* q, int N, int T, int C, int drop_n, float* p, float* prior_nchw,
+                                       float* partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(logits && p && N > 0 && T > 0 && C > 0 && C <= 64 && nblk > 0, "tpgsr_softmax_prior_fwd: bad arguments (C <= 64)");
+  TPGSR_CHECK_ARG(!q || partial, "tpgsr_softmax_prior_fwd: semantic-loss partials need a partial buffer");
+  hipLaunchKernelGGL(softmax_prior_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, logits, q, N, T, C, drop_n, p, prior_nchw,
+                     q ? partial : nullptr);
+  TPGSR_LAUNCH_CHECK("tpgsr_softmax_prior_fwd");
+}
+
+// loss = w * (sum|q-p| + sum kl) / (N*T*C)
+__global__ void semantic_loss_finalize_kernel(const float* __restrict__ partial, int nblk, long long count, float w, float* loss) {
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) {
+    a += (double)partial[i * 2];
+    b += (double)partial[i * 2 + 1];
+  }
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  if (threadIdx.x == 0) loss[0] = (float)((double)w * (a + b) / (double)count);
+}
+
+extern "C" int tpgsr_semantic_loss_finalize(const float* partial, int nblk, long long count, float w, float* loss, void* stream) {
+  TPGSR_CHECK_ARG(partial && loss && nblk > 0 && count > 0, "tpgsr_semantic_loss_finalize: bad arguments");
+  hipLaunchKernelGGL(semantic_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nblk, count, w, loss);
+  TPGSR_LAUNCH_CHECK("tpgsr_semantic_loss_finalize");
+}
+
+// dlogits = softmax backward of dp, dp = [n >= drop_n] * dprior[n][c][0][t] + wsem/(count) * ( -sign(q-p) - q'/(p') )
+__global__ __launch_bounds__(256) void softmax_prior_bwd_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                                const float* __restrict__ dprior, const float* __restrict__ dp_in,
+                                                                int N, int T, int C, int drop_n, float wsem_over_count,
+                                                                float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = N * T;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    int n = row / T, t = row - n * T;
+    float pv = 0.f, dp = 0.f;
+    if (lane < C) {
+      pv = p[(size_t)row * C + lane];
+      if (dprior && n >= drop_n) dp += dprior[((size_t)n * C + lane) * T + t];
+      if (dp_in) dp += dp_in[(size_t)row * C + lane];
+      if (q) {
+        float qv = q[(size_t)row * C + lane];
+        float diff = qv - pv;
+        float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        dp += wsem_over_count * (-sg - (qv + 1e-20f) / (pv + 1e-20f));
+      }
+    }
+    float dot = wave_sum(dp * pv);
+    if (lane < C) dlogits[(size_t)row * C + lane] = pv * (dp - dot);
+  }
+}
+
+extern "C" int tpgsr_softmax_prior_bwd(const float* p, const float* q, const float* dprior_nchw, const float* dp_in, int N, int T, int C,
+                                       int drop_n, float wsem, float* dlogits, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(p && dlogits && N > 0 && T > 0 && C > 0 && C <= 64 && nblk > 0, "tpgsr_softmax_prior_bwd: bad arguments");
+  float wc = q ? wsem / (float)((long long)N * T * C) : 0.f;
+  hipLaunchKernelGGL(softmax_prior_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, q, dprior_nchw, dp_in, N, T, C, drop_n, wc,
+                     dlogits);
+  TPGSR_LAUNCH_CHECK("tpgsr_softmax_prior_bwd");
+}

@@ -304,19 +304,17 @@ class TConvStrip:
 # =================================================================================================================
 # TSRN engine
 # =================================================================================================================
-class TSRNEngine:
-    """Owns the arenas, packed operands, workspaces and the recorded plans of one TSRN module."""
+class _EngineBase:
+    """Arenas, packed-operand table, stream-ordered scratch and plan cache shared by the network engines."""
 
-    STN_POOLS = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (1, 1)]
-
-    def __init__(self, module: torch.nn.Module, grid_align_corners: bool = False):
+    def __init__(self, module: torch.nn.Module):
         self.module = module
         self.arena = ParamArena(module)
         self.device = None
-        self.grid_align_corners = grid_align_corners
         self._plans: Dict[tuple, dict] = {}
         self._scratch: Dict[str, torch.Tensor] = {}
         self._pack: List[tuple] = []
+        self._pending_batches = 0
 
     # ---- scratch buffers live only between consecutive launches (stream-ordered reuse) ----------------------
     def scratch(self, name, numel):
@@ -351,7 +349,6 @@ class TSRNEngine:
     def pack_all(self):
         K.pack_program(self._pack_dev, self._pack_n, self._pack_blocks)
 
-    # ------------------------------------------------------------------------------------------------------------
     def bind(self, device):
         rebuilt = self.arena.ensure(device)
         if not rebuilt and self.device == device:
@@ -372,6 +369,31 @@ class TSRNEngine:
                 raise RuntimeError(f"buffer {name} is on {b.device}, parameters on {device}: call module.to(device) first")
         self._build_layers()
         self._finish_pack_table()
+
+    def flush_counters(self):
+        if self._pending_batches and self.device is not None:
+            for n, b in self.B.items():
+                if n.endswith("num_batches_tracked"):
+                    b += self._pending_batches
+        self._pending_batches = 0
+
+    def _two_pass(self, key, record):
+        """pass 1 sizes the stream-ordered scratch buffers, pass 2 records against their final addresses"""
+        if key not in self._plans:
+            ws = _Ws(self.device)
+            record(ws, False)
+            self._plans[key] = record(ws, True)
+        return self._plans[key]
+
+
+class TSRNEngine(_EngineBase):
+    """Owns the arenas, packed operands, workspaces and the recorded plans of one TSRN / TSRN_TL module."""
+
+    STN_POOLS = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (1, 1)]
+
+    def __init__(self, module: torch.nn.Module, grid_align_corners: bool = False):
+        super().__init__(module)
+        self.grid_align_corners = grid_align_corners
 
     def _build_layers(self):
         m = self.module
@@ -423,13 +445,7 @@ class TSRNEngine:
 
     # ------------------------------------------------------------------------------------------------------------
     def plans(self, N, H, W, training):
-        key = (N, H, W, bool(training))
-        if key not in self._plans:
-            # pass 1 sizes the stream-ordered scratch buffers, pass 2 records against their final addresses
-            ws = _Ws(self.device)
-            self._record(N, H, W, training, ws, final=False)
-            self._plans[key] = self._record(N, H, W, training, ws, final=True)
-        return self._plans[key]
+        return self._two_pass((N, H, W, bool(training)), lambda ws, final: self._record(N, H, W, training, ws, final))
 
     def _record(self, N, H, W, training, ws, final):
         fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
@@ -701,14 +717,6 @@ class TSRNEngine:
             self._pending_batches += 1   # num_batches_tracked is bookkeeping only (momentum is fixed): flushed lazily
         return sr
 
-    _pending_batches = 0
-
-    def flush_counters(self):
-        if self._pending_batches and self.device is not None:
-            for n, b in self.B.items():
-                if n.endswith("num_batches_tracked"):
-                    b += self._pending_batches
-        self._pending_batches = 0
 
     def backward(self, x_shape, sr: torch.Tensor, dsr: torch.Tensor):
         N, _, H, W = x_shape

@@ -1,0 +1,254 @@
+"""Static execution plans for the CRNN text-prior generator (reference: model/crnn/crnn.py:29-90): seven convs
+(three with train-mode BatchNorm) + four max-pools, then two BidirectionalLSTM(256) + Linear stages.
+
+Same machinery as the TSRN engine: NHWC workspaces, BN/ReLU folded into consumer loaders or into the pooling kernel,
+all GEMM-shaped work (convs, LSTM input projections, the per-step recurrent projections, embeddings, every weight
+gradient) on the fp32-MFMA implicit-GEMM kernel, gate math in small fused kernels, parameter gradients written into
+the flat arena.  The sequence tensor is kept batch-major [N][T][C] (== NHWC with H = 1, W = T), so a time step of the
+recurrence is a 1x1 "conv" that reads pixel t of every image (negative pad_w selects the column)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+from .engine import BNLayer, ConvLayer, F32, _EngineBase
+from .kernels import ConvGeom, Plan, recording
+
+
+class LstmLayer:
+    """BidirectionalLSTM (crnn.py:5-26): nn.LSTM(nIn, Hh, bidirectional) + Linear(2*Hh, nOut)."""
+
+    def __init__(self, eng, prefix: str):
+        self.eng, self.prefix = eng, prefix
+        P, dev = eng.P, eng.device
+        r = prefix + ".rnn."
+        self.r = r
+        self.Hh = Hh = P[r + "weight_hh_l0"].shape[1]
+        self.Cin = Cin = P[r + "weight_ih_l0"].shape[1]
+        G4 = 4 * Hh
+        self.wih_f = torch.empty(Cin, 2 * G4, dtype=F32, device=dev)      # [K=Cin][2*4Hh]
+        self.wih_d = torch.empty(2 * G4, Cin, dtype=F32, device=dev)      # dgrad operand
+        self.bih = torch.empty(2 * G4, dtype=F32, device=dev)
+        self.bhh = torch.empty(2, G4, dtype=F32, device=dev)
+        self.whh_f = torch.empty(2, Hh, G4, dtype=F32, device=dev)         # per direction [K=Hh][4Hh] = W_hh^T
+        for d, suf in enumerate(("", "_reverse")):
+            eng.add_pack(P[r + "weight_ih_l0" + suf], self.wih_f, self.wih_d[d * G4:(d + 1) * G4], Cout=G4, Cin=Cin, kind=0,
+                         f_ld=2 * G4, f_coff=d * G4)
+            eng.add_pack(P[r + "bias_ih_l0" + suf], self.bih[d * G4:(d + 1) * G4], None, kind=2)
+            eng.add_pack(P[r + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
+            eng.add_pack(P[r + "weight_hh_l0" + suf], self.whh_f[d], None, Cout=G4, Cin=Hh, kind=0, f_ld=G4)
+        self.emb = ConvLayer(eng, prefix + ".embedding.weight", prefix + ".embedding.bias")
+
+    def fwd(self, N, T, x, G, gh, Cst, out, e, **loader):
+        """x [N][T][Cin] -> G (gates) -> out [N][T][2Hh] -> e = Linear(out) [N][T][nOut]"""
+        Hh, G4, P = self.Hh, 4 * self.Hh, self.eng.P
+        K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, self.Cin, 2 * G4), x, self.wih_f, G, bias=self.bih, **loader))
+        for s in range(T):
+            if s > 0:
+                for d in range(2):
+                    tp = s - 1 if d == 0 else T - s          # time index of the previous state of direction d
+                    g = ConvGeom(N, 1, T, Hh, G4, 1, 1, 0, -tp, 1, 1)
+                    K.conv_fwd(K.make_conv_args(g, out, self.whh_f[d], gh[d], in_ld=2 * Hh, in_coff=d * Hh))
+            K.lstm_step_fwd(G, gh if s > 0 else None, self.bhh, Cst, out, N, T, Hh, s)
+        self.emb.fwd(N, 1, T, out, e)
+
+    def bwd(self, N, T, x, G, Cst, out, de, dout, dhc, dcc, dx, **loader):
+        """de = dL/d e  ->  all parameter gradients, dx = dL/d loader(x) (if dx is not None)"""
+        eng, P, Gd, r = self.eng, self.eng.P, self.eng.G, self.r
+        Hh, G4 = self.Hh, 4 * self.Hh
+        self.emb.wgrad(N, 1, T, out, de)
+        self.emb.dgrad(N, 1, T, de, dout)
+        for s in range(T):
+            if s > 0:
+                for d in range(2):
+                    tn = T - s if d == 0 else s - 1           # time index processed by the previous backward step
+                    g = ConvGeom(N, 1, T, G4, Hh, 1, 1, 0, -tn, 1, 1)
+                    # dh_prev = dG[tn] @ W_hh  (operand [K=4Hh][Hh] is the PyTorch weight itself)
+                    K.conv_fwd(K.make_conv_args(g, G, P[r + "weight_hh_l0" + ("" if d == 0 else "_reverse")], dhc[d],
+                                                in_ld=2 * G4, in_coff=d * G4))
+            K.lstm_step_bwd(G, Cst, dout, dhc if s > 0 else None, dcc, N, T, Hh, s)
+        for d, suf in enumerate(("", "_reverse")):
+            sgn = 1 if d == 0 else -1
+            # hidden side: dW_hh[d] = dG[:, d]^T h_prev, db_hh[d] = colsum(dG[:, d])
+            gh_ = ConvGeom(N, 1, T, Hh, G4, 1, 1, 0, sgn, 1, T)
+            Z = K.wgrad_splits(gh_.M, gh_.K, G4)
+            part, dbp = eng.scratch("wgrad_part", Z * Hh * G4), eng.scratch("wgrad_dbpart", Z * G4)
+            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gh_, out, in_ld=2 * Hh, in_coff=d * Hh), G, part, dbp,
+                                           dy_ld=2 * G4, dy_coff=d * G4))
+            K.wgrad_reduce(part, dbp, Z, gh_, Gd[r + "weight_hh_l0" + suf], Gd[r + "bias_hh_l0" + suf], accumulate=True)
+            # input side
+            gi_ = ConvGeom(N, 1, T, self.Cin, G4)
+            Z = K.wgrad_splits(gi_.M, gi_.K, G4)
+            part, dbp = eng.scratch("wgrad_part", Z * self.Cin * G4), eng.scratch("wgrad_dbpart", Z * G4)
+            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gi_, x, **loader), G, part, dbp, dy_ld=2 * G4, dy_coff=d * G4))
+            K.wgrad_reduce(part, dbp, Z, gi_, Gd[r + "weight_ih_l0" + suf], Gd[r + "bias_ih_l0" + suf], accumulate=True)
+        if dx is not None:
+            K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, 2 * G4, self.Cin), G, self.wih_d, dx))
+
+
+class CRNNEngine(_EngineBase):
+    IMG_HW = (32, 100)
+    # (kernel, stride, padding) of pooling0..3 (crnn.py:56-66); None = no pooling after that conv
+    POOLS = {0: ((2, 2), (2, 2), (0, 0)), 1: ((2, 2), (2, 2), (0, 0)), 3: ((2, 2), (2, 1), (0, 1)), 5: ((2, 2), (2, 1), (0, 1))}
+    BN_AT = (2, 4, 6)
+
+    def _build_layers(self):
+        self.convs, self.bns = [], {}
+        for i in range(7):
+            k, pad = (3, 1) if i < 6 else (2, 0)
+            self.convs.append(ConvLayer(self, f"cnn.conv{i}.weight", f"cnn.conv{i}.bias", k, k, pad, pad, need_dgrad=True))
+            if i in self.BN_AT:
+                self.bns[i] = BNLayer(self, f"cnn.batchnorm{i}")
+        self.lstm = [LstmLayer(self, "rnn.0"), LstmLayer(self, "rnn.1")]
+        self.nclass = self.P["rnn.1.embedding.weight"].shape[0]
+
+    def _dims(self):
+        """(H, W) seen by conv i and after its optional pool"""
+        h, w = self.IMG_HW
+        dims = []
+        for i in range(7):
+            k, pad = (3, 1) if i < 6 else (2, 0)
+            oh, ow = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+            ph, pw = oh, ow
+            if i in self.POOLS:
+                (kh, kw), (sh, sw), (pdh, pdw) = self.POOLS[i]
+                ph, pw = (oh + 2 * pdh - kh) // sh + 1, (ow + 2 * pdw - kw) // sw + 1
+            dims.append(((h, w), (oh, ow), (ph, pw)))
+            h, w = ph, pw
+        assert h == 1, "the height of conv must be 1"   # crnn.py:83
+        return dims
+
+    def plans(self, N, training):
+        return self._two_pass((N, bool(training)), lambda ws, final: self._record(N, training, ws, final))
+
+    def _record(self, N, training, ws, final):
+        fwd, bwd = Plan("crnn_fwd"), Plan("crnn_bwd")
+        fwd.final = bwd.final = final
+        with recording(fwd):
+            self._record_fwd(N, training, ws)
+        if training:
+            with recording(bwd):
+                self._record_bwd(N, ws)
+        return dict(fwd=fwd, bwd=bwd, ws=ws)
+
+    def _record_fwd(self, N, training, ws):
+        self.pack_all()
+        dims = self._dims()
+        gray = ws("gray", N * self.IMG_HW[0] * self.IMG_HW[1], 1)   # launch structs hold static pointers: stage the input
+        K.copy(K.DynPtr("gray"), gray, gray.numel())
+        cur, loader = gray, {}
+        for i, conv in enumerate(self.convs):
+            (h, w), (oh, ow), (ph, pw) = dims[i]
+            s = ws(f"s{i}", N * oh * ow, conv.Cout)
+            bn = self.bns.get(i)
+            part = bn.partial(N * oh * ow)[0] if (bn and training) else None
+            conv.fwd(N, h, w, cur, s, bn_partial=part, **loader)
+            if bn:
+                bn.finalize(N * oh * ow, conv.b, training)
+            if i in self.POOLS:
+                k, st, pd = self.POOLS[i]
+                a = ws(f"a{i}", N * ph * pw, conv.Cout)
+                K.pool2d_fwd(s, N, oh, ow, conv.Cout, bn.scale if bn else None, bn.shift if bn else None, "relu", k, st, pd, a)
+                cur, loader = a, {}
+            else:   # BN(+ReLU) rides on the consumer's loader (conv2, conv4, conv6 are always followed by BN)
+                cur, loader = s, (dict(in_act="relu", **bn.loader) if bn else dict(in_act="relu"))
+        T = dims[6][1][1]
+        self.T = T
+        x = cur
+        for j, L in enumerate(self.lstm):
+            G4 = 4 * L.Hh
+            G = ws(f"l{j}_G", N * T, 2 * G4)
+            gh = ws(f"l{j}_gh", 2, N, G4)
+            Cst = ws(f"l{j}_C", N * T, 2 * L.Hh)
+            out = ws(f"l{j}_out", N * T, 2 * L.Hh)
+            e = ws(f"l{j}_e", N * T, L.emb.Cout)
+            L.fwd(N, T, x, G, gh, Cst, out, e, **(loader if j == 0 else {}))
+            x = e
+        K.copy(x, K.DynPtr("logits"), N * T * self.nclass)
+
+    def _record_bwd(self, N, ws):
+        t = ws.t
+        dims = self._dims()
+        T = self.T
+        de = ws("dlogits", N * T, self.nclass)
+        K.copy(K.DynPtr("dlogits"), de, N * T * self.nclass)
+        cnn_loader = dict(in_act="relu", **self.bns[6].loader)
+        for j in (1, 0):
+            L = self.lstm[j]
+            G4 = 4 * L.Hh
+            dout = ws(f"l{j}_dout", N * T, 2 * L.Hh)
+            dhc = ws(f"l{j}_dhc", 2, N, L.Hh)
+            dcc = ws(f"l{j}_dcc", N, 2 * L.Hh)
+            x = t[f"l{j - 1}_e"] if j == 1 else t["s6"]
+            dx = ws(f"l{j}_dx", N * T, L.Cin)
+            L.bwd(N, T, x, t[f"l{j}_G"], t[f"l{j}_C"], t[f"l{j}_out"], de, dout, dhc, dcc, dx, **({} if j == 1 else cnn_loader))
+            de = dx
+        da = de                                   # d relu(bn6(s6))
+        for i in range(6, -1, -1):
+            conv, bn = self.convs[i], self.bns.get(i)
+            (h, w), (oh, ow), (ph, pw) = dims[i]
+            M = N * oh * ow
+            s = t[f"s{i}"]
+            ds = ws(f"ds{i}", M, conv.Cout)
+            if i in self.POOLS:
+                k, st, pd = self.POOLS[i]
+                K.pool2d_bwd(s, da, N, oh, ow, conv.Cout, bn.scale if bn else None, bn.shift if bn else None, "relu", k, st, pd, ds)
+                if bn:   # (not the case in CRNN: pooled convs have no BN) dz -> BN backward
+                    dz = ds
+                    ds = ws(f"ds{i}b", M, conv.Cout)
+                    bn.backward(dz, None, s, M, "none", ds)
+            elif bn:
+                bn.backward(da, None, s, M, "relu", ds)
+            else:
+                K.act_bwd(s, da, M * conv.Cout, "relu", ds)
+            # the conv's own input and the loader it was read through
+            if i == 0:
+                xin, ld = t["gray"], {}
+            else:
+                pi, pbn = i - 1, self.bns.get(i - 1)
+                if pi in self.POOLS:
+                    xin, ld = t[f"a{pi}"], {}
+                else:
+                    xin, ld = t[f"s{pi}"], (dict(in_act="relu", **pbn.loader) if pbn else dict(in_act="relu"))
+            conv.wgrad(N, h, w, xin, ds, loader=ld)
+            if i > 0:
+                da = ws(f"da{i - 1}", N * h * w, conv.Cin)
+                conv.dgrad(N, h, w, ds, da)
+            else:
+                dg = ws("dgray", N * h * w, 1)
+                conv.dgrad(N, h, w, ds, dg)
+                K.copy(dg, K.DynPtr("dgray"), N * h * w)
+
+    # ---- execution ----------------------------------------------------------------------------------------------
+    def forward(self, gray: torch.Tensor, training: bool) -> torch.Tensor:
+        """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major; the module returns the (T, N, C) view)"""
+        if not gray.is_cuda:
+            raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
+        if gray.dim() != 4 or gray.shape[1] != 1 or tuple(gray.shape[2:]) != self.IMG_HW:
+            raise ValueError(f"CRNN expects (N, 1, {self.IMG_HW[0]}, {self.IMG_HW[1]}) input, got {tuple(gray.shape)}")
+        self.bind(gray.device)
+        N = gray.shape[0]
+        pl = self.plans(N, training)
+        gray = gray.contiguous().float()            # (N,1,H,W) NCHW with C = 1 is already NHWC
+        logits = torch.empty(N, self.T, self.nclass, dtype=F32, device=gray.device)
+        fwd = pl["fwd"]
+        fwd.set_ptr("gray", gray.data_ptr())
+        fwd.set_ptr("logits", logits.data_ptr())
+        fwd.run()
+        if training:
+            self._pending_batches += 1
+        self._last_gray = gray
+        return logits
+
+    def backward(self, N, gray: torch.Tensor, dlogits: torch.Tensor, need_dgray: bool = False) -> Optional[torch.Tensor]:
+        pl = self.plans(N, True)
+        self.arena.attach_grads()
+        bwd = pl["bwd"]
+        dlogits = dlogits.contiguous().float()
+        dgray = torch.empty_like(gray)
+        bwd.set_ptr("dlogits", dlogits.data_ptr())
+        bwd.set_ptr("dgray", dgray.data_ptr())
+        bwd.run()
+        return dgray if need_dgray else None

@@ -315,6 +315,44 @@ def hsum(d, N, H, W, C_, dstrip, accumulate=True):
     _launch("tpgsr_hsum", _p(d), N, H, W, C_, _p(dstrip), int(accumulate))
 
 
+# ---- CRNN pieces ----------------------------------------------------------------------------------------------
+def bicubic_gray_fwd(x_nchw, N, Ctot, H, W, OH, OW, out):
+    _launch("tpgsr_bicubic_gray_fwd", _p(x_nchw), N, Ctot, H, W, OH, OW, _p(out))
+
+
+def bicubic_gray_bwd(dout, N, Ctot, H, W, OH, OW, din_nchw):
+    _launch("tpgsr_bicubic_gray_bwd", _p(dout), N, Ctot, H, W, OH, OW, _p(din_nchw))
+
+
+def pool2d_fwd(x, N, H, W, C_, scale, shift, act, k, s, pd, out):
+    _launch("tpgsr_pool2d_fwd", _p(x), N, H, W, C_, _p(scale), _p(shift), act_code(act), k[0], k[1], s[0], s[1], pd[0], pd[1], _p(out))
+
+
+def pool2d_bwd(x, dout, N, H, W, C_, scale, shift, act, k, s, pd, dz):
+    _launch("tpgsr_pool2d_bwd", _p(x), _p(dout), N, H, W, C_, _p(scale), _p(shift), act_code(act), k[0], k[1], s[0], s[1], pd[0], pd[1],
+            _p(dz))
+
+
+def lstm_step_fwd(G, gh, bhh, Cst, out, N, T, Hh, step):
+    _launch("tpgsr_lstm_step_fwd", _p(G), _p(gh), _p(bhh), _p(Cst), _p(out), N, T, Hh, step)
+
+
+def lstm_step_bwd(G, Cst, dout, dhc, dcc, N, T, Hh, step):
+    _launch("tpgsr_lstm_step_bwd", _p(G), _p(Cst), _p(dout), _p(dhc), _p(dcc), N, T, Hh, step)
+
+
+def softmax_prior_fwd(logits, q, N, T, C_, drop_n, p, prior, partial, nblk):
+    _launch("tpgsr_softmax_prior_fwd", _p(logits), _p(q), N, T, C_, drop_n, _p(p), _p(prior), _p(partial), nblk)
+
+
+def semantic_loss_finalize(partial, nblk, count, w, loss):
+    _launch("tpgsr_semantic_loss_finalize", _p(partial), nblk, count, w, _p(loss))
+
+
+def softmax_prior_bwd(p, q, dprior, dp_in, N, T, C_, drop_n, wsem, dlogits, nblk):
+    _launch("tpgsr_softmax_prior_bwd", _p(p), _p(q), _p(dprior), _p(dp_in), N, T, C_, drop_n, wsem, _p(dlogits), nblk)
+
+
 # ---- tail / loss / optimiser ----------------------------------------------------------------------------------
 def tail_shiftsum_tanh(P, bias, N, H, W, Co, KS, out_nchw):
     _launch("tpgsr_tail_shiftsum_tanh", _p(P), _p(bias), N, H, W, Co, KS, _p(out_nchw))
