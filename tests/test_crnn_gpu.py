@@ -161,3 +161,94 @@ def test_crnn_gradients_vs_oracle():
     rel = (gd.grad.cpu() - gr.grad).norm().item() / gr.grad.norm().item()
     print("dgray rel err", rel)
     assert rel < 3e-3
+
+
+def _c3_models(seeds=(301, 302, 303), stn=True, n_sr=1, n_stu=1):
+    from tpgsr_amd.model import tsrn
+    from tpgsr_amd.model.crnn import crnn
+    srs, sds = [], []
+    for k in range(n_sr):
+        sd = O.recipe_state_dict(O.tsrn_spec(STN=stn, mask=True, text_prior=True), seeds[0] + 10 * k, tps_hw=(16, 64))
+        m = tsrn.TSRN_TL(STN=stn, mask=True); m.load_state_dict(sd); srs.append(m.to(DEV).train()); sds.append(sd)
+    sd_t = O.recipe_state_dict(O.crnn_spec(), seeds[1])
+    teacher = crnn.CRNN(32, 1, 37, 256); teacher.load_state_dict(sd_t); teacher = teacher.to(DEV).eval()
+    stus, sd_s = [], []
+    for k in range(n_stu):
+        sd = O.recipe_state_dict(O.crnn_spec(), seeds[2] + 10 * k)
+        s = crnn.CRNN(32, 1, 37, 256); s.load_state_dict(sd); stus.append(s.to(DEV).train()); sd_s.append(sd)
+    return srs, stus, teacher, sds, sd_s, sd_t
+
+
+def test_train_c3_step_vs_golden(golden_dir):
+    """C3: TSRN_TL + teacher CRNN + one student, stu_iter 1 -- loss / grad-norm / arg-max prior vs the reference's numbers"""
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    t = np.load(os.path.join(golden_dir, "train_c3.npz"))
+    srs, stus, teacher, *_ = _c3_models()
+    ts = TPGSRTrainStep(srs, stus, teacher, stu_iter=1)
+    lr, hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+    loss = ts.step(lr, hr)
+    gn = ts.opt.grad_norm(srs[0])
+    print("C3 step0", loss.item(), t["loss"][0], gn.item(), t["gnorm"][0])
+    assert abs(loss.item() - t["loss"][0]) < 3e-4 * t["loss"][0]
+    assert abs(gn.item() - t["gnorm"][0]) < 3e-3 * t["gnorm"][0]
+    assert (ts.last_p.cpu().permute(1, 0, 2).argmax(-1).numpy() == t["prior_argmax_step0"]).all()
+    l1 = ts.step(lr, hr).item()
+    print("C3 step1", l1, t["loss"][1])
+    assert abs(l1 - t["loss"][1]) < 2e-2 * t["loss"][1]
+
+
+def test_cascade_two_stages_vs_oracle():
+    """stu_iter 2, sr_share, two students, no STN: every gradient (SR net accumulated over both stages, both students,
+    incl. the path through parse_crnn_data of stage 2) against oracle autograd, via one fused step's Adam-free grads.
+
+    Conditioning, measured with the oracle itself in fp32 vs fp64 on exactly this case (tools/dbg/dbg_cascade.py and the
+    fp64 probe quoted in DESIGN.md): the students' parameter gradients are ill-conditioned in fp32 -- the oracle's own
+    fp32 result is 1.07e-2 / 1.22e-2 (relative, student 0 / 1) away from its fp64 result, the stage-1 prior gradient
+    1.1e-2 -- so student tolerances are percent-level by nature (the HIP path lands at 1.09e-2 / 1.25e-2, i.e. at the
+    oracle's own noise level); the SR-net gradients and the last-stage prior gradient (2.6e-5) are tight."""
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    srs, stus, teacher, sds, sd_s, sd_t = _c3_models(stn=False, n_sr=1, n_stu=2)
+    lr, hr = O.synthetic_batch(4, 77)
+    ps = O.as_params(sds[0]); pt = O.as_params(sd_t, False); pu = [O.as_params(x) for x in sd_s]
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
+    ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=2, sr_share=True, tpg_share=False, stn=False)
+    ts = TPGSRTrainStep(srs, stus, teacher, stu_iter=2, sr_share=True, tpg_share=False)
+    for m in srs + stus:
+        m._engine().bind(torch.device(DEV, 0))
+    teacher._engine().bind(torch.device(DEV, 0))
+    loss = ts._phase_a(lr.to(DEV), hr.to(DEV))            # forward + backward only (no optimiser): raw gradients
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref["loss"].item()) < 3e-4 * ref["loss"].item()
+    # oracle grads were clipped in place for the SR group: compare directions via the un-clipped norm ratio
+    flat_ref = ref["grads"]
+    n_sr = len(O.trainable_keys(ps))
+    names_sr = O.trainable_keys(ps)
+    coef = min(1.0, 0.25 / (float(ref["grad_norms"][0]) + 1e-6))
+    P = dict(srs[0].named_parameters())
+    gmax = max(g.norm().item() for g in flat_ref[:n_sr]) / coef
+    bad, num, den = [], 0.0, 0.0
+    for k, gref in zip(names_sr, flat_ref[:n_sr]):
+        d = (P[k].grad.cpu() * coef - gref)
+        num += d.double().pow(2).sum().item(); den += gref.double().pow(2).sum().item()
+        rel = d.norm().item() / max(gref.norm().item(), 1e-3 * gmax * coef)
+        if rel > 2e-2:
+            bad.append((k, rel))
+    print("cascade SR grads: global rel err", (num / den) ** 0.5, "worst", max([0] + [b[1] for b in bad]))
+    # two stage gradients of similar size partly cancel in the shared SR net, which amplifies relative fp32 noise
+    assert (num / den) ** 0.5 < 5e-3 and not bad, bad[:8]
+    ofs = n_sr
+    for j, q in enumerate(pu):
+        Ps = dict(stus[j].named_parameters())
+        keys = O.trainable_keys(q)
+        gm = max(g.norm().item() for g in flat_ref[ofs:ofs + len(keys)])
+        num = den = 0.0
+        worst = (None, 0.0)
+        for k, gref in zip(keys, flat_ref[ofs:ofs + len(keys)]):
+            d = Ps[k].grad.cpu() - gref
+            num += d.double().pow(2).sum().item(); den += gref.double().pow(2).sum().item()
+            rel = d.norm().item() / max(gref.norm().item(), 1e-3 * gm)
+            if rel > worst[1]:
+                worst = (k, rel)
+        print(f"cascade student {j}: global rel err {(num / den) ** 0.5:.3e}, worst per-tensor {worst}")
+        assert (num / den) ** 0.5 < 3e-2, (j, (num / den) ** 0.5, worst)
+        ofs += len(keys)

@@ -98,7 +98,7 @@ class _Ws:
         return t
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in self.t.values())
+        return sum(t.numel() * t.element_size() for t in self.t.values() if isinstance(t, torch.Tensor))
 
 
 # =================================================================================================================
@@ -159,13 +159,20 @@ class BNLayer:
         self.gamma, self.beta = eng.P[prefix + ".weight"], eng.P[prefix + ".bias"]
         self.rm, self.rv = eng.B[prefix + ".running_mean"], eng.B[prefix + ".running_var"]
         self.C = C_ = self.gamma.numel()
-        dev = eng.device
-        # pad_to > C: identity (1, 0) tail so a concatenated loader can index scale/shift past this BN's channels
-        self.scale = torch.ones(max(C_, pad_to), dtype=F32, device=dev)
-        self.shift = torch.zeros(max(C_, pad_to), dtype=F32, device=dev)
-        self.save_mean = torch.empty(C_, dtype=F32, device=dev)
-        self.save_rstd = torch.empty(C_, dtype=F32, device=dev)
-        self.coef = torch.empty(3, C_, dtype=F32, device=dev)
+        self.pad_to = max(C_, pad_to)
+        eng._bn_layers.append(self)
+        self.scale = self.shift = self.save_mean = self.save_rstd = self.coef = None   # bound per plan by use(ws)
+
+    def use(self, ws):
+        """Batch statistics / folded scale+shift belong to ONE forward: they live in the plan's workspace (a network
+        shared between cascade stages runs several forwards before the first backward)."""
+        if ("bn", self.prefix) not in ws.t:
+            dev, C_ = self.eng.device, self.C
+            # pad_to > C: identity (1, 0) tail so a concatenated loader can index scale/shift past this BN's channels
+            ws.t[("bn", self.prefix)] = (torch.ones(self.pad_to, dtype=F32, device=dev), torch.zeros(self.pad_to, dtype=F32, device=dev),
+                                         torch.empty(C_, dtype=F32, device=dev), torch.empty(C_, dtype=F32, device=dev),
+                                         torch.empty(3, C_, dtype=F32, device=dev))
+        self.scale, self.shift, self.save_mean, self.save_rstd, self.coef = ws.t[("bn", self.prefix)]
 
     def partial(self, M):
         """scratch for the producing conv's epilogue statistics"""
@@ -314,6 +321,7 @@ class _EngineBase:
         self._plans: Dict[tuple, dict] = {}
         self._scratch: Dict[str, torch.Tensor] = {}
         self._pack: List[tuple] = []
+        self._bn_layers: List["BNLayer"] = []
         self._pending_batches = 0
 
     # ---- scratch buffers live only between consecutive launches (stream-ordered reuse) ----------------------
@@ -357,6 +365,7 @@ class _EngineBase:
         self._plans.clear()
         self._scratch.clear()
         self._pack = []
+        self._bn_layers = []
         m = self.module
         self.P = dict(m.named_parameters())
         self.B = dict(m.named_buffers())
@@ -444,12 +453,16 @@ class TSRNEngine(_EngineBase):
             self.NC = self.B["tps.target_control_points"].shape[0]
 
     # ------------------------------------------------------------------------------------------------------------
-    def plans(self, N, H, W, training):
-        return self._two_pass((N, H, W, bool(training)), lambda ws, final: self._record(N, H, W, training, ws, final))
+    def plans(self, N, H, W, training, slot=0):
+        """slot: independent activation workspace (a shared SR net runs once per cascade stage, each stage's backward
+        needs its own saved activations -- interfaces/super_resolution.py:306-385 with --sr_share)"""
+        return self._two_pass((N, H, W, bool(training), slot), lambda ws, final: self._record(N, H, W, training, ws, final))
 
     def _record(self, N, H, W, training, ws, final):
         fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
         fwd.final = bwd.final = final
+        for bn in self._bn_layers:
+            bn.use(ws)
         with recording(fwd):
             self._record_fwd(N, H, W, training, ws)
         if training:
@@ -692,14 +705,14 @@ class TSRNEngine(_EngineBase):
                 conv.dgrad(N, h, w, ds, dact)
 
     # ---- execution -----------------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.module.in_planes:
             raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
         self.bind(x.device)
         N, _, H, W = x.shape
-        pl = self.plans(N, H, W, training)
+        pl = self.plans(N, H, W, training, slot)
         x = x.contiguous().float()
         sr = torch.empty(N, self.in_planes, 2 * H, 2 * W, dtype=F32, device=x.device)
         fwd = pl["fwd"]
@@ -718,9 +731,9 @@ class TSRNEngine(_EngineBase):
         return sr
 
 
-    def backward(self, x_shape, sr: torch.Tensor, dsr: torch.Tensor):
+    def backward(self, x_shape, sr: torch.Tensor, dsr: torch.Tensor, slot: int = 0):
         N, _, H, W = x_shape
-        pl = self.plans(N, H, W, True)
+        pl = self.plans(N, H, W, True, slot)
         self.arena.attach_grads()
         bwd = pl["bwd"]
         dsr = dsr.contiguous().float()

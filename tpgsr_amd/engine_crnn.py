@@ -120,12 +120,14 @@ class CRNNEngine(_EngineBase):
         assert h == 1, "the height of conv must be 1"   # crnn.py:83
         return dims
 
-    def plans(self, N, training):
-        return self._two_pass((N, bool(training)), lambda ws, final: self._record(N, training, ws, final))
+    def plans(self, N, training, slot=0):
+        return self._two_pass((N, bool(training), slot), lambda ws, final: self._record(N, training, ws, final))
 
     def _record(self, N, training, ws, final):
         fwd, bwd = Plan("crnn_fwd"), Plan("crnn_bwd")
         fwd.final = bwd.final = final
+        for bn in self._bn_layers:
+            bn.use(ws)
         with recording(fwd):
             self._record_fwd(N, training, ws)
         if training:
@@ -222,7 +224,7 @@ class CRNNEngine(_EngineBase):
                 K.copy(dg, K.DynPtr("dgray"), N * h * w)
 
     # ---- execution ----------------------------------------------------------------------------------------------
-    def forward(self, gray: torch.Tensor, training: bool) -> torch.Tensor:
+    def forward(self, gray: torch.Tensor, training: bool, slot: int = 0) -> torch.Tensor:
         """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major; the module returns the (T, N, C) view)"""
         if not gray.is_cuda:
             raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
@@ -230,7 +232,7 @@ class CRNNEngine(_EngineBase):
             raise ValueError(f"CRNN expects (N, 1, {self.IMG_HW[0]}, {self.IMG_HW[1]}) input, got {tuple(gray.shape)}")
         self.bind(gray.device)
         N = gray.shape[0]
-        pl = self.plans(N, training)
+        pl = self.plans(N, training, slot)
         gray = gray.contiguous().float()            # (N,1,H,W) NCHW with C = 1 is already NHWC
         logits = torch.empty(N, self.T, self.nclass, dtype=F32, device=gray.device)
         fwd = pl["fwd"]
@@ -242,8 +244,8 @@ class CRNNEngine(_EngineBase):
         self._last_gray = gray
         return logits
 
-    def backward(self, N, gray: torch.Tensor, dlogits: torch.Tensor, need_dgray: bool = False) -> Optional[torch.Tensor]:
-        pl = self.plans(N, True)
+    def backward(self, N, gray: torch.Tensor, dlogits: torch.Tensor, need_dgray: bool = False, slot: int = 0) -> Optional[torch.Tensor]:
+        pl = self.plans(N, True, slot)
         self.arena.attach_grads()
         bwd = pl["bwd"]
         dlogits = dlogits.contiguous().float()

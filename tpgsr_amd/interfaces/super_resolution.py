@@ -121,3 +121,178 @@ class TSRNTrainStep:
             self._exchange()
             self._graph_b.replay()
         return self._graph_loss
+
+
+def parse_crnn_data(imgs_input: torch.Tensor) -> torch.Tensor:
+    """TextBase.parse_crnn_data (reference interfaces/base.py:806-829): bicubic resize of the RGB channels to (32, 100)
+    and luminance -> (N, 1, 32, 100).  Differentiable (later cascade stages back-propagate into the previous SR)."""
+    return _ParseCrnnFn.apply(imgs_input)
+
+
+class _ParseCrnnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        if not x.is_cuda:
+            raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback)")
+        x = x.contiguous().float()
+        N, C, H, W = x.shape
+        out = torch.empty(N, 1, 32, 100, device=x.device)
+        K.bicubic_gray_fwd(x, N, C, H, W, 32, 100, out)
+        ctx.shape = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, C, H, W = ctx.shape
+        din = torch.empty(N, C, H, W, device=dout.device)
+        K.bicubic_gray_bwd(dout.contiguous().float(), N, C, H, W, 32, 100, din)
+        return din
+
+
+class TPGSRTrainStep:
+    """Configs C3-C5 (`--arch tsrn_tl_cascade --use_distill`), interfaces/super_resolution.py:295-406 + :419-424:
+    teacher CRNN(HR) -> q (no grad); per stage: student CRNN(prev image) -> softmax p -> distill loss*100 -> prior
+    (N,37,1,26) with samples [0, N//4) zeroed -> TSRN_TL(LR, prior) -> image loss*100; sum; backward through every
+    stage (the student receives gradient from the distill loss AND through the prior; later stages back-propagate
+    through parse_crnn_data into the previous SR image); clip each SR net at 0.25 (students are not clipped); ONE Adam
+    over SR nets + students."""
+
+    def __init__(self, sr_models, students, teacher, stu_iter=1, sr_share=True, tpg_share=False, gradient=True,
+                 loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1):
+        self.sr = list(sr_models) if isinstance(sr_models, (list, tuple)) else [sr_models]
+        self.stu = list(students) if isinstance(students, (list, tuple)) else [students]
+        self.teacher = teacher
+        self.stu_iter, self.sr_share, self.tpg_share = stu_iter, sr_share, tpg_share
+        self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
+        mods = self.sr + self.stu
+        self.opt = FusedAdam(mods, lr=lr, betas=betas, clip_modules=self.sr, max_norm=max_norm)
+        self.pg, self.world = process_group, world_size
+        self._static = None
+        self._graph = None
+        self._dbg = {}
+
+    def _buffers(self, lr_img):
+        dev, N = lr_img.device, lr_img.shape[0]
+        if self._static is None or self._static["key"] != (dev, tuple(lr_img.shape)):
+            _, C, H, W = lr_img.shape
+            S = self.stu_iter
+            st = dict(key=(dev, tuple(lr_img.shape)), q=torch.empty(N, 26, 37, device=dev),
+                      gray_hr=torch.empty(N, 1, 32, 100, device=dev), loss=torch.zeros((), device=dev),
+                      dloss=torch.full((1,), 100.0, device=dev), inv_world=torch.full((1,), 1.0 / self.world, device=dev),
+                      part_img=[torch.empty(_NBLK, 2, device=dev) for _ in range(S)],
+                      part_sem=[torch.empty(_NBLK, 2, device=dev) for _ in range(S)],
+                      l_img=[torch.zeros((), device=dev) for _ in range(S)], l_sem=[torch.zeros((), device=dev) for _ in range(S)],
+                      gray=[torch.empty(N, 1, 32, 100, device=dev) for _ in range(S)],
+                      p=[torch.empty(N, 26, 37, device=dev) for _ in range(S)],
+                      prior=[torch.empty(N, 37, 1, 26, device=dev) for _ in range(S)],
+                      dsr=[torch.empty(N, C, 2 * H, 2 * W, device=dev) for _ in range(S)],
+                      dcas=torch.empty(N, C, 2 * H, 2 * W, device=dev), dlogits=torch.empty(N, 26, 37, device=dev))
+            self._static = st
+        return self._static
+
+    def _phase_a(self, lr_img, hr_img):
+        st = self._buffers(lr_img)
+        N, C, H, W = lr_img.shape
+        H2, W2 = 2 * H, 2 * W
+        hr = hr_img.contiguous()
+        lr_img = lr_img.contiguous()
+        self.opt.zero_grad()
+        # teacher on HR (eval mode, no gradient)
+        K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
+        t_logits = self.teacher._engine().forward(st["gray_hr"], False)
+        K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
+        cascade, ch, cw = lr_img, H, W
+        srs, logits_keep = [], []
+        for i in range(self.stu_iter):
+            stu = self.stu[0 if self.tpg_share else i]
+            srm = self.sr[0 if self.sr_share else i]
+            K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
+            logits = stu._engine().forward(st["gray"][i], True, slot=i)
+            K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
+            K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
+            sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i)
+            K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
+            n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
+            K.image_loss_finalize(st["part_img"][i], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
+            srs.append(sr)
+            cascade, ch, cw = sr, H2, W2
+        # total loss (device scalar) = sum of the 2*stu_iter scalars
+        K.copy(st["l_img"][0], st["loss"], 1)
+        for i in range(self.stu_iter):
+            if i > 0:
+                K.add(st["loss"], st["l_img"][i], 1, st["loss"])
+            K.add(st["loss"], st["l_sem"][i], 1, st["loss"])
+        # backward, last stage first
+        for i in range(self.stu_iter - 1, -1, -1):
+            stu = self.stu[0 if self.tpg_share else i]
+            srm = self.sr[0 if self.sr_share else i]
+            K.image_loss_bwd(srs[i], hr, st["dloss"], N, C, H2, W2, self.gradient, self.w0, self.w1, st["dsr"][i])
+            if i < self.stu_iter - 1:      # gradient arriving through the next stage's parse_crnn_data
+                K.add(st["dsr"][i], st["dcas"], st["dsr"][i].numel(), st["dsr"][i])
+            dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i)
+            K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
+            if getattr(self, "_debug", False):
+                self._dbg.setdefault("dprior", {})[i] = dprior.clone()
+                self._dbg.setdefault("dlogits", {})[i] = st["dlogits"].clone()
+            dgray = stu._engine().backward(N, st["gray"][i], st["dlogits"], need_dgray=i > 0, slot=i)
+            if i > 0:
+                self._dbg_dgray = dgray
+                K.bicubic_gray_bwd(dgray, N, C, H2, W2, 32, 100, st["dcas"])
+        self.last_sr, self.last_p = srs[-1], st["p"][self.stu_iter - 1]
+        return st["loss"]
+
+    def _exchange(self):
+        if self.world > 1:
+            for m in self.sr + self.stu:
+                exchange_gradients(m._engine().arena.grad, self.pg)
+
+    def _phase_b(self):
+        if self.world > 1:
+            for m in self.sr + self.stu:
+                a = m._engine().arena
+                K.scale_(a.grad, a.numel, self._static["inv_world"])
+        self.opt.step()
+
+    def step(self, lr_img, hr_img):
+        for m in self.sr + self.stu:
+            if not m.training:
+                raise RuntimeError("TPGSRTrainStep.step needs the SR nets and students in train() mode")
+            m._engine().bind(lr_img.device)
+        self.teacher._engine().bind(lr_img.device)
+        loss = self._phase_a(lr_img, hr_img)
+        self._exchange()
+        self._phase_b()
+        return loss
+
+    def capture(self, lr_img, hr_img, warmup=2):
+        self._lr, self._hr = lr_img.clone(), hr_img.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.step(self._lr, self._hr)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._graph_loss = self._phase_a(self._lr, self._hr)
+            if self.world == 1:
+                self._phase_b()
+        self._graph, self._graph_b = ga, None
+        if self.world > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                self._phase_b()
+            self._graph_b = gb
+        return ga
+
+    def replay(self, lr_img=None, hr_img=None):
+        if lr_img is not None:
+            self._lr.copy_(lr_img)
+        if hr_img is not None:
+            self._hr.copy_(hr_img)
+        self._graph.replay()
+        if self._graph_b is not None:
+            self._exchange()
+            self._graph_b.replay()
+        return self._graph_loss

@@ -1,1 +1,1 @@
-from . import image_loss, gradient_loss  # noqa: F401
+from . import image_loss, gradient_loss, semantic_loss  # noqa: F401
