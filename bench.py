@@ -75,6 +75,21 @@ def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def mfma_probe_tflops():
+    """register-only v_mfma_f32_32x32x2_f32 loop: what this chip sustains at its real clock (datasheet: 157.3)"""
+    from tpgsr_amd import kernels as K
+    out = torch.zeros(4, device="cuda")
+    blocks, iters = 4096, 1000
+    K.mfma_probe(out, blocks, iters)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    K.mfma_probe(out, blocks, iters)
+    e1.record()
+    torch.cuda.synchronize()
+    return blocks * 4 * 2.0 * iters * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def cpu_baseline_subprocess(timeout_s=150):
     """Run the CPU-oracle timing in a child process with a hard timeout (a mis-sized thread pool must never stall the bench)."""
     import subprocess
@@ -215,7 +230,8 @@ def main():
                                "unit": "TFLOP/s", "frac": round(r["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "launches_per_step": r["launches"], "avg_us_per_launch": round(r["avg_us_per_launch"], 2),
                                "gflop_per_launch": round(r["flops_per_step"] / r["launches"] / 1e9, 4),
-                               "share_of_step_ms": round(r["ms_per_step"], 4)}
+                               "share_of_step_ms": round(r["ms_per_step"], 4),
+                               "measured_mfma_only_peak": round(mfma_probe_tflops(), 1)}
             # whole-step view against SURVEY 8d's algorithmic constants (58.8 MB, 5.5 GFLOP per image per C2 step)
             out["step_roofline"] = {"hbm_frac": round(value / world * 58.8e6 / 8.0e12, 4),
                                     "fp32_flop_frac": round(value / world * 5.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)}

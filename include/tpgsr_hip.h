@@ -129,6 +129,8 @@ typedef struct {
   int numel, blk0;
 } tpgsr_pack_desc;
 int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+/* diagnostic: `blocks` workgroups x 4 waves x 2*iters register-only v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) */
+int tpgsr_mfma_probe(float* out, int blocks, int iters, void* stream);
 int tpgsr_copy(const float* src, float* dst, long long n, void* stream);   /* async D2D copy (graph memcpy node) */
 int tpgsr_zero(float* dst, long long n, void* stream);                     /* async memset */
 

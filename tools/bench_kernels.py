@@ -68,7 +68,17 @@ def gru_case(axis):
     print(f"bigru_bwd axis={axis}  {us:8.1f} us")
 
 
+def mfma_probe():
+    out = torch.zeros(4, device=DEV)
+    for blocks in (1024, 2048, 4096):
+        iters = 2000
+        us = timeit(lambda: K.mfma_probe(out, blocks, iters), reps=5, warm=2)
+        fl = blocks * 4 * 2.0 * iters * 4096
+        print(f"mfma_probe blocks={blocks}: {us:8.1f} us  {fl / us / 1e6:7.2f} TFLOP/s (register-only fp32 MFMA)")
+
+
 if __name__ == "__main__":
+    mfma_probe()
     conv_case("3x3 64->64 (RRB conv)", H, W, 64, 64, 3, 3, 1, 1)
     conv_case("3x3 64->64 +bn/mish loader+stats", H, W, 64, 64, 3, 3, 1, 1, prologue=True, stats=True)
     conv_case("1x1 64->64 (GruBlock conv1)", H, W, 64, 64, 1, 1, 0, 0)

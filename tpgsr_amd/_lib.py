@@ -43,6 +43,7 @@ class PackDesc(C.Structure):
 
 _SIGS = {
     "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
+    "tpgsr_mfma_probe": (ci, [vp, ci, ci, vp]),
     "tpgsr_copy": (ci, [vp, vp, ll, vp]),
     "tpgsr_zero": (ci, [vp, ll, vp]),
     "tpgsr_version": (ci, []),

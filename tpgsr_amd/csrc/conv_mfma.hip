@@ -9,6 +9,7 @@
 // second operand row-major in LDS; v_mfma_f32_32x32x2_f32 fragments are fetched with conflict-free ds_read_b32
 // (lane l reads row k0 + (l>>5), column (l&31)).  fp32 in, fp32 accumulate: bit-for-bit an fmaf chain.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 64
 #define BN 64
@@ -241,12 +242,18 @@ __device__ __forceinline__ float4 finish_a(const tpgsr_conv_args& a, const ARaw&
 // ------------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------------
-template <int LD>   // LD >= 0: vector quad loader with compile-time prologue bits; LD < 0: generic scalar loader
-__global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M, int K, int vecB) {
+// SPLIT = 2: two 256-thread groups per workgroup work on the two halves of the K range of the SAME 64x64 tile (own LDS
+// buffers, combined through LDS at the end).  Used for grids of only a few tiles per CU (the 64->64 convs: 768 tiles):
+// it doubles the resident wavefronts per SIMD without shrinking the MFMA tile.
+template <int LD, int SPLIT>   // LD >= 0: vector quad loader with compile-time prologue bits; LD < 0: generic scalar loader
+__global__ __launch_bounds__(256 * SPLIT) void conv_fwd_kernel(tpgsr_conv_args a, int M, int K, int vecB) {
   constexpr bool VEC_A = LD >= 0;
-  __shared__ float As[KC][ALD];
-  __shared__ float Bs[KC][BN];
-  const int tid = threadIdx.x;
+  __shared__ float As_[SPLIT][KC][ALD];
+  __shared__ float Bs_[SPLIT][KC][BN];
+  const int grp = SPLIT > 1 ? (int)(threadIdx.x >> 8) : 0;
+  float (*As)[ALD] = As_[grp];
+  float (*Bs)[BN] = Bs_[grp];
+  const int tid = threadIdx.x & 255;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int nbn = (a.Cout + BN - 1) / BN;
@@ -255,7 +262,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
   const int m0 = mblk * BM, n0 = (tile - mblk * nbn) * BN;
   const int ntaps = a.KH * a.KW;
   const int cin4 = a.Cin >> 2;
-  const int nchunks = (K + KC - 1) / KC;
+  const int nchunks_all = (K + KC - 1) / KC;
+  const int nchunks = (nchunks_all + SPLIT - 1) / SPLIT;   // chunks per group; a group's surplus chunk loads zeros
+  const int ch0 = grp * nchunks;
 
   // A staging: thread -> quad (tid&7) of the chunk, pixels (tid>>3) and (tid>>3)+32
   const int aq = tid & 7;
@@ -324,28 +333,49 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  load_chunk(0);
+  load_chunk(ch0);
   store_chunk();
   __syncthreads();
   const int arow = lane >> 5;
   const int acol = wm * 32 + (lane & 31);
   const int bcol = wn * 32 + (lane & 31);
+  const bool abl_noload = vecB & 256, abl_nolds = vecB & 512, abl_nobar = vecB & 1024;   // timing ablations (tools/bench_kernels.py)
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    if (ch + 1 < nchunks && !abl_noload) load_chunk(ch0 + ch + 1);
+    if (!abl_nolds) {
 #pragma unroll
-    for (int kk = 0; kk < KC / 2; ++kk) {
-      float av = As[2 * kk + arow][acol];
-      float bv = Bs[2 * kk + arow][bcol];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int kk = 0; kk < KC / 2; ++kk) {
+        float av = As[2 * kk + arow][acol];
+        float bv = Bs[2 * kk + arow][bcol];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+    } else {
+      float av = As[arow][acol], bv = Bs[arow][bcol];
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the prologue arithmetic / LDS stores of the next tile behind the MFMAs
-    __syncthreads();
+    if (!abl_nobar) __syncthreads();
     if (ch + 1 < nchunks) {
       store_chunk();
-      __syncthreads();
+      if (!abl_nobar) __syncthreads();
     }
   }
 
+  if (SPLIT > 1) {   // combine the two K halves: group 1 parks its accumulators in LDS, group 0 adds them
+    float* xch = &As_[0][0][0];   // As_ = 2*KC*ALD = 4160 floats >= the 64x64 tile; nobody reads it after the loop's last barrier
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += xch[(wave * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  const bool active = grp == 0;   // group 1 keeps running (barriers below stay workgroup-uniform) but writes nothing
   // ---- epilogue: bias, activation, (pixel-shuffled) store, BN partial statistics ----
   const int n = n0 + bcol;
   const bool nvalid = n < a.Cout;
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
   for (int r = 0; r < 16; ++r) {
     int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     int m = m0 + wm * 32 + row;
-    if (m < M && nvalid) {
+    if (m < M && nvalid && active) {
       float raw = acc[r];
       s += raw;
       ss += raw * raw;
@@ -375,13 +405,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(tpgsr_conv_args a, int M,
   if (a.bn_partial) {
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
-    float* red = &As[0][0];  // all MFMA reads finished behind the loop's final barrier
+    float* red = &Bs[0][0];  // group-private; all MFMA reads finished behind the loop's final barrier
     if (lane < 32) {
       red[(wm * 2 + 0) * BN + bcol] = s;
       red[(wm * 2 + 1) * BN + bcol] = ss;
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < a.Cout) {
+    if (active && tid < BN && n0 + tid < a.Cout) {
       float* dst = a.bn_partial + (size_t)mblk * 2 * a.Cout;
       dst[n0 + tid] = red[0 * BN + tid] + red[2 * BN + tid];
       dst[a.Cout + n0 + tid] = red[1 * BN + tid] + red[3 * BN + tid];
@@ -429,10 +459,18 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   int vecB = ((a->Cout & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
-#define TPGSR_FWD_CASE(B) case B: hipLaunchKernelGGL(conv_fwd_kernel<B>, grid, dim3(256), 0, st, *a, (int)M, K, vecB); break;
   vecB = vecB && ((a->wt_ld & 3) == 0) && ((a->wt_coff & 3) == 0);
+  // few tiles per CU and a long K loop: split K over two thread groups of one workgroup (twice the resident waves)
+  if (const char* abl = getenv("TPGSR_CONV_ABLATE")) vecB |= atoi(abl) << 8;   // diagnostic timing ablations only
+  const char* nosplit = getenv("TPGSR_CONV_NO_SPLITK");
+  const bool split = grid.x < 256 * 5 && (K + KC - 1) / KC >= 6 && !(nosplit && nosplit[0] == '1');
+#define TPGSR_FWD_CASE(B)                                                                                \
+  case B:                                                                                                \
+    if (split) hipLaunchKernelGGL((conv_fwd_kernel<B, 2>), grid, dim3(512), 0, st, *a, (int)M, K, vecB); \
+    else hipLaunchKernelGGL((conv_fwd_kernel<B, 1>), grid, dim3(256), 0, st, *a, (int)M, K, vecB);       \
+    break;
   if ((a->Cin & 3) != 0 || !vecB) {
-    hipLaunchKernelGGL(conv_fwd_kernel<-1>, grid, dim3(256), 0, st, *a, (int)M, K, vecB);
+    hipLaunchKernelGGL((conv_fwd_kernel<-1, 1>), grid, dim3(256), 0, st, *a, (int)M, K, vecB);
   } else {
     switch (ld) {
       TPGSR_FWD_CASE(0) TPGSR_FWD_CASE(1) TPGSR_FWD_CASE(3) TPGSR_FWD_CASE(4) TPGSR_FWD_CASE(5) TPGSR_FWD_CASE(7)
@@ -863,4 +901,29 @@ extern "C" int tpgsr_zero(float* dst, long long n, void* stream) {
     return TPGSR_ERR_LAUNCH;
   }
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// diagnostic: register-only fp32 MFMA loop (no memory traffic) -- the achievable v_mfma_f32_32x32x2_f32 rate of this
+// chip at its sustained clock; bench.py reports it next to the datasheet peak
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters, float a0, float b0) {
+  floatx16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+  float a = a0 + (float)(threadIdx.x & 7), b = b0 + (float)(threadIdx.x & 3);
+  for (int it = 0; it < iters; ++it) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+  if (s == 12345.678f) out[0] = s;   // keep the loop alive
+}
+
+extern "C" int tpgsr_mfma_probe(float* out, int blocks, int iters, void* stream) {
+  TPGSR_CHECK_ARG(out && blocks > 0 && iters > 0, "tpgsr_mfma_probe: bad arguments");
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 1.0f, 0.5f);
+  TPGSR_LAUNCH_CHECK("tpgsr_mfma_probe");
 }

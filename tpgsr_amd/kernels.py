@@ -200,6 +200,10 @@ def pack_program(descs_dev, ndesc, total_blocks):
     _launch("tpgsr_pack_program", _p(descs_dev), ndesc, total_blocks)
 
 
+def mfma_probe(out, blocks, iters):
+    _launch("tpgsr_mfma_probe", _p(out), blocks, iters)
+
+
 def copy(src, dst, n):
     _launch("tpgsr_copy", _p(src), _p(dst), n)
 
