@@ -252,3 +252,48 @@ def test_cascade_two_stages_vs_oracle():
         print(f"cascade student {j}: global rel err {(num / den) ** 0.5:.3e}, worst per-tensor {worst}")
         assert (num / den) ** 0.5 < 3e-2, (j, (num / den) ** 0.5, worst)
         ofs += len(keys)
+
+
+def test_dropin_module_api_c3_step(golden_dir):
+    """The reference's own loop body (interfaces/super_resolution.py:295-424) written against the drop-in modules:
+    torch autograd + torch.optim.Adam + clip_grad_norm_ drive the HIP plans through the nn.Module API."""
+    from tpgsr_amd.interfaces.super_resolution import parse_crnn_data
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    from tpgsr_amd.loss.semantic_loss import SemanticLoss
+    t = np.load(os.path.join(golden_dir, "train_c3.npz"))
+    srs, stus, teacher, *_ = _c3_models()
+    model, stu = srs[0], stus[0]
+    for q in teacher.parameters():
+        q.requires_grad = False
+    image_crit, sem_loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4]), SemanticLoss()
+    optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    images_lr, images_hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+    losses = []
+    for step in range(2):
+        label_vecs_hr = torch.nn.functional.softmax(teacher(parse_crnn_data(images_hr[:, :3, :, :])).detach(), -1)
+        label_vecs_logits = stu(parse_crnn_data(images_lr[:, :3, :, :]))
+        label_vecs = torch.nn.functional.softmax(label_vecs_logits, -1)
+        label_vecs_final = label_vecs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+        loss_recog_distill = sem_loss(label_vecs, label_vecs_hr) * 100
+        drop_vec = torch.ones(images_lr.shape[0]).float()
+        drop_vec[:int(images_lr.shape[0] // 4)] = 0.
+        label_vecs_final = label_vecs_final * drop_vec.to(DEV).view(-1, 1, 1, 1)
+        cascade_images = model(images_lr, label_vecs_final)
+        loss_img = image_crit(cascade_images, images_hr).mean() * 100
+        loss_im = loss_img + loss_recog_distill
+        optimizer_G.zero_grad()
+        loss_im.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+        optimizer_G.step()
+        losses.append(loss_im.item())
+        if step == 0:
+            assert abs(loss_im.item() - t["loss"][0]) < 3e-4 * t["loss"][0]
+            assert abs(float(gn) - t["gnorm"][0]) < 3e-3 * t["gnorm"][0]
+            assert (label_vecs.detach().argmax(-1).cpu().numpy() == t["prior_argmax_step0"]).all()
+    print("drop-in loop losses", losses, t["loss"][:2])
+    assert abs(losses[1] - t["loss"][1]) < 2e-2 * t["loss"][1]
+    # state_dict round trip keeps the reference's key layout
+    sd = model.state_dict()
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "state_dict_layouts.json")))["tsrn_tl_stn_mask"]
+    assert [(k, list(v.shape)) for k, v in sd.items()] == [(a, b) for a, b in ref]

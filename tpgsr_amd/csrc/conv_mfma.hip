@@ -460,10 +460,11 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
   vecB = vecB && ((a->wt_ld & 3) == 0) && ((a->wt_coff & 3) == 0);
-  // few tiles per CU and a long K loop: split K over two thread groups of one workgroup (twice the resident waves)
-  if (const char* abl = getenv("TPGSR_CONV_ABLATE")) vecB |= atoi(abl) << 8;   // diagnostic timing ablations only
-  const char* nosplit = getenv("TPGSR_CONV_NO_SPLITK");
-  const bool split = grid.x < 256 * 5 && (K + KC - 1) / KC >= 6 && !(nosplit && nosplit[0] == '1');
+  // optional (TPGSR_CONV_SPLITK=1): split K over two thread groups of one workgroup (twice the resident waves on grids
+  // of few tiles per CU).  Measured neutral on MI355X for the 768-tile 64->64 convs (48.0 vs 47.4 us): the launch is
+  // bound by per-launch fixed costs, not by occupancy, so it is off by default.
+  const char* splitk = getenv("TPGSR_CONV_SPLITK");
+  const bool split = splitk && splitk[0] == '1' && grid.x < 256 * 5 && (K + KC - 1) / KC >= 6;
 #define TPGSR_FWD_CASE(B)                                                                                \
   case B:                                                                                                \
     if (split) hipLaunchKernelGGL((conv_fwd_kernel<B, 2>), grid, dim3(512), 0, st, *a, (int)M, K, vecB); \

@@ -32,13 +32,13 @@ extern "C" int tpgsr_bn_stats(const float* x, long long M, int C, int ld, float*
 }
 
 // one block of 256 threads per 32 channels; 8 row-slices per channel, fp64 combine
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                           long long count, const float* conv_bias,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum,
                                                           float eps, int eval, float* scale, float* shift,
                                                           float* save_mean, float* save_rstd) {
-  __shared__ double red[2][64][16];
+  __shared__ double red[2][16][16];
   int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   int c = blockIdx.x * 16 + cl;
   if (eval) {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   }
   double s = 0.0, ss = 0.0;
   if (c < C)
-    for (int b = sl; b < nblk; b += 64) {
+    for (int b = sl; b < nblk; b += 16) {
       s += (double)partial[((size_t)b * 2 + 0) * C + c];
       ss += (double)partial[((size_t)b * 2 + 1) * C + c];
     }
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   red[1][sl][cl] = ss;
   __syncthreads();
   if (sl == 0 && c < C) {
-    for (int i = 1; i < 64; ++i) {
+    for (int i = 1; i < 16; ++i) {
       s += red[0][i][cl];
       ss += red[1][i][cl];
     }
@@ -89,7 +89,7 @@ extern "C" int tpgsr_bn_finalize(const float* partial, int nblk, int C, long lon
   TPGSR_CHECK_ARG(gamma && beta && scale && shift && C > 0, "tpgsr_bn_finalize: null pointer");
   TPGSR_CHECK_ARG(eval || (partial && nblk > 0 && count > 0), "tpgsr_bn_finalize: training mode needs partial statistics");
   TPGSR_CHECK_ARG(!eval || (running_mean && running_var), "tpgsr_bn_finalize: eval mode needs running statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
                      conv_bias, gamma, beta, running_mean, running_var, momentum, eps, eval, scale, shift, save_mean,
                      save_rstd);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_finalize");
@@ -161,17 +161,17 @@ extern "C" int tpgsr_bn_bwd_reduce(const float* da, const float* da2, const floa
   TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_reduce");
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                               long long count, const float* __restrict__ gamma,
                                                               const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_rstd, float* dgamma,
                                                               float* dbeta, int accumulate, float* coef) {
-  __shared__ double red[2][64][16];
+  __shared__ double red[2][16][16];
   int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   int c = blockIdx.x * 16 + cl;
   double s = 0.0, sx = 0.0;
   if (c < C)
-    for (int b = sl; b < nblk; b += 64) {
+    for (int b = sl; b < nblk; b += 16) {
       s += (double)partial[((size_t)b * 2 + 0) * C + c];
       sx += (double)partial[((size_t)b * 2 + 1) * C + c];
     }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   red[1][sl][cl] = sx;
   __syncthreads();
   if (sl == 0 && c < C) {
-    for (int i = 1; i < 64; ++i) {
+    for (int i = 1; i < 16; ++i) {
       s += red[0][i][cl];
       sx += red[1][i][cl];
     }
@@ -198,7 +198,7 @@ extern "C" int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long
                                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                      int accumulate, float* coef, void* stream) {
   TPGSR_CHECK_ARG(partial && gamma && save_mean && save_rstd && coef && nblk > 0 && count > 0, "tpgsr_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
                      gamma, save_mean, save_rstd, dgamma, dbeta, accumulate, coef);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_finalize");
 }
