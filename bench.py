@@ -50,7 +50,7 @@ def conv_roofline(eng, N, H, W, reps=5):
     ops = []
     flops = 0.0
     for plan in (pl["fwd"], pl["bwd"]):
-        for name, fn, args in plan.ops:
+        for name, fn, args, _sid in plan.ops:
             if name == "tpgsr_conv_fwd":
                 a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
                 flops += 2.0 * (a.N * a.OH * a.OW) * (a.KH * a.KW * a.Cin) * a.Cout

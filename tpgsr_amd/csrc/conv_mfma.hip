@@ -75,57 +75,6 @@ __device__ __forceinline__ float load_a_scalar(const tpgsr_conv_args& a, const P
   return v;
 }
 
-// four consecutive k (one (tap, 4-channel) quad) of the A operand; requires Cin % 4 == 0.
-// Branch-free on purpose: an out-of-range tap / padding pixel loads from pixel 0 and is zeroed by a select, so the
-// compiler can issue the global loads early and wait for them only where the values are stored to LDS.
-// LD bits: 1 = per-channel affine, 2 = activation (a.in_act), 4 = residual add (in2), 8 = un-PixelShuffle gather
-template <int LD>
-__device__ __forceinline__ float4 load_a_quad(const tpgsr_conv_args& a, const PixelPos& p, int tap, int c, int ntaps) {
-  int kh = tap / a.KW, kw = tap - kh * a.KW;
-  int ih = p.oh + kh - a.pad_h, iw = p.ow + kw - a.pad_w;
-  const bool ok = p.valid && tap < ntaps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-  const size_t pix = ok ? (size_t)(p.n * a.H + ih) * a.W + iw : 0;
-  float4 v;
-  if (!(LD & 8)) {
-    v = *reinterpret_cast<const float4*>(a.in + pix * a.in_ld + a.in_coff + c);
-  } else {
-    int C4 = a.Cin >> 2, cs = c >> 2;
-    size_t W2 = 2 * (size_t)a.W;
-    int n = ok ? p.n : 0, ih2 = ok ? ih : 0, iw2 = ok ? iw : 0;
-    const float* b = a.in + ((size_t)(n * 2 * a.H + 2 * ih2) * W2 + 2 * iw2) * C4 + cs;
-    v.x = b[0];
-    v.y = b[C4];
-    v.z = b[W2 * C4];
-    v.w = b[W2 * C4 + C4];
-  }
-  if (LD & 1) {
-    float4 s = *reinterpret_cast<const float4*>(a.in_scale + c);
-    float4 t = *reinterpret_cast<const float4*>(a.in_shift + c);
-    v.x = v.x * s.x + t.x;
-    v.y = v.y * s.y + t.y;
-    v.z = v.z * s.z + t.z;
-    v.w = v.w * s.w + t.w;
-  }
-  if (LD & 2) {
-    v.x = apply_act(v.x, a.in_act);
-    v.y = apply_act(v.y, a.in_act);
-    v.z = apply_act(v.z, a.in_act);
-    v.w = apply_act(v.w, a.in_act);
-  }
-  if (LD & 4) {
-    float4 r = *reinterpret_cast<const float4*>(a.in2 + pix * a.in2_ld + c);
-    v.x += r.x;
-    v.y += r.y;
-    v.z += r.z;
-    v.w += r.w;
-  }
-  v.x = ok ? v.x : 0.f;
-  v.y = ok ? v.y : 0.f;
-  v.z = ok ? v.z : 0.f;
-  v.w = ok ? v.w : 0.f;
-  return v;
-}
-
 // 4 consecutive columns of a row-major [rows][ld] operand; vec: 16-byte aligned full quads (branch-free)
 __device__ __forceinline__ float4 load_row4(const float* base, size_t row, int ld, int col, int ncols, bool rowvalid,
                                             bool vec) {
@@ -171,14 +120,41 @@ struct ARaw {
   bool ok, raw;   // raw: value comes from the concatenated strip (no affine / activation / residual)
 };
 
-// issue the loads of one A quad (no dependent arithmetic); LD bits as in load_a_quad
+// issue the loads of one A quad (four consecutive k = one (tap, 4-channel) group; needs Cin % 4 == 0), no dependent
+// arithmetic.  LD bits: 1 = per-channel affine, 2 = activation (a.in_act), 4 = residual add (in2), 8 = un-PixelShuffle
+// gather, 16 = concatenated strip
+// position of one thread's A quad inside the K = (kh, kw, c) index space; advanced incrementally from chunk to chunk
+// (the per-chunk integer divisions were ~100 VALU instructions per wave per chunk next to 16 MFMAs)
+struct KPos {
+  int kh, kw, c;
+};
+__device__ __forceinline__ KPos kpos_init(const tpgsr_conv_args& a, int kq) {   // kq: quad index, K / 4 ordering
+  const int cin4 = a.Cin >> 2;
+  int tap = kq / cin4;
+  KPos k;
+  k.c = (kq - tap * cin4) * 4;
+  k.kh = tap / a.KW;
+  k.kw = tap - k.kh * a.KW;
+  return k;
+}
+__device__ __forceinline__ void kpos_advance(const tpgsr_conv_args& a, KPos& k, int dk) {
+  k.c += dk;
+  while (k.c >= a.Cin) {
+    k.c -= a.Cin;
+    if (++k.kw == a.KW) {
+      k.kw = 0;
+      ++k.kh;
+    }
+  }
+}
+
 template <int LD>
 __device__ __forceinline__ ARaw load_a_raw(const tpgsr_conv_args& a, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rin2,
-                                           const PixelPos& p, int tap, int c, int ntaps) {
+                                           const PixelPos& p, const KPos& kp) {
   ARaw r;
-  int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int kh = kp.kh, kw = kp.kw, c = kp.c;
   int ih = p.oh + kh - a.pad_h, iw = p.ow * stride_w(a) + kw - a.pad_w;
-  r.ok = p.valid && tap < ntaps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+  r.ok = p.valid && kh < a.KH && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
   int Wr = a.W;
   if (a.in_dil_w > 1) {
     r.ok = r.ok && (iw % a.in_dil_w) == 0;
@@ -260,8 +236,6 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_fwd_kernel(tpgsr_conv_args a
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mblk = tile / nbn;
   const int m0 = mblk * BM, n0 = (tile - mblk * nbn) * BN;
-  const int ntaps = a.KH * a.KW;
-  const int cin4 = a.Cin >> 2;
   const int nchunks_all = (K + KC - 1) / KC;
   const int nchunks = (nchunks_all + SPLIT - 1) / SPLIT;   // chunks per group; a group's surplus chunk loads zeros
   const int ch0 = grp * nchunks;
@@ -286,17 +260,16 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_fwd_kernel(tpgsr_conv_args a
                                                    : make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * Wr_ * a.in2_ld);
   const int wld = a.wt_ld > 0 ? a.wt_ld : a.Cout;
   const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt, (size_t)K * wld);
+  KPos kp = kpos_init(a, VEC_A ? ch0 * (KC / 4) + aq : 0);   // this thread's quad of chunk ch0; load_chunk advances it
   auto load_chunk = [&](int ch) {
     if (VEC_A) {
-      int kq = ch * (KC / 4) + aq;
-      int tap = kq / cin4;
-      int c = (kq - tap * cin4) * 4;
-      qa0 = load_a_raw<LDV>(a, rs_in, rs_in2, px0, tap, c, ntaps);
-      qa1 = load_a_raw<LDV>(a, rs_in, rs_in2, px1, tap, c, ntaps);
+      qa0 = load_a_raw<LDV>(a, rs_in, rs_in2, px0, kp);
+      qa1 = load_a_raw<LDV>(a, rs_in, rs_in2, px1, kp);
       if (LDV & 1) {
-        qs = *reinterpret_cast<const float4*>(a.in_scale + c);
-        qt = *reinterpret_cast<const float4*>(a.in_shift + c);
+        qs = *reinterpret_cast<const float4*>(a.in_scale + kp.c);
+        qt = *reinterpret_cast<const float4*>(a.in_shift + kp.c);
       }
+      kpos_advance(a, kp, KC);
       int k0 = ch * KC + bk0, k1 = k0 + 16;
       const bool cok = n0 + bc < a.Cout;   // rows k >= K fall outside the buffer: hardware zero fill
       rb0 = buf_load4(rs_wt, cok ? ((unsigned)k0 * (unsigned)wld + (unsigned)(a.wt_coff + n0 + bc)) * 4u : OOB_OFF);
@@ -339,21 +312,27 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_fwd_kernel(tpgsr_conv_args a
   const int arow = lane >> 5;
   const int acol = wm * 32 + (lane & 31);
   const int bcol = wn * 32 + (lane & 31);
-  const bool abl_noload = vecB & 256, abl_nolds = vecB & 512, abl_nobar = vecB & 1024;   // timing ablations (tools/bench_kernels.py)
+#ifdef TPGSR_CONV_ABLATE_BUILD   // timing ablations (tools/bench_kernels.py); runtime flags would force the accumulator
+  const bool abl_noload = vecB & 256, abl_nolds = vecB & 512, abl_nobar = vecB & 1024;   // through VGPR copies every chunk
+#else
+  constexpr bool abl_noload = false, abl_nolds = false, abl_nobar = false;
+#endif
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch + 1 < nchunks && !abl_noload) load_chunk(ch0 + ch + 1);
+    float av[KC / 2], bv[KC / 2];
     if (!abl_nolds) {
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        float av = As[2 * kk + arow][acol];
-        float bv = Bs[2 * kk + arow][bcol];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int kk = 0; kk < KC / 2; ++kk) {   // all fragment reads first: one LDS round trip per chunk, not one per MFMA pair
+        av[kk] = As[2 * kk + arow][acol];
+        bv[kk] = Bs[2 * kk + arow][bcol];
       }
     } else {
-      float av = As[arow][acol], bv = Bs[arow][bcol];
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int kk = 0; kk < KC / 2; ++kk) av[kk] = As[arow][acol], bv[kk] = Bs[arow][bcol];
     }
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks each read pair next to its MFMAs again)
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);   // keep the prologue arithmetic / LDS stores of the next tile behind the MFMAs
     if (!abl_nobar) __syncthreads();
     if (ch + 1 < nchunks) {
@@ -523,18 +502,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
   const int k0 = kblk * WK, n0 = nblk * BN;
   const int mbeg = zblk * MB;
   const int mend = min(M, mbeg + MB);
-  const int ntaps = a.KH * a.KW;
-  const int cin4 = a.Cin >> 2;
 
   // A staging: quad (tid&15) of this block's 64 k rows (fixed for the whole kernel), pixels (tid>>4), +16
   const int aq = tid & 15;
   const int ap0 = tid >> 4;
-  int atap = 0, ac = 0;
-  if (VEC_A) {
-    int kq = (k0 >> 2) + aq;
-    atap = kq / cin4;
-    ac = (kq - atap * cin4) * 4;
-  }
+  const KPos kp = kpos_init(a, VEC_A ? (k0 >> 2) + aq : 0);
+  const int ac = kp.c;
   const int yr0 = tid >> 4;
   const int yc = (tid & 15) * 4;
 
@@ -557,8 +530,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
     PixelPos p0 = decode_pixel(a, ma, mend);
     PixelPos p1 = decode_pixel(a, mb, mend);
     if (VEC_A) {
-      qa0 = load_a_raw<LDV>(a, rs_in, rs_in2, p0, atap, ac, ntaps);
-      qa1 = load_a_raw<LDV>(a, rs_in, rs_in2, p1, atap, ac, ntaps);
+      qa0 = load_a_raw<LDV>(a, rs_in, rs_in2, p0, kp);
+      qa1 = load_a_raw<LDV>(a, rs_in, rs_in2, p1, kp);
       if (!w.dy_ps) {
         const bool cok = n0 + yc < a.Cout;
         ry0 = buf_load4(rs_dy, (p0.valid && cok) ? ((unsigned)ma * (unsigned)w.dy_ld + (unsigned)(w.dy_coff + n0 + yc)) * 4u : OOB_OFF);
@@ -611,12 +584,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
   for (int mc = mbeg; mc < mend; mc += WM) {
     const bool more = mc + WM < mend;
     if (more) load_chunk(mc + WM);
+    float av[WM / 2], bv[WM / 2];
 #pragma unroll
     for (int mm = 0; mm < WM / 2; ++mm) {
-      float av = As[arow][2 * mm + half];
-      float bv = Ys[2 * mm + half][bcol];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      av[mm] = As[arow][2 * mm + half];
+      bv[mm] = Ys[2 * mm + half][bcol];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mm = 0; mm < WM / 2; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mm], bv[mm], acc, 0, 0, 0);
     if (want_db) {
 #pragma unroll 8
       for (int r = 0; r < WM; ++r) dbacc += Ys[r][tid];

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -148,9 +149,10 @@ class ConvLayer:
         has_b = self.b is not None and not self.tail
         dbp = eng.scratch("wgrad_dbpart", Z * g.Cout) if has_b else None
         ca = K.make_conv_args(g, x, **(loader or {}))
-        K.conv_wgrad(K.make_wgrad_args(ca, dy, part, dbp, **(dy_kw or {})))
-        K.wgrad_reduce(part, dbp, Z, g, eng.G[self.wname], eng.G[self.bname] if has_b else None,
-                       layout=2 if self.tail else 0, accumulate=True, gscale=self.wscale)
+        with K.side():
+            K.conv_wgrad(K.make_wgrad_args(ca, dy, part, dbp, **(dy_kw or {})))
+            K.wgrad_reduce(part, dbp, Z, g, eng.G[self.wname], eng.G[self.bname] if has_b else None,
+                           layout=2 if self.tail else 0, accumulate=True, gscale=self.wscale)
 
 
 class BNLayer:
@@ -240,25 +242,25 @@ class GruLayer:
         """all parameter gradients of the block + dx = dL/d loader(x)"""
         eng, G, gp = self.eng, self.eng.G, self.gp
         K.bigru_bwd(gi, h, dh, dh2, self.whh, self.bhh, N, H, W, self.axis, dgi, dgh)
-        M = N * H * W
-        for d, suf in enumerate(("", "_reverse")):
-            sgn = 1 if d == 0 else -1
-            # hidden side: dW_hh[d] = dgh[:, d]^T h_prev(d), h_prev = h shifted one step against the scan direction
-            gh = ConvGeom(N, H, W, 32, 96, 1, 1, sgn if self.axis == 1 else 0, sgn if self.axis == 0 else 0, H, W)
-            Z = K.wgrad_splits(gh.M, gh.K, 96)
-            part = eng.scratch("wgrad_part", Z * 32 * 96)
-            dbp = eng.scratch("wgrad_dbpart", Z * 96)
-            ca = K.make_conv_args(gh, h, in_ld=64, in_coff=32 * d)
-            K.conv_wgrad(K.make_wgrad_args(ca, dgh, part, dbp, dy_ld=192, dy_coff=96 * d))
-            K.wgrad_reduce(part, dbp, Z, gh, G[gp + "weight_hh_l0" + suf], G[gp + "bias_hh_l0" + suf], accumulate=True)
-            # input side: dW_ih[d] = dgi[:, d]^T u, db_ih[d] = colsum
-            gi_ = ConvGeom(N, H, W, self.Cg, 96)
-            Z = K.wgrad_splits(gi_.M, gi_.K, 96)
-            part = eng.scratch("wgrad_part", Z * self.Cg * 96)
-            dbp = eng.scratch("wgrad_dbpart", Z * 96)
-            ca = K.make_conv_args(gi_, u)
-            K.conv_wgrad(K.make_wgrad_args(ca, dgi, part, dbp, dy_ld=192, dy_coff=96 * d))
-            K.wgrad_reduce(part, dbp, Z, gi_, G[gp + "weight_ih_l0" + suf], G[gp + "bias_ih_l0" + suf], accumulate=True)
+        with K.side():
+            for d, suf in enumerate(("", "_reverse")):
+                sgn = 1 if d == 0 else -1
+                # hidden side: dW_hh[d] = dgh[:, d]^T h_prev(d), h_prev = h shifted one step against the scan direction
+                gh = ConvGeom(N, H, W, 32, 96, 1, 1, sgn if self.axis == 1 else 0, sgn if self.axis == 0 else 0, H, W)
+                Z = K.wgrad_splits(gh.M, gh.K, 96)
+                part = eng.scratch("wgrad_part", Z * 32 * 96)
+                dbp = eng.scratch("wgrad_dbpart", Z * 96)
+                ca = K.make_conv_args(gh, h, in_ld=64, in_coff=32 * d)
+                K.conv_wgrad(K.make_wgrad_args(ca, dgh, part, dbp, dy_ld=192, dy_coff=96 * d))
+                K.wgrad_reduce(part, dbp, Z, gh, G[gp + "weight_hh_l0" + suf], G[gp + "bias_hh_l0" + suf], accumulate=True)
+                # input side: dW_ih[d] = dgi[:, d]^T u, db_ih[d] = colsum
+                gi_ = ConvGeom(N, H, W, self.Cg, 96)
+                Z = K.wgrad_splits(gi_.M, gi_.K, 96)
+                part = eng.scratch("wgrad_part", Z * self.Cg * 96)
+                dbp = eng.scratch("wgrad_dbpart", Z * 96)
+                ca = K.make_conv_args(gi_, u)
+                K.conv_wgrad(K.make_wgrad_args(ca, dgi, part, dbp, dy_ld=192, dy_coff=96 * d))
+                K.wgrad_reduce(part, dbp, Z, gi_, G[gp + "weight_ih_l0" + suf], G[gp + "bias_ih_l0" + suf], accumulate=True)
         # du = dgi W_ih  (dgrad of the input projection), then the 1x1 conv
         K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cg), dgi, self.wih_d, du))
         self.conv.wgrad(N, H, W, x, du, loader=loader)
@@ -299,8 +301,9 @@ class TConvStrip:
         Z = K.wgrad_splits(g.M, g.K, g.Cout)
         part = eng.scratch("wgrad_part", Z * g.K * g.Cout)
         ca = K.make_conv_args(g, x, in_dil_w=self.sw, **(loader or {}))
-        K.conv_wgrad(K.make_wgrad_args(ca, dy, part, None))
-        K.wgrad_reduce(part, None, Z, g, eng.G[self.wname], None, layout=3, accumulate=True)
+        with K.side():
+            K.conv_wgrad(K.make_wgrad_args(ca, dy, part, None))
+            K.wgrad_reduce(part, None, Z, g, eng.G[self.wname], None, layout=3, accumulate=True)
 
     def dgrad(self, N, Win, dy, dx):
         """dx[N][1][Win][Cin] = strided conv of dy[N][1][OW][Cout] with the un-flipped taps"""
@@ -403,6 +406,9 @@ class TSRNEngine(_EngineBase):
     def __init__(self, module: torch.nn.Module, grid_align_corners: bool = False):
         super().__init__(module)
         self.grid_align_corners = grid_align_corners
+        # weight-gradient launches on a second stream (Plan.side).  Needs every buffer a wgrad reads to be written once
+        # per backward pass: _record_bwd gives each layer its own dy / du / dgi / dgh instead of recycling one set.
+        self.overlap_wgrad = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
 
     def _build_layers(self):
         m = self.module
@@ -461,6 +467,7 @@ class TSRNEngine(_EngineBase):
     def _record(self, N, H, W, training, ws, final):
         fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
         fwd.final = bwd.final = final
+        bwd.overlap = self.overlap_wgrad
         for bn in self._bn_layers:
             bn.use(ws)
         with recording(fwd):
@@ -468,6 +475,7 @@ class TSRNEngine(_EngineBase):
         if training:
             with recording(bwd):
                 self._record_bwd(N, H, W, ws)
+                bwd.join()
         return dict(fwd=fwd, bwd=bwd, ws=ws)
 
     # ---- forward -------------------------------------------------------------------------------------------------
@@ -616,23 +624,29 @@ class TSRNEngine(_EngineBase):
         self.up.wgrad(N, H, W, t["y7"], dm, loader=dict(in2=t["b1"], **self.bn7.loader), dy_kw=dict(dy_ps=True))
         d_s = ws("d_s", P1, Cc)                                           # = d(bn7 out) = one of b1's gradients
         self.up.dgrad(N, H, W, dm, d_s, in_ps=True)
-        dy = ws("dy", P1, Cc)
+        uniq = self.overlap_wgrad
+
+        def buf(name, tag, C_):    # one buffer per use when a side-stream wgrad reads it, else one recycled buffer
+            return ws(tag + name if uniq else name, P1, C_)
+
+        dy = buf("dy", "b7_", Cc)
         self.bn7.backward(d_s, None, t["y7"], P1, "none", dy)
         gA, gB = ws("gA", P1, Cc), ws("gB", P1, Cc)
         last_out = t[f"r{self.srb - 1}_out"] if self.srb else t["b1"]
         self.conv7.wgrad(N, H, W, last_out, dy)
         self.conv7.dgrad(N, H, W, dy, gA)
         have_B = False
-        dgi, dgh = ws("dgi", P1, 192), ws("dgh", P1, 192)
-        du, da = ws("du", P1, Cc), ws("da", P1, Cc)
+        da = ws("da", P1, Cc)
         for i in range(self.srb - 1, -1, -1):
             L = self.rrb[i]
             p = f"r{i}_"
+            dgi, dgh, du = buf("dgi", p + "g2_", 192), buf("dgh", p + "g2_", 192), buf("du", p + "g2_", Cc)
             X = t[f"r{i - 1}_out"] if i > 0 else t["b1"]
             y1, y2, u1, gi1, h1, u2, gi2, out = (t[p + n] for n in ("y1", "y2", "u1", "gi1", "h1", "u2", "gi2", "out"))
             # gru2 (input X + h1): parameter grads + d(X + h1) -> gA (incoming gA/gB are dead after the scan)
             L["gru2"].bwd(N, H, W, X, u2, gi2, out, gA, gB if have_B else None, dgi, dgh, du, gA, in2=h1)
             # gru1 (input bn2(y2) [+ text strip]): dh = gA
+            dgi, dgh, du = buf("dgi", p + "g1_", 192), buf("dgh", p + "g1_", 192), buf("du", p + "g1_", Cc)
             if self.tl:
                 g1 = L["gru1"]
                 g1.bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
@@ -643,9 +657,11 @@ class TSRNEngine(_EngineBase):
                 K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
                 L["gru1"].bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
+            dy = buf("dy", p + "c2_", Cc)
             L["bn2"].backward(da, None, y2, P1, "none", dy)
             L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
             L["conv2"].dgrad(N, H, W, dy, da)                              # d mish(bn1(y1))
+            dy = buf("dy", p + "c1_", Cc)
             L["bn1"].backward(da, None, y1, P1, "mish", dy)
             L["conv1"].wgrad(N, H, W, X, dy)
             L["conv1"].dgrad(N, H, W, dy, gB)                              # second gradient path into X

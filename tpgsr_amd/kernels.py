@@ -19,6 +19,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SIDE = {}
+
+
+def side_stream(device=None) -> "torch.cuda.Stream":
+    """The per-device second HIP stream weight-gradient launches are recorded on (see Plan.side)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _SIDE.get(idx)
+    if st is None:
+        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
 class Plan:
     """A recorded, replayable list of kernel launches (static pointers + geometry).  Built once per shape by running
     the wrappers below under ``with recording(plan)``; ``run()`` replays it on the current stream with no Python
@@ -27,9 +39,11 @@ class Plan:
 
     def __init__(self, name=""):
         self.name = name
-        self.ops = []      # [name, cfunc, [args...]]
+        self.ops = []      # [name, cfunc, [args...], stream id]; cfunc None: "fork" / "join" stream dependencies
         self.keep = []     # tensors / arg structs referenced by raw pointer
         self.dyn = {}      # key -> [(op index, arg index)]
+        self.sid = 0       # stream the next recorded launch goes to: 0 = the caller's stream, 1 = side stream
+        self.forks = 0
 
     def mark_dynamic(self, key):
         """The NEXT recorded pointer argument equal to the DynPtr placeholder `key` becomes patchable."""
@@ -39,15 +53,70 @@ class Plan:
         for oi, ai in self.dyn[key]:
             self.ops[oi][2][ai] = ptr
 
+    def side(self):
+        """``with plan.side():`` -- the launches recorded inside go to the side stream, ordered after everything
+        recorded so far (fork) and in order among themselves; ``join()`` orders the caller's stream after them.
+        The backward pass puts every weight-gradient GEMM + its slab reduce there: they are leaves of the dependency
+        graph (nothing but the optimiser reads them), so they fill the machine while the latency-bound data-gradient
+        chain (dgrad -> BN backward -> BiGRU BPTT -> ...) runs on the main stream.  Under torch.cuda.graph capture
+        the same calls become fork/join edges of the hipGraph.  Results do not depend on the interleaving: every
+        kernel reduces in a fixed order and side launches only read buffers the main stream never rewrites."""
+        return _SideCtx(self)
+
+    def join(self):
+        if self.forks:
+            self.ops.append(["join", None, None, 0])
+            self.forks = 0
+
     def run(self):
-        s = _stream()
-        for name, fn, args in self.ops:
-            rc = fn(*args, s)
+        main = torch.cuda.current_stream()
+        streams = (main.cuda_stream, None)
+        side = None
+        for name, fn, args, sid in self.ops:
+            if fn is None:
+                if side is None:
+                    side = side_stream(main.device)
+                    streams = (main.cuda_stream, side.cuda_stream)
+                if name == "fork":
+                    side.wait_stream(main)
+                else:
+                    main.wait_stream(side)
+                continue
+            rc = fn(*args, streams[sid])
             if rc:
                 check(rc, f"{self.name}:{name}")
 
     def __len__(self):
         return len(self.ops)
+
+
+class _SideCtx:
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        p = self.plan
+        assert p.sid == 0, "nested side-stream sections"
+        p.ops.append(["fork", None, None, 0])
+        p.forks += 1
+        p.sid = 1
+
+    def __exit__(self, *exc):
+        self.plan.sid = 0
+        return False
+
+
+class _NoSide:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def side():
+    """Side-stream section of the plan being recorded (no-op when launching eagerly outside a plan)."""
+    return _REC.side() if _REC is not None and getattr(_REC, "overlap", False) else _NoSide()
 
 
 class DynPtr:
@@ -83,7 +152,7 @@ def _launch(name, *args):
             if isinstance(a, DynPtr):
                 _REC.dyn.setdefault(a.key, []).append((oi, ai))
                 args[ai] = None
-        _REC.ops.append([name, fn, args])
+        _REC.ops.append([name, fn, args, _REC.sid])
         return
     check(fn(*args, _stream()), name)
 
