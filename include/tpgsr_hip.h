@@ -293,6 +293,30 @@ int tpgsr_adam_step(float* p, const float* g, float* m, float* v, long long n, c
 int tpgsr_step_inc(int* step_dev, void* stream);
 int tpgsr_scale_(float* x, long long n, const float* coef, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Launch plans: a recorded sequence of the launches above, replayed by one call (the host-side analogue of
+ * the reference's per-iteration Python loop body, interfaces/super_resolution.py:336-424, with the interpreter
+ * taken out of the per-kernel path).  `symbol` is the name of any launch entry point of this header (the ones
+ * whose last parameter is the stream); `args` are its parameters in order, WITHOUT the stream: pointers in .p,
+ * integers in .i, floats in .f.  For tpgsr_conv_fwd / tpgsr_conv_wgrad args[0].p points to the argument struct,
+ * which is copied.  side != 0 puts the launch on the side stream given to tpgsr_plan_run; fork orders the side
+ * stream after everything recorded so far on the main stream, join orders the main stream after the side stream.
+ * add_* return the op index (>= 0) or a negative error.
+ * ---------------------------------------------------------------------------------------------- */
+typedef union tpgsr_plan_arg {
+  const void* p;
+  long long i;
+  double f;
+} tpgsr_plan_arg;
+void* tpgsr_plan_create(void);
+void tpgsr_plan_destroy(void* plan);
+int tpgsr_plan_size(const void* plan);
+int tpgsr_plan_add_launch(void* plan, const char* symbol, const tpgsr_plan_arg* args, int nargs, int side);
+int tpgsr_plan_add_fork(void* plan);
+int tpgsr_plan_add_join(void* plan);
+int tpgsr_plan_set_arg(void* plan, int op, int arg, const tpgsr_plan_arg* value);   /* patch a per-step pointer / scalar */
+int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,3 +62,31 @@ def test_product_path_has_no_cpu_fallback():
                           "tpgsr_amd.loss.image_loss; print(any(m.startswith('oracle') for m in sys.modules))"],
                          capture_output=True, text=True, cwd=ROOT)
     assert out.stdout.strip() == "False", out.stdout + out.stderr
+
+
+def test_native_plan_records_without_gpu():
+    """The plan executor (csrc/plan.cpp) can be built, inspected and rejected arguments reported with no device."""
+    from tpgsr_amd import _lib
+    lib = _lib.load()
+    h = lib.tpgsr_plan_create()
+    try:
+        args = (_lib.PlanArg * 4)()
+        args[0].p, args[1].p, args[2].i, args[3].p = 0x1000, 0x2000, 16, 0x3000
+        assert lib.tpgsr_plan_add_launch(h, b"tpgsr_add", args, 4, 0) == 0
+        assert lib.tpgsr_plan_add_fork(h) == 1
+        ca = _lib.ConvArgs()
+        one = (_lib.PlanArg * 1)()
+        one[0].p = ctypes.addressof(ca)
+        assert lib.tpgsr_plan_add_launch(h, b"tpgsr_conv_fwd", one, 1, 1) == 2
+        assert lib.tpgsr_plan_add_join(h) == 3
+        assert lib.tpgsr_plan_size(h) == 4
+        v = _lib.PlanArg()
+        v.p = 0x4000
+        assert lib.tpgsr_plan_set_arg(h, 0, 3, ctypes.byref(v)) == 0
+        assert lib.tpgsr_plan_set_arg(h, 2, 0, ctypes.byref(v)) < 0          # the copied argument struct is not patchable
+        assert lib.tpgsr_plan_add_launch(h, b"tpgsr_add", args, 3, 0) < 0     # wrong arity
+        assert b"arguments" in lib.tpgsr_last_error()
+        assert lib.tpgsr_plan_add_launch(h, b"tpgsr_version", args, 0, 0) < 0  # not a launch entry point
+        assert lib.tpgsr_plan_size(h) == 4
+    finally:
+        lib.tpgsr_plan_destroy(h)

@@ -140,6 +140,37 @@ def test_train_step0_with_stn_and_graph_replay(golden_dir):
     assert lb[0] == la[1] and lb[1] == la[2]   # same kernels, same order, deterministic reductions: bitwise equal
 
 
+def test_native_plan_two_streams_bitwise_equal_to_interpreted_single_stream(golden_dir, monkeypatch):
+    """The C-ABI plan executor with weight gradients on the side stream == op-by-op ctypes replay == everything on one
+    stream, bit for bit (3 optimiser steps: loss sequence and final parameters)."""
+    from tpgsr_amd import kernels as K
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    t = np.load(os.path.join(golden_dir, "train_c2.npz"))
+    lr, hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+
+    def run(mode):
+        with monkeypatch.context() as m:
+            if mode == "interpreted":
+                m.setattr(K.Plan, "run", K.Plan.run_interpreted)
+            if mode == "single":
+                m.setenv("TPGSR_OVERLAP_WGRAD", "0")
+            net, _ = _build(stn=True, seed=201)
+            net.train()
+            ts = TSRNTrainStep(net)
+            losses = [ts.step(lr, hr).item() for _ in range(3)]
+            torch.cuda.synchronize()
+            eng = net._engine()
+            n_side = sum(1 for op in eng.plans(lr.shape[0], 16, 64, True)["bwd"].ops if op[3] == 1)
+            return losses, eng.arena.flat.clone(), n_side
+
+    la, pa, sa = run("native")
+    lb, pb, sb = run("interpreted")
+    lc, pc, sc = run("single")
+    assert sa > 50 and sb == sa and sc == 0
+    assert la == lb == lc
+    assert torch.equal(pa, pb) and torch.equal(pa, pc)
+
+
 def test_stn_stage_by_stage_vs_oracle():
     """Where the STN path differs from the oracle: control points, source coordinates, rectified image."""
     net, sd = _build(stn=True, seed=101)

@@ -41,7 +41,20 @@ class PackDesc(C.Structure):
                 ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci)]
 
 
+class PlanArg(C.Union):
+    """tpgsr_plan_arg: one launch argument of a native plan (pointer / integer / float)"""
+    _fields_ = [("p", vp), ("i", ll), ("f", C.c_double)]
+
+
 _SIGS = {
+    "tpgsr_plan_create": (vp, []),
+    "tpgsr_plan_destroy": (None, [vp]),
+    "tpgsr_plan_size": (ci, [vp]),
+    "tpgsr_plan_add_launch": (ci, [vp, C.c_char_p, C.POINTER(PlanArg), ci, ci]),
+    "tpgsr_plan_add_fork": (ci, [vp]),
+    "tpgsr_plan_add_join": (ci, [vp]),
+    "tpgsr_plan_set_arg": (ci, [vp, ci, ci, C.POINTER(PlanArg)]),
+    "tpgsr_plan_run": (ci, [vp, vp, vp]),
     "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_mfma_probe": (ci, [vp, ci, ci, vp]),
     "tpgsr_copy": (ci, [vp, vp, ll, vp]),

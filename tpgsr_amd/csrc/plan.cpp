@@ -1,0 +1,207 @@
+// Native launch-plan executor: a recorded list of C-ABI kernel launches (+ fork/join edges between the caller's stream
+// and a side stream) replayed by ONE call, so a training step costs one host round trip instead of ~450 interpreter-level
+// calls.  The plan stores, per launch, the entry point and its scalar/pointer arguments; pointers to argument structs
+// (tpgsr_conv_args / tpgsr_wgrad_args) are copied into plan-owned storage.  Patchable pointer slots (per-step input /
+// output tensors) are rewritten with tpgsr_plan_set_arg.  Capturable into a hipGraph like the launches themselves.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+#include "../../include/tpgsr_hip.h"
+
+void tpgsr_set_error(const char* fmt, ...);
+
+namespace {
+
+typedef int (*thunk_fn)(const tpgsr_plan_arg* a, void* stream);
+
+template <typename T>
+inline T arg_as(const tpgsr_plan_arg& a) {
+  if constexpr (std::is_pointer<T>::value) return reinterpret_cast<T>(const_cast<void*>(a.p));
+  else if constexpr (std::is_floating_point<T>::value) return static_cast<T>(a.f);
+  else return static_cast<T>(a.i);
+}
+
+// every launch entry point is int f(P0, ..., Pn-1, void* stream): unpack P_i from a[i], pass the stream last
+template <typename Tuple, typename F, size_t... I>
+inline int call_with(F fn, const tpgsr_plan_arg* a, void* st, std::index_sequence<I...>) {
+  return fn(arg_as<typename std::tuple_element<I, Tuple>::type>(a[I])..., st);
+}
+
+template <typename F, F fn>
+struct Thunk;
+template <typename... P, int (*fn)(P...)>
+struct Thunk<int (*)(P...), fn> {
+  typedef std::tuple<P...> Tuple;
+  static constexpr int nargs = (int)sizeof...(P) - 1;
+  static_assert(std::is_same<typename std::tuple_element<sizeof...(P) - 1, Tuple>::type, void*>::value,
+                "launch entry points end with the stream");
+  static int call(const tpgsr_plan_arg* a, void* st) {
+    return call_with<Tuple>(fn, a, st, std::make_index_sequence<sizeof...(P) - 1>{});
+  }
+};
+
+struct Entry {
+  thunk_fn fn;
+  int nargs;
+  int struct_bytes;   // > 0: argument 0 points to a struct of this size (copied into the plan)
+};
+
+#define TPGSR_REG(sym) {#sym, {&Thunk<decltype(&sym), &sym>::call, Thunk<decltype(&sym), &sym>::nargs, 0}}
+#define TPGSR_REG_S(sym, T) {#sym, {&Thunk<decltype(&sym), &sym>::call, Thunk<decltype(&sym), &sym>::nargs, (int)sizeof(T)}}
+
+const std::unordered_map<std::string, Entry>& registry() {
+  static const std::unordered_map<std::string, Entry> r = {
+      TPGSR_REG_S(tpgsr_conv_fwd, tpgsr_conv_args), TPGSR_REG_S(tpgsr_conv_wgrad, tpgsr_wgrad_args),
+      TPGSR_REG(tpgsr_wgrad_reduce), TPGSR_REG(tpgsr_pack_conv_weight), TPGSR_REG(tpgsr_pack_tail_weight),
+      TPGSR_REG(tpgsr_pack_program), TPGSR_REG(tpgsr_mfma_probe), TPGSR_REG(tpgsr_copy), TPGSR_REG(tpgsr_zero),
+      TPGSR_REG(tpgsr_bn_finalize), TPGSR_REG(tpgsr_bn_stats), TPGSR_REG(tpgsr_bn_bwd_reduce),
+      TPGSR_REG(tpgsr_bn_bwd_finalize), TPGSR_REG(tpgsr_bn_bwd_apply), TPGSR_REG(tpgsr_affine_act),
+      TPGSR_REG(tpgsr_affine_act_pool), TPGSR_REG(tpgsr_affine_act_pool_bwd), TPGSR_REG(tpgsr_prelu_fwd),
+      TPGSR_REG(tpgsr_prelu_bwd), TPGSR_REG(tpgsr_add), TPGSR_REG(tpgsr_act_bwd), TPGSR_REG(tpgsr_nchw_to_nhwc),
+      TPGSR_REG(tpgsr_nhwc_to_nchw), TPGSR_REG(tpgsr_reduce_partials), TPGSR_REG(tpgsr_bigru_fwd),
+      TPGSR_REG(tpgsr_bigru_bwd), TPGSR_REG(tpgsr_tps_grid_fwd), TPGSR_REG(tpgsr_tps_grid_bwd),
+      TPGSR_REG(tpgsr_grid_sample_fwd), TPGSR_REG(tpgsr_grid_sample_bwd), TPGSR_REG(tpgsr_strip_resample_fwd),
+      TPGSR_REG(tpgsr_strip_resample_bwd), TPGSR_REG(tpgsr_hsum), TPGSR_REG(tpgsr_bicubic_gray_fwd),
+      TPGSR_REG(tpgsr_bicubic_gray_bwd), TPGSR_REG(tpgsr_pool2d_fwd), TPGSR_REG(tpgsr_pool2d_bwd),
+      TPGSR_REG(tpgsr_lstm_step_fwd), TPGSR_REG(tpgsr_lstm_step_bwd), TPGSR_REG(tpgsr_softmax_prior_fwd),
+      TPGSR_REG(tpgsr_semantic_loss_finalize), TPGSR_REG(tpgsr_softmax_prior_bwd), TPGSR_REG(tpgsr_tail_shiftsum_tanh),
+      TPGSR_REG(tpgsr_tail_bwd), TPGSR_REG(tpgsr_image_loss_fwd), TPGSR_REG(tpgsr_image_loss_finalize),
+      TPGSR_REG(tpgsr_image_loss_bwd), TPGSR_REG(tpgsr_sumsq_partial), TPGSR_REG(tpgsr_clip_coef),
+      TPGSR_REG(tpgsr_adam_step), TPGSR_REG(tpgsr_step_inc), TPGSR_REG(tpgsr_scale_),
+  };
+  return r;
+}
+
+enum { OP_LAUNCH = 0, OP_FORK = 1, OP_JOIN = 2 };
+constexpr int MAX_ARGS = 24;
+
+struct Op {
+  int kind, sid, nargs;
+  thunk_fn fn;
+  const char* name;       // registry key (static storage)
+  tpgsr_plan_arg args[MAX_ARGS];
+  int blob;               // index into Plan::blobs of the copied argument struct, or -1
+  hipEvent_t ev;
+};
+
+struct Plan {
+  std::vector<Op> ops;
+  std::vector<std::unique_ptr<char[]>> blobs;
+  ~Plan() {
+    for (auto& o : ops)
+      if (o.ev) (void)hipEventDestroy(o.ev);
+  }
+};
+
+}  // namespace
+
+extern "C" void* tpgsr_plan_create(void) { return new Plan(); }
+
+extern "C" void tpgsr_plan_destroy(void* plan) { delete static_cast<Plan*>(plan); }
+
+extern "C" int tpgsr_plan_size(const void* plan) { return plan ? (int)static_cast<const Plan*>(plan)->ops.size() : -1; }
+
+extern "C" int tpgsr_plan_add_launch(void* plan, const char* symbol, const tpgsr_plan_arg* args, int nargs, int side) {
+  if (!plan || !symbol || !args) {
+    tpgsr_set_error("tpgsr_plan_add_launch: null argument");
+    return -1;
+  }
+  auto it = registry().find(symbol);
+  if (it == registry().end()) {
+    tpgsr_set_error("tpgsr_plan_add_launch: '%s' is not a launch entry point", symbol);
+    return -1;
+  }
+  const Entry& e = it->second;
+  if (nargs != e.nargs || nargs > MAX_ARGS) {
+    tpgsr_set_error("tpgsr_plan_add_launch: %s takes %d arguments before the stream, got %d", symbol, e.nargs, nargs);
+    return -1;
+  }
+  Plan* p = static_cast<Plan*>(plan);
+  Op o;
+  memset(&o, 0, sizeof(o));
+  o.kind = OP_LAUNCH;
+  o.sid = side ? 1 : 0;
+  o.nargs = nargs;
+  o.fn = e.fn;
+  o.name = it->first.c_str();
+  o.blob = -1;
+  memcpy(o.args, args, sizeof(tpgsr_plan_arg) * nargs);
+  if (e.struct_bytes > 0) {
+    if (!args[0].p) {
+      tpgsr_set_error("tpgsr_plan_add_launch: %s needs its argument struct", symbol);
+      return -1;
+    }
+    std::unique_ptr<char[]> b(new char[e.struct_bytes]);
+    memcpy(b.get(), args[0].p, e.struct_bytes);
+    o.args[0].p = b.get();
+    o.blob = (int)p->blobs.size();
+    p->blobs.push_back(std::move(b));
+  }
+  p->ops.push_back(o);
+  return (int)p->ops.size() - 1;
+}
+
+static int add_edge(void* plan, int kind) {
+  if (!plan) {
+    tpgsr_set_error("tpgsr_plan_add_fork/join: null plan");
+    return -1;
+  }
+  Plan* p = static_cast<Plan*>(plan);
+  Op o;
+  memset(&o, 0, sizeof(o));
+  o.kind = kind;
+  o.blob = -1;
+  p->ops.push_back(o);   // the event is created on first replay (recording needs no device)
+  return (int)p->ops.size() - 1;
+}
+extern "C" int tpgsr_plan_add_fork(void* plan) { return add_edge(plan, OP_FORK); }
+extern "C" int tpgsr_plan_add_join(void* plan) { return add_edge(plan, OP_JOIN); }
+
+extern "C" int tpgsr_plan_set_arg(void* plan, int op, int arg, const tpgsr_plan_arg* value) {
+  Plan* p = static_cast<Plan*>(plan);
+  if (!p || op < 0 || op >= (int)p->ops.size() || p->ops[op].kind != OP_LAUNCH || arg < 0 || arg >= p->ops[op].nargs ||
+      (arg == 0 && p->ops[op].blob >= 0) || !value) {
+    tpgsr_set_error("tpgsr_plan_set_arg: bad slot (op %d, arg %d)", op, arg);
+    return -1;
+  }
+  p->ops[op].args[arg] = *value;
+  return 0;
+}
+
+extern "C" int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream) {
+  Plan* p = static_cast<Plan*>(plan);
+  if (!p) {
+    tpgsr_set_error("tpgsr_plan_run: null plan");
+    return -1;
+  }
+  hipStream_t s[2] = {(hipStream_t)main_stream, (hipStream_t)side_stream};
+  const int n = (int)p->ops.size();
+  for (int i = 0; i < n; ++i) {
+    Op& o = p->ops[i];
+    if (o.kind == OP_LAUNCH) {
+      int rc = o.fn(o.args, s[o.sid]);
+      if (rc) return rc;   // the entry point has set the message
+    } else {
+      if (s[1] == s[0] || !s[1]) {
+        tpgsr_set_error("tpgsr_plan_run: the plan has side-stream sections but no distinct side stream was given");
+        return -1;
+      }
+      if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) {
+        tpgsr_set_error("tpgsr_plan_run: hipEventCreateWithFlags failed");
+        return -2;
+      }
+      hipStream_t from = o.kind == OP_FORK ? s[0] : s[1], to = o.kind == OP_FORK ? s[1] : s[0];
+      if (hipEventRecord(o.ev, from) != hipSuccess || hipStreamWaitEvent(to, o.ev, 0) != hipSuccess) {
+        tpgsr_set_error("tpgsr_plan_run: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
+        return -2;
+      }
+    }
+  }
+  return 0;
+}

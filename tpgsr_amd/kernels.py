@@ -44,6 +44,8 @@ class Plan:
         self.dyn = {}      # key -> [(op index, arg index)]
         self.sid = 0       # stream the next recorded launch goes to: 0 = the caller's stream, 1 = side stream
         self.forks = 0
+        self._native = None  # tpgsr_plan handle, built on first run()
+        self._has_side = False
 
     def mark_dynamic(self, key):
         """The NEXT recorded pointer argument equal to the DynPtr placeholder `key` becomes patchable."""
@@ -52,6 +54,10 @@ class Plan:
     def set_ptr(self, key, ptr):
         for oi, ai in self.dyn[key]:
             self.ops[oi][2][ai] = ptr
+            if self._native:
+                v = _lib.PlanArg()
+                v.p = ptr
+                check(_lib.load().tpgsr_plan_set_arg(self._native, oi, ai, C.byref(v)), "tpgsr_plan_set_arg")
 
     def side(self):
         """``with plan.side():`` -- the launches recorded inside go to the side stream, ordered after everything
@@ -68,7 +74,47 @@ class Plan:
             self.ops.append(["join", None, None, 0])
             self.forks = 0
 
+    def _build_native(self):
+        """Hand the recorded launches to the C-ABI plan executor (csrc/plan.cpp): replay = ONE foreign call."""
+        lib = _lib.load()
+        h = lib.tpgsr_plan_create()
+        try:
+            for name, fn, args, sid in self.ops:
+                if fn is None:
+                    rc = lib.tpgsr_plan_add_fork(h) if name == "fork" else lib.tpgsr_plan_add_join(h)
+                else:
+                    types = fn.argtypes[:-1]          # the trailing stream is supplied at run time
+                    arr = (_lib.PlanArg * max(1, len(types)))()
+                    for i, (t, a) in enumerate(zip(types, args)):
+                        if t is _lib.cf:
+                            arr[i].f = float(a)
+                        elif t is _lib.vp:
+                            arr[i].p = a
+                        elif t in (_lib.ci, _lib.ll):
+                            arr[i].i = int(a)
+                        else:                          # POINTER(struct): recorded as ctypes.byref(struct)
+                            arr[i].p = C.addressof(a._obj)
+                    rc = lib.tpgsr_plan_add_launch(h, name.encode(), arr, len(types), sid)
+                if rc < 0:
+                    check(rc, f"{self.name}: native plan, op {name}")
+        except Exception:
+            lib.tpgsr_plan_destroy(h)
+            raise
+        assert lib.tpgsr_plan_size(h) == len(self.ops)
+        self._native = h
+        self._has_side = any(fn is None for _, fn, _, _ in self.ops)
+
     def run(self):
+        if not self._native:
+            self._build_native()
+        main = torch.cuda.current_stream()
+        side = side_stream(main.device).cuda_stream if self._has_side else None
+        rc = _lib.load().tpgsr_plan_run(self._native, main.cuda_stream, side)
+        if rc:
+            check(rc, self.name)
+
+    def run_interpreted(self):
+        """The same replay op by op through ctypes (reference implementation of run(); tests compare the two)."""
         main = torch.cuda.current_stream()
         streams = (main.cuda_stream, None)
         side = None
@@ -85,6 +131,14 @@ class Plan:
             rc = fn(*args, streams[sid])
             if rc:
                 check(rc, f"{self.name}:{name}")
+
+    def __del__(self):
+        h, self._native = getattr(self, "_native", None), None
+        if h:
+            try:
+                _lib.load().tpgsr_plan_destroy(h)
+            except Exception:
+                pass
 
     def __len__(self):
         return len(self.ops)
