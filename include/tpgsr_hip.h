@@ -191,14 +191,14 @@ int tpgsr_reduce_partials(const float* part, int Z, int n, float* out, int accum
  * axis 1: along H (one per (n,col)) -- the `.transpose(-1,-2)` of model/tsrn.py:391 without a copy.
  * ---------------------------------------------------------------------------------------------- */
 int tpgsr_bigru_fwd(const float* gi, const float* w_hh /* [2][96][32] */, const float* b_hh /* [2][96] */,
-                    int N, int H, int W, int axis, float* h_out, void* stream);
-/* Backward through time.  Recomputes the gates from gi and h_out; dh = dh_out (+ dh_out2 if non-NULL).
- * Writes dgi [P][192] = (dr, dz, dn) pre-activation gradients of the input side (must NOT alias gi) and
+                    int N, int H, int W, int axis, float* h_out, float* gates /* [P][256] or NULL */, void* stream);
+/* Backward through time from the gate values the forward pass stored: gates [P][256], column = dir*128 + q*32 + j,
+ * q = (r, z, n, W_hn h + b_hn) -- pass gates = NULL to tpgsr_bigru_fwd at inference.  dh = dh_out (+ dh_out2 if
+ * non-NULL).  Writes dgi [P][192] = (dr, dz, dn) pre-activation gradients of the input side and
  * dgh [P][192] = (dr, dz, dn*r) of the hidden side, from which dW_ih/db_ih/d(input) and dW_hh/db_hh follow
  * as plain GEMMs / column sums (tpgsr_conv_wgrad against the input resp. the one-step-shifted states). */
-int tpgsr_bigru_bwd(const float* gi, const float* h_out, const float* dh_out, const float* dh_out2,
-                    const float* w_hh, const float* b_hh, int N, int H, int W, int axis, float* dgi, float* dgh,
-                    void* stream);
+int tpgsr_bigru_bwd(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
+                    const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dgh, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * STN / TPS rectification -- model/tps_spatial_transformer.py:97-112, grid_sample :10-18

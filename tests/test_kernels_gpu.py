@@ -387,11 +387,15 @@ def test_bigru_fwd_bwd(axis, N, H, W):
     h_out = torch.full((Pn, 64), float("nan"), device=DEV)
     whd, bhd = w_hh.to(DEV).contiguous(), b_hh.to(DEV).contiguous()
     dhd, dh2d = dh.reshape(Pn, 64).to(DEV), dh2.reshape(Pn, 64).to(DEV)
-    k.bigru_fwd(gi, whd, bhd, N, H, W, axis, h_out)
+    gates = torch.full((Pn, 256), float("nan"), device=DEV)
+    h_inf = torch.empty(Pn, 64, device=DEV)
+    k.bigru_fwd(gi, whd, bhd, N, H, W, axis, h_inf)                 # inference form: no gate store
+    k.bigru_fwd(gi, whd, bhd, N, H, W, axis, h_out, gates)
     torch.cuda.synchronize()
+    assert torch.equal(h_inf, h_out) and not torch.isnan(gates).any()
     assert (h_out.cpu().double() - y.detach().reshape(Pn, 64)).abs().max() < 2e-6
     dgi = torch.full((Pn, 192), float("nan"), device=DEV); dgh = torch.full((Pn, 192), float("nan"), device=DEV)
-    k.bigru_bwd(gi, h_out, dhd, dh2d, whd, bhd, N, H, W, axis, dgi, dgh)
+    k.bigru_bwd(gates, h_out, dhd, dh2d, whd, N, H, W, axis, dgi, dgh)
     torch.cuda.synchronize()
     dgi_c, dgh_c = dgi.cpu().double(), dgh.cpu().double()
     # input-side grads follow from dgi

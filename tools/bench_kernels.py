@@ -59,12 +59,13 @@ def gru_case(axis):
     whh = torch.randn(2, 96, 32, device=DEV) * 0.1
     bhh = torch.randn(2, 96, device=DEV) * 0.1
     h = torch.empty(P, 64, device=DEV)
-    us = timeit(lambda: K.bigru_fwd(gi, whh, bhh, N, H, W, axis, h))
+    gates = torch.empty(P, 256, device=DEV)
+    us = timeit(lambda: K.bigru_fwd(gi, whh, bhh, N, H, W, axis, h, gates))
     print(f"bigru_fwd axis={axis}  {us:8.1f} us")
     dh = torch.randn(P, 64, device=DEV)
     dgi = torch.empty(P, 192, device=DEV)
     dgh = torch.empty(P, 192, device=DEV)
-    us = timeit(lambda: K.bigru_bwd(gi, h, dh, None, whh, bhh, N, H, W, axis, dgi, dgh))
+    us = timeit(lambda: K.bigru_bwd(gates, h, dh, None, whh, N, H, W, axis, dgi, dgh))
     print(f"bigru_bwd axis={axis}  {us:8.1f} us")
 
 

@@ -82,8 +82,8 @@ _SIGS = {
     "tpgsr_nchw_to_nhwc": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "tpgsr_nhwc_to_nchw": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "tpgsr_reduce_partials": (ci, [vp, ci, ci, vp, ci, vp]),
-    "tpgsr_bigru_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
-    "tpgsr_bigru_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_bigru_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_bigru_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     "tpgsr_tps_grid_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "tpgsr_tps_grid_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "tpgsr_grid_sample_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),

@@ -231,17 +231,17 @@ class GruLayer:
             eng.add_pack(P[gp + "weight_hh_l0" + suf], self.whh[d], None, kind=2)
             eng.add_pack(P[gp + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
 
-    def fwd(self, N, H, W, x, u, gi, h, **loader):
-        """u = conv1x1(loader(x)); gi = u W_ih^T + b_ih; h = BiGRU(gi)"""
+    def fwd(self, N, H, W, x, u, gi, h, gates=None, **loader):
+        """u = conv1x1(loader(x)); gi = u W_ih^T + b_ih; h = BiGRU(gi) (gates: saved for bwd in training plans)"""
         self.conv.fwd(N, H, W, x, u, **loader)
         g = ConvGeom(N, H, W, self.Cg, 192)
         K.conv_fwd(K.make_conv_args(g, u, self.wih_f, gi, bias=self.bih))
-        K.bigru_fwd(gi, self.whh, self.bhh, N, H, W, self.axis, h)
+        K.bigru_fwd(gi, self.whh, self.bhh, N, H, W, self.axis, h, gates)
 
-    def bwd(self, N, H, W, x, u, gi, h, dh, dh2, dgi, dgh, du, dx, **loader):
+    def bwd(self, N, H, W, x, u, gates, h, dh, dh2, dgi, dgh, du, dx, **loader):
         """all parameter gradients of the block + dx = dL/d loader(x)"""
         eng, G, gp = self.eng, self.eng.G, self.gp
-        K.bigru_bwd(gi, h, dh, dh2, self.whh, self.bhh, N, H, W, self.axis, dgi, dgh)
+        K.bigru_bwd(gates, h, dh, dh2, self.whh, N, H, W, self.axis, dgi, dgh)
         with K.side():
             for d, suf in enumerate(("", "_reverse")):
                 sgn = 1 if d == 0 else -1
@@ -499,6 +499,8 @@ class TSRNEngine(_EngineBase):
             y1, y2 = ws(t + "y1", P1, Cc), ws(t + "y2", P1, Cc)
             u1, gi1, h1 = ws(t + "u1", P1, Cc), ws(t + "gi1", P1, 192), ws(t + "h1", P1, Cc)
             u2, gi2, out = ws(t + "u2", P1, Cc), ws(t + "gi2", P1, 192), ws(t + "out", P1, Cc)
+            gt1 = ws(t + "gt1", P1, 256) if training else None      # GRU gate values, kept for back-propagation
+            gt2 = ws(t + "gt2", P1, 256) if training else None
             part, _ = L["bn1"].partial(P1)
             L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None)
             L["bn1"].finalize(P1, L["conv1"].b, training)
@@ -507,10 +509,10 @@ class TSRNEngine(_EngineBase):
             L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None)
             L["bn2"].finalize(P1, L["conv2"].b, training)
             if self.tl:   # torch.cat([bn2(y2), text strip], 1) inside the 1x1 conv's loader (model/tsrn.py:419-423)
-                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
+                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, gt1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
             else:
-                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, **L["bn2"].loader)
-            L["gru2"].fwd(N, H, W, cur, u2, gi2, out, in2=h1)
+                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, gt1, **L["bn2"].loader)
+            L["gru2"].fwd(N, H, W, cur, u2, gi2, out, gt2, in2=h1)
             cur = out
         y7 = ws("y7", P1, Cc)
         part, _ = self.bn7.partial(P1)
@@ -642,21 +644,21 @@ class TSRNEngine(_EngineBase):
             p = f"r{i}_"
             dgi, dgh, du = buf("dgi", p + "g2_", 192), buf("dgh", p + "g2_", 192), buf("du", p + "g2_", Cc)
             X = t[f"r{i - 1}_out"] if i > 0 else t["b1"]
-            y1, y2, u1, gi1, h1, u2, gi2, out = (t[p + n] for n in ("y1", "y2", "u1", "gi1", "h1", "u2", "gi2", "out"))
+            y1, y2, u1, gt1, h1, u2, gt2, out = (t[p + n] for n in ("y1", "y2", "u1", "gt1", "h1", "u2", "gt2", "out"))
             # gru2 (input X + h1): parameter grads + d(X + h1) -> gA (incoming gA/gB are dead after the scan)
-            L["gru2"].bwd(N, H, W, X, u2, gi2, out, gA, gB if have_B else None, dgi, dgh, du, gA, in2=h1)
+            L["gru2"].bwd(N, H, W, X, u2, gt2, out, gA, gB if have_B else None, dgi, dgh, du, gA, in2=h1)
             # gru1 (input bn2(y2) [+ text strip]): dh = gA
             dgi, dgh, du = buf("dgi", p + "g1_", 192), buf("dgh", p + "g1_", 192), buf("du", p + "g1_", Cc)
             if self.tl:
                 g1 = L["gru1"]
-                g1.bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
+                g1.bwd(N, H, W, y2, u1, gt1, h1, gA, None, dgi, dgh, du, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
                 # data gradient of the 96->64 1x1 conv in two column blocks: image features and text strip
                 K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, Cc, Cc), du, g1.conv.wt_d, da, wt_ld=g1.conv.Cin, wt_coff=0))
                 dtb = ws("d_tb", P1, self.Ct)
                 K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, Cc, self.Ct), du, g1.conv.wt_d, dtb, wt_ld=g1.conv.Cin, wt_coff=Cc))
                 K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
-                L["gru1"].bwd(N, H, W, y2, u1, gi1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
+                L["gru1"].bwd(N, H, W, y2, u1, gt1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
             dy = buf("dy", p + "c2_", Cc)
             L["bn2"].backward(da, None, y2, P1, "none", dy)
             L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)

@@ -403,13 +403,13 @@ def reduce_partials(part, Z, n, out, accumulate=True):
 
 
 # ---- GRU ------------------------------------------------------------------------------------------------------
-def bigru_fwd(gi, w_hh, b_hh, N, H, W, axis, h_out):
-    _launch("tpgsr_bigru_fwd", _p(gi), _p(w_hh), _p(b_hh), N, H, W, axis, _p(h_out))
+def bigru_fwd(gi, w_hh, b_hh, N, H, W, axis, h_out, gates=None):
+    """gates [P][256]: (r, z, n, W_hn h + b_hn) per direction, stored for bigru_bwd (None at inference)"""
+    _launch("tpgsr_bigru_fwd", _p(gi), _p(w_hh), _p(b_hh), N, H, W, axis, _p(h_out), _p(gates))
 
 
-def bigru_bwd(gi, h_out, dh_out, dh_out2, w_hh, b_hh, N, H, W, axis, dgi, dgh):
-    _launch("tpgsr_bigru_bwd", _p(gi), _p(h_out), _p(dh_out), _p(dh_out2), _p(w_hh), _p(b_hh), N, H, W, axis, _p(dgi),
-                                      _p(dgh))
+def bigru_bwd(gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh):
+    _launch("tpgsr_bigru_bwd", _p(gates), _p(h_out), _p(dh_out), _p(dh_out2), _p(w_hh), N, H, W, axis, _p(dgi), _p(dgh))
 
 
 # ---- STN ------------------------------------------------------------------------------------------------------
