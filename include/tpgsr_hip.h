@@ -32,7 +32,7 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
-/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc): a binding can verify its mirror */
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc): a binding can verify its mirror */
 int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -102,6 +102,22 @@ int tpgsr_conv_wgrad(const tpgsr_wgrad_args* a, void* stream);
 int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
                        int layout, float* dw, float* db, int accumulate, float gscale /* multiplies dw only */,
                        void* stream);
+
+/* The same reduce for MANY layers in one launch: a device-resident table of descriptors (fields as the parameters of
+ * tpgsr_wgrad_reduce; blk0 = first workgroup of the descriptor, consecutive descriptors own consecutive ranges of
+ * tpgsr_wgrad_reduce_blocks(K, Cout, has_bias) workgroups; total_blocks = their sum).  Descriptors of one program must
+ * target distinct dw / db. */
+typedef struct tpgsr_wgrad_reduce_desc {
+  const float* part;
+  const float* dbpart;
+  float* dw;
+  float* db;
+  int Z, K, Cin, Cout, KH, KW, layout, accumulate;
+  float gscale;
+  int blk0;
+} tpgsr_wgrad_reduce_desc;
+int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias);
+int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 
 /* Pack a PyTorch conv weight [Cout][Cin][KH][KW] into the forward operand wt_f[(kh*KW+kw)*Cin+ci][co] and the
  * data-gradient operand wt_d[((KH-1-kh)*KW+(KW-1-kw))*Cout+co][ci] (dgrad == tpgsr_conv_fwd over dy with wt_d
@@ -316,6 +332,10 @@ int tpgsr_plan_add_fork(void* plan);
 int tpgsr_plan_add_join(void* plan);
 int tpgsr_plan_set_arg(void* plan, int op, int arg, const tpgsr_plan_arg* value);   /* patch a per-step pointer / scalar */
 int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream);
+/* A HIP stream for the side-stream role, optionally confined to the compute units whose bits are set in cu_mask
+ * (n_words 32-bit words, bit i of word w = CU 32*w + i; NULL / 0 = all CUs).  Returns NULL on failure. */
+void* tpgsr_stream_create(const unsigned int* cu_mask, int n_words);
+int tpgsr_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -152,8 +152,9 @@ def test_native_plan_two_streams_bitwise_equal_to_interpreted_single_stream(gold
         with monkeypatch.context() as m:
             if mode == "interpreted":
                 m.setattr(K.Plan, "run", K.Plan.run_interpreted)
-            if mode == "single":
+            if mode == "single":      # one stream, every slab reduce right behind its weight-gradient GEMM
                 m.setenv("TPGSR_OVERLAP_WGRAD", "0")
+                m.setenv("TPGSR_DEFER_REDUCE", "0")
             net, _ = _build(stn=True, seed=201)
             net.train()
             ts = TSRNTrainStep(net)
@@ -166,7 +167,7 @@ def test_native_plan_two_streams_bitwise_equal_to_interpreted_single_stream(gold
     la, pa, sa = run("native")
     lb, pb, sb = run("interpreted")
     lc, pc, sc = run("single")
-    assert sa > 50 and sb == sa and sc == 0
+    assert 50 < sa < 100 and sb == sa and sc == 0      # side stream: the weight-gradient GEMMs + ONE batched reduce
     assert la == lb == lc
     assert torch.equal(pa, pb) and torch.equal(pa, pc)
 

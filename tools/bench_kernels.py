@@ -69,6 +69,31 @@ def gru_case(axis):
     print(f"bigru_bwd axis={axis}  {us:8.1f} us")
 
 
+def bn_case():
+    P, Cc = N * H * W, 64
+    nblk = (P + 63) // 64
+    part = torch.randn(nblk, 2, Cc, device=DEV).abs()
+    gamma, beta = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV)
+    rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    scale, shift, mean, rstd = (torch.empty(Cc, device=DEV) for _ in range(4))
+    us = timeit(lambda: K.bn_finalize(part, nblk, Cc, P, None, gamma, beta, rm, rv, scale, shift, mean, rstd))
+    print(f"bn_finalize C=64 nblk={nblk}  {us:8.1f} us")
+    y, da, dy = torch.randn(P, Cc, device=DEV), torch.randn(P, Cc, device=DEV), torch.empty(P, Cc, device=DEV)
+    nb = min(1024, P // 64)
+    bp = torch.empty(nb, 2, Cc, device=DEV)
+    coef = torch.empty(3, Cc, device=DEV)
+    dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    us = timeit(lambda: K.bn_bwd_reduce(da, None, y, P, Cc, scale, shift, mean, rstd, "mish", bp, nb))
+    print(f"bn_bwd_reduce (mish)  {us:8.1f} us")
+    us = timeit(lambda: K.bn_bwd_finalize(bp, nb, Cc, P, gamma, mean, rstd, dg, db, coef))
+    print(f"bn_bwd_finalize       {us:8.1f} us")
+    us = timeit(lambda: K.bn_bwd_apply(da, None, y, P, Cc, scale, shift, "mish", coef, dy))
+    print(f"bn_bwd_apply (mish)   {us:8.1f} us")
+    a1 = torch.empty(P, Cc, device=DEV)
+    us = timeit(lambda: K.affine_act(y, P, Cc, scale, shift, "mish", a1))
+    print(f"affine_act (mish)     {us:8.1f} us")
+
+
 def mfma_probe():
     out = torch.zeros(4, device=DEV)
     for blocks in (1024, 2048, 4096):
@@ -91,3 +116,4 @@ if __name__ == "__main__":
     conv_case("9x9 4->64 (block1)", H, W, 4, 64, 9, 9, 4, 4)
     gru_case(0)
     gru_case(1)
+    bn_case()

@@ -41,6 +41,11 @@ class PackDesc(C.Structure):
                 ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci)]
 
 
+class WgradReduceDesc(C.Structure):
+    _fields_ = [("part", vp), ("dbpart", vp), ("dw", vp), ("db", vp), ("Z", ci), ("K", ci), ("Cin", ci), ("Cout", ci),
+                ("KH", ci), ("KW", ci), ("layout", ci), ("accumulate", ci), ("gscale", cf), ("blk0", ci)]
+
+
 class PlanArg(C.Union):
     """tpgsr_plan_arg: one launch argument of a native plan (pointer / integer / float)"""
     _fields_ = [("p", vp), ("i", ll), ("f", C.c_double)]
@@ -55,6 +60,8 @@ _SIGS = {
     "tpgsr_plan_add_join": (ci, [vp]),
     "tpgsr_plan_set_arg": (ci, [vp, ci, ci, C.POINTER(PlanArg)]),
     "tpgsr_plan_run": (ci, [vp, vp, vp]),
+    "tpgsr_stream_create": (vp, [C.POINTER(C.c_uint), ci]),
+    "tpgsr_stream_destroy": (ci, [vp]),
     "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_mfma_probe": (ci, [vp, ci, ci, vp]),
     "tpgsr_copy": (ci, [vp, vp, ll, vp]),
@@ -65,6 +72,8 @@ _SIGS = {
     "tpgsr_wgrad_splits": (ci, [ci, ci, ci]),
     "tpgsr_conv_wgrad": (ci, [C.POINTER(WgradArgs), vp]),
     "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
+    "tpgsr_wgrad_reduce_blocks": (ci, [ci, ci, ci]),
+    "tpgsr_wgrad_reduce_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_pack_conv_weight": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp]),
     "tpgsr_pack_tail_weight": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "tpgsr_bn_finalize": (ci, [vp, ci, ci, ll, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp]),
@@ -138,7 +147,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

@@ -685,15 +685,15 @@ __device__ __forceinline__ size_t wgrad_out_index(int k, int co, int Cin, int Co
   return (((size_t)tco * Cin + ci) * KH + kh) * KH + tkw;
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
-                                                           int Z, int K, int Cin, int Cout, int KH, int KW, int layout,
-                                                           float* dw, float* db, int accumulate, float gscale) {
-  __shared__ float red[8][33];
+__device__ __forceinline__ void wgrad_reduce_body(float (*red)[33], const float* __restrict__ part,
+                                                  const float* __restrict__ dbpart, int Z, int K, int Cin, int Cout, int KH,
+                                                  int KW, int layout, float* dw, float* db, int accumulate, float gscale,
+                                                  unsigned blk) {
   const int tx = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const size_t total = (size_t)K * Cout;
   const size_t ndb = (db && dbpart) ? (size_t)Cout : 0;
   // logical index space: [0, total) = weight entries, [total, total + ndb) = bias entries
-  size_t idx = (size_t)blockIdx.x * 32 + tx;
+  size_t idx = (size_t)blk * 32 + tx;
   const bool is_w = idx < total;
   const bool is_b = !is_w && idx < total + ndb;
   const float* src = is_w ? part + idx : dbpart + (idx - total);
@@ -725,6 +725,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       db[o] = accumulate ? db[o] + s : s;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                           int Z, int K, int Cin, int Cout, int KH, int KW, int layout,
+                                                           float* dw, float* db, int accumulate, float gscale) {
+  __shared__ float red[8][33];
+  wgrad_reduce_body(red, part, dbpart, Z, K, Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale, blockIdx.x);
+}
+
+// every slab reduce of a backward pass in ONE launch (device-resident descriptor table, like pack_program): the
+// per-layer reduces were ~70 launches of ~9 us each on the weight-gradient stream
+__global__ __launch_bounds__(256) void wgrad_reduce_program_kernel(const tpgsr_wgrad_reduce_desc* __restrict__ descs, int ndesc) {
+  __shared__ float red[8][33];
+  __shared__ int s_d;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = ndesc - 1;  // last descriptor whose blk0 <= blockIdx.x
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    s_d = lo;
+  }
+  __syncthreads();
+  const tpgsr_wgrad_reduce_desc d = descs[s_d];
+  wgrad_reduce_body(red, d.part, d.dbpart, d.Z, d.K, d.Cin, d.Cout, d.KH, d.KW, d.layout, d.dw, d.db, d.accumulate, d.gscale,
+                    blockIdx.x - (unsigned)d.blk0);
+}
+
+extern "C" int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias) {
+  return cdiv((size_t)K * Cout + (has_bias ? Cout : 0), 32);
+}
+
+extern "C" int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_dev, int ndesc, int total_blocks, void* stream) {
+  TPGSR_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0, "tpgsr_wgrad_reduce_program: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_program_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc);
+  TPGSR_LAUNCH_CHECK("tpgsr_wgrad_reduce_program");
 }
 
 extern "C" int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,

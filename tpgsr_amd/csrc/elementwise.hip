@@ -31,18 +31,36 @@ extern "C" int tpgsr_bn_stats(const float* x, long long M, int C, int ld, float*
   TPGSR_LAUNCH_CHECK("tpgsr_bn_stats");
 }
 
-// one block of 256 threads per 32 channels; 8 row-slices per channel, fp64 combine
+// per-channel sum of the two partial rows [nblk][2][C] in fp64: one workgroup per channel, 256 row lanes (every lane issues
+// its <= nblk/256 loads back to back), wave shuffle + 4-entry LDS combine in a fixed order.  (16 channels x 16 row
+// slices per workgroup = 4 workgroups for C = 64 took 12-16 us: each thread walked 48 partial rows serially.)
+__device__ __forceinline__ void channel_sums(const float* __restrict__ partial, int nblk, int C, int c, double& s, double& ss) {
+  __shared__ double red[2][4];
+  double a = 0.0, b2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    a += (double)partial[((size_t)b * 2 + 0) * C + c];
+    b2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  a = wave_sum_d(a);
+  b2 = wave_sum_d(b2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b2;
+  }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                           long long count, const float* conv_bias,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum,
                                                           float eps, int eval, float* scale, float* shift,
                                                           float* save_mean, float* save_rstd) {
-  __shared__ double red[2][16][16];
-  int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  int c = blockIdx.x * 16 + cl;
+  const int c = blockIdx.x;
   if (eval) {
-    if (sl == 0 && c < C) {
+    if (threadIdx.x == 0) {
       float rstd = 1.f / sqrtf(running_var[c] + eps);
       float sc = gamma[c] * rstd;
       scale[c] = sc;
@@ -50,20 +68,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     return;
   }
-  double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int b = sl; b < nblk; b += 16) {
-      s += (double)partial[((size_t)b * 2 + 0) * C + c];
-      ss += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = ss;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int i = 1; i < 16; ++i) {
-      s += red[0][i][cl];
-      ss += red[1][i][cl];
-    }
+  double s, ss;
+  channel_sums(partial, nblk, C, c, s, ss);
+  if (threadIdx.x == 0) {
     double mean_raw = s / (double)count;
     double var = ss / (double)count - mean_raw * mean_raw;
     if (var < 0.0) var = 0.0;
@@ -89,7 +96,7 @@ extern "C" int tpgsr_bn_finalize(const float* partial, int nblk, int C, long lon
   TPGSR_CHECK_ARG(gamma && beta && scale && shift && C > 0, "tpgsr_bn_finalize: null pointer");
   TPGSR_CHECK_ARG(eval || (partial && nblk > 0 && count > 0), "tpgsr_bn_finalize: training mode needs partial statistics");
   TPGSR_CHECK_ARG(!eval || (running_mean && running_var), "tpgsr_bn_finalize: eval mode needs running statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
                      conv_bias, gamma, beta, running_mean, running_var, momentum, eps, eval, scale, shift, save_mean,
                      save_rstd);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_finalize");
@@ -166,23 +173,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_rstd, float* dgamma,
                                                               float* dbeta, int accumulate, float* coef) {
-  __shared__ double red[2][16][16];
-  int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  int c = blockIdx.x * 16 + cl;
-  double s = 0.0, sx = 0.0;
-  if (c < C)
-    for (int b = sl; b < nblk; b += 16) {
-      s += (double)partial[((size_t)b * 2 + 0) * C + c];
-      sx += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = sx;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int i = 1; i < 16; ++i) {
-      s += red[0][i][cl];
-      sx += red[1][i][cl];
-    }
+  const int c = blockIdx.x;
+  double s, sx;
+  channel_sums(partial, nblk, C, c, s, sx);
+  if (threadIdx.x == 0) {
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sx : (float)sx;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
     double rstd = save_rstd[c], mu = save_mean[c], g = gamma[c];
@@ -198,7 +192,7 @@ extern "C" int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long
                                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                      int accumulate, float* coef, void* stream) {
   TPGSR_CHECK_ARG(partial && gamma && save_mean && save_rstd && coef && nblk > 0 && count > 0, "tpgsr_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, count,
                      gamma, save_mean, save_rstd, dgamma, dbeta, accumulate, coef);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_finalize");
 }

@@ -21,6 +21,7 @@ extern "C" int tpgsr_sizeof(int which) {
     case 0: return (int)sizeof(tpgsr_conv_args);
     case 1: return (int)sizeof(tpgsr_wgrad_args);
     case 2: return (int)sizeof(tpgsr_pack_desc);
+    case 3: return (int)sizeof(tpgsr_wgrad_reduce_desc);
     default: return -1;
   }
 }

@@ -58,7 +58,7 @@ struct Entry {
 const std::unordered_map<std::string, Entry>& registry() {
   static const std::unordered_map<std::string, Entry> r = {
       TPGSR_REG_S(tpgsr_conv_fwd, tpgsr_conv_args), TPGSR_REG_S(tpgsr_conv_wgrad, tpgsr_wgrad_args),
-      TPGSR_REG(tpgsr_wgrad_reduce), TPGSR_REG(tpgsr_pack_conv_weight), TPGSR_REG(tpgsr_pack_tail_weight),
+      TPGSR_REG(tpgsr_wgrad_reduce), TPGSR_REG(tpgsr_wgrad_reduce_program), TPGSR_REG(tpgsr_pack_conv_weight), TPGSR_REG(tpgsr_pack_tail_weight),
       TPGSR_REG(tpgsr_pack_program), TPGSR_REG(tpgsr_mfma_probe), TPGSR_REG(tpgsr_copy), TPGSR_REG(tpgsr_zero),
       TPGSR_REG(tpgsr_bn_finalize), TPGSR_REG(tpgsr_bn_stats), TPGSR_REG(tpgsr_bn_bwd_reduce),
       TPGSR_REG(tpgsr_bn_bwd_finalize), TPGSR_REG(tpgsr_bn_bwd_apply), TPGSR_REG(tpgsr_affine_act),
@@ -202,6 +202,28 @@ extern "C" int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream) 
         return -2;
       }
     }
+  }
+  return 0;
+}
+
+// ---- side stream with a compute-unit mask -----------------------------------------------------------------------------
+// The weight-gradient stream may be confined to a subset of the CUs so that its MFMA-heavy workgroups do not sit on the
+// SIMDs the latency-bound critical path (BiGRU BPTT, BN reductions, data-gradient convs) runs on.
+extern "C" void* tpgsr_stream_create(const unsigned int* cu_mask, int n_words) {
+  hipStream_t st = nullptr;
+  hipError_t e = (cu_mask && n_words > 0) ? hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask)
+                                          : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    tpgsr_set_error("tpgsr_stream_create: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  return st;
+}
+
+extern "C" int tpgsr_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    tpgsr_set_error("tpgsr_stream_destroy failed");
+    return -2;
   }
   return 0;
 }

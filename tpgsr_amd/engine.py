@@ -145,9 +145,8 @@ class ConvLayer:
         eng = self.eng
         g = self.geom(N, H, W)
         Z = K.wgrad_splits(g.M, g.K, g.Cout)
-        part = eng.scratch("wgrad_part", Z * g.K * g.Cout)
         has_b = self.b is not None and not self.tail
-        dbp = eng.scratch("wgrad_dbpart", Z * g.Cout) if has_b else None
+        part, dbp = eng.wgrad_buffers(Z * g.K * g.Cout, Z * g.Cout if has_b else 0)
         ca = K.make_conv_args(g, x, **(loader or {}))
         with K.side():
             K.conv_wgrad(K.make_wgrad_args(ca, dy, part, dbp, **(dy_kw or {})))
@@ -248,16 +247,14 @@ class GruLayer:
                 # hidden side: dW_hh[d] = dgh[:, d]^T h_prev(d), h_prev = h shifted one step against the scan direction
                 gh = ConvGeom(N, H, W, 32, 96, 1, 1, sgn if self.axis == 1 else 0, sgn if self.axis == 0 else 0, H, W)
                 Z = K.wgrad_splits(gh.M, gh.K, 96)
-                part = eng.scratch("wgrad_part", Z * 32 * 96)
-                dbp = eng.scratch("wgrad_dbpart", Z * 96)
+                part, dbp = eng.wgrad_buffers(Z * 32 * 96, Z * 96)
                 ca = K.make_conv_args(gh, h, in_ld=64, in_coff=32 * d)
                 K.conv_wgrad(K.make_wgrad_args(ca, dgh, part, dbp, dy_ld=192, dy_coff=96 * d))
                 K.wgrad_reduce(part, dbp, Z, gh, G[gp + "weight_hh_l0" + suf], G[gp + "bias_hh_l0" + suf], accumulate=True)
                 # input side: dW_ih[d] = dgi[:, d]^T u, db_ih[d] = colsum
                 gi_ = ConvGeom(N, H, W, self.Cg, 96)
                 Z = K.wgrad_splits(gi_.M, gi_.K, 96)
-                part = eng.scratch("wgrad_part", Z * self.Cg * 96)
-                dbp = eng.scratch("wgrad_dbpart", Z * 96)
+                part, dbp = eng.wgrad_buffers(Z * self.Cg * 96, Z * 96)
                 ca = K.make_conv_args(gi_, u)
                 K.conv_wgrad(K.make_wgrad_args(ca, dgi, part, dbp, dy_ld=192, dy_coff=96 * d))
                 K.wgrad_reduce(part, dbp, Z, gi_, G[gp + "weight_ih_l0" + suf], G[gp + "bias_ih_l0" + suf], accumulate=True)
@@ -299,7 +296,7 @@ class TConvStrip:
     def wgrad(self, N, Win, x, dy, loader=None):
         eng, g = self.eng, self.geom(N, Win)
         Z = K.wgrad_splits(g.M, g.K, g.Cout)
-        part = eng.scratch("wgrad_part", Z * g.K * g.Cout)
+        part, _ = eng.wgrad_buffers(Z * g.K * g.Cout)
         ca = K.make_conv_args(g, x, in_dil_w=self.sw, **(loader or {}))
         with K.side():
             K.conv_wgrad(K.make_wgrad_args(ca, dy, part, None))
@@ -326,6 +323,7 @@ class _EngineBase:
         self._pack: List[tuple] = []
         self._bn_layers: List["BNLayer"] = []
         self._pending_batches = 0
+        self._wg_idx, self._cur_ws = 0, None
 
     # ---- scratch buffers live only between consecutive launches (stream-ordered reuse) ----------------------
     def scratch(self, name, numel):
@@ -336,6 +334,16 @@ class _EngineBase:
             t = torch.empty(max(int(numel), 1), dtype=F32, device=self.device)
             self._scratch[name] = t
         return t
+
+    def wgrad_buffers(self, n_part, n_db=0):
+        """Slab buffers of one weight-gradient launch: stream-ordered scratch when its reduce follows immediately, the
+        layer's own workspace when the plan batches all reduces into one launch at the end (K.flush_wgrad_reduces)."""
+        if K.deferring():
+            i = self._wg_idx
+            self._wg_idx += 1
+            ws = self._cur_ws
+            return ws(f"wgp{i}", n_part), (ws(f"wgb{i}", n_db) if n_db else None)
+        return self.scratch("wgrad_part", n_part), (self.scratch("wgrad_dbpart", n_db) if n_db else None)
 
     def add_pack(self, src, dst_f, dst_d, Cout=0, Cin=0, KH=1, KW=1, kind=0, f_ld=0, f_coff=0, wscale=1.0):
         self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale))
@@ -409,6 +417,8 @@ class TSRNEngine(_EngineBase):
         # weight-gradient launches on a second stream (Plan.side).  Needs every buffer a wgrad reads to be written once
         # per backward pass: _record_bwd gives each layer its own dy / du / dgi / dgh instead of recycling one set.
         self.overlap_wgrad = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
+        # all weight-gradient slab reduces of a backward pass in one launch (each layer then keeps its own slab buffers)
+        self.defer_reduce = os.environ.get("TPGSR_DEFER_REDUCE", "1") != "0"
 
     def _build_layers(self):
         m = self.module
@@ -468,6 +478,8 @@ class TSRNEngine(_EngineBase):
         fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
         fwd.final = bwd.final = final
         bwd.overlap = self.overlap_wgrad
+        bwd.deferred = [] if self.defer_reduce else None
+        self._cur_ws, self._wg_idx = ws, 0
         for bn in self._bn_layers:
             bn.use(ws)
         with recording(fwd):
@@ -475,6 +487,8 @@ class TSRNEngine(_EngineBase):
         if training:
             with recording(bwd):
                 self._record_bwd(N, H, W, ws)
+                if self.defer_reduce:
+                    K.flush_wgrad_reduces()
                 bwd.join()
         return dict(fwd=fwd, bwd=bwd, ws=ws)
 

@@ -6,6 +6,7 @@ into a hipGraph (torch.cuda.graph).  No fallbacks: a failed/rejected launch rais
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -22,12 +23,41 @@ def _stream():
 _SIDE = {}
 
 
+def parse_cu_mask(spec: str):
+    """'0xffff...': hex bit mask (bit i = CU i); 'N' or 'N/S': N CUs, every S-th (default: the first N)"""
+    if spec.lower().startswith("0x"):
+        v = int(spec, 16)
+    else:
+        n, _, stride = spec.partition("/")
+        n, stride = int(n), int(stride or 1)
+        v = 0
+        for i in range(n):
+            v |= 1 << (i * stride)
+    words = []
+    while v:
+        words.append(v & 0xFFFFFFFF)
+        v >>= 32
+    return words or [0]
+
+
 def side_stream(device=None) -> "torch.cuda.Stream":
-    """The per-device second HIP stream weight-gradient launches are recorded on (see Plan.side)."""
+    """The per-device second HIP stream weight-gradient launches are recorded on (see Plan.side).
+    TPGSR_SIDE_CUMASK confines it to a subset of the compute units (parse_cu_mask)."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _SIDE.get(idx)
     if st is None:
-        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+        spec = os.environ.get("TPGSR_SIDE_CUMASK", "")
+        if spec:
+            words = parse_cu_mask(spec)
+            arr = (C.c_uint * len(words))(*words)
+            with torch.cuda.device(idx):
+                raw = _lib.load().tpgsr_stream_create(arr, len(words))
+            if not raw:
+                check(-2, "tpgsr_stream_create")
+            st = torch.cuda.ExternalStream(raw, device=idx)
+        else:
+            st = torch.cuda.Stream(device=idx)
+        _SIDE[idx] = st
     return st
 
 
@@ -306,9 +336,42 @@ def conv_wgrad(w: WgradArgs):
     _launch("tpgsr_conv_wgrad", C.byref(w))
 
 
+def deferring() -> bool:
+    """True while recording a plan that batches its weight-gradient slab reduces into one launch (Plan.deferred)."""
+    return _REC is not None and getattr(_REC, "deferred", None) is not None
+
+
 def wgrad_reduce(part, dbpart, Z, g: ConvGeom, dw, db=None, *, layout=0, accumulate=True, gscale=1.0):
+    if deferring():   # the caller gave this layer its own slab buffers; reduced by flush_wgrad_reduces()
+        _REC.deferred.append((part, dbpart, Z, g.K, g.Cin, g.Cout, g.KH, g.KW, layout, dw, db, int(accumulate), float(gscale)))
+        return
     _launch("tpgsr_wgrad_reduce", _p(part), _p(dbpart), Z, g.K, g.Cin, g.Cout, g.KH, g.KW, layout, _p(dw), _p(db),
                                          int(accumulate), gscale)
+
+
+def flush_wgrad_reduces():
+    """Emit ONE tpgsr_wgrad_reduce_program launch (side stream) for every reduce deferred so far in this plan."""
+    rec = _REC
+    items = rec.deferred
+    if not items:
+        return
+    lib = _lib.load()
+    arr = (_lib.WgradReduceDesc * len(items))()
+    blk = 0
+    seen = set()
+    for d, (part, dbpart, Z, Kd, Cin, Cout, KH, KW, layout, dw, db, acc, gscale) in zip(arr, items):
+        has_b = db is not None and dbpart is not None
+        d.part, d.dbpart = _p(part), (_p(dbpart) if has_b else None)
+        d.dw, d.db = _p(dw), (_p(db) if has_b else None)
+        d.Z, d.K, d.Cin, d.Cout, d.KH, d.KW, d.layout, d.accumulate, d.gscale, d.blk0 = Z, Kd, Cin, Cout, KH, KW, layout, acc, gscale, blk
+        blk += lib.tpgsr_wgrad_reduce_blocks(Kd, Cout, int(has_b))
+        assert dw.data_ptr() not in seen, "two deferred reduces of one program target the same gradient"
+        seen.add(dw.data_ptr())
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][0].device)
+    n = len(items)
+    rec.deferred = []
+    with side():
+        _launch("tpgsr_wgrad_reduce_program", _p(table), n, blk)
 
 
 def pack_conv_weight(w, Cout, Cin, KH, KW, wt_f=None, wt_d=None, *, transposed=False, wscale=1.0):
