@@ -32,7 +32,7 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
-/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc): a binding can verify its mirror */
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc): a binding can verify its mirror */
 int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -134,6 +134,10 @@ int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, f
  *   kind 1: tail conv [Co][C][KS][KS] folded (Cout = Co, KH = KW = KS)     kind 2: plain copy of numel floats
  *   kind 3: ConvTranspose2d weight [Cin][Cout][KH][KW] as its equivalent conv
  *   kind 4: ConvTranspose2d weight [Cin][Cout][3][3] on an H=1 strip -> 1x3 conv operand (kh=1 slice, taps flipped)
+ *   kind 5: GruBlock (model/tsrn.py:491-508) 1x1 conv composed with one direction of the GRU input projection:
+ *           Wc[g][ci] = sum_u src[g][u] * src2[u][ci]  (src = weight_ih [Cout=96][KH=64 hidden-of-conv], src2 = conv1
+ *           weight [64][Cin]) -> dst_f[ci*f_ld + f_coff + g] and dst_d[(f_coff + g)*Cin + ci]; numel = Cout*Cin
+ *   kind 6: its bias: dst_f[f_coff + g] = sum_u src[g][u] * src2[u] + src3[g]  (src2 = conv1 bias, src3 = bias_ih)
  * blk0 = prefix sum of ceil(numel/256) over the preceding descriptors; total_blocks = the full sum. */
 typedef struct {
   const float* src;
@@ -143,7 +147,32 @@ typedef struct {
   int kind, f_ld, f_coff;
   float wscale;
   int numel, blk0;
+  const float* src2;
+  const float* src3;
 } tpgsr_pack_desc;
+/* Chain rule of the composed GruBlock operand, for many blocks in one launch.  Given dWc [2*G][Cin] / dbc [2*G] (the
+ * weight / bias gradient of the composed 1x1 conv, both directions stacked, G = 96):
+ *   dW1[u][ci] += sum_g Wih[g][u] dWc[g][ci]     db1[u] += sum_g Wih[g][u] dbc[g]
+ *   dWih[g][u] += sum_ci dWc[g][ci] W1[u][ci] + dbc[g] b1[u]      dbih[g] += dbc[g]
+ * (the conv output is W1 x + b1; Wih = [wih0; wih1], U = 64 conv outputs)
+ * blk0 / total_blocks as above with tpgsr_compose_bwd_blocks(Cin) workgroups per descriptor. */
+typedef struct tpgsr_compose_bwd_desc {
+  const float* dWc;
+  const float* dbc;
+  const float* W1;
+  const float* b1;
+  const float* wih0;
+  const float* wih1;
+  float* dW1;
+  float* db1;
+  float* dwih0;
+  float* dwih1;
+  float* dbih0;
+  float* dbih1;
+  int Cin, U, G, blk0;
+} tpgsr_compose_bwd_desc;
+int tpgsr_compose_bwd_blocks(int Cin, int U, int G);
+int tpgsr_compose_bwd_program(const tpgsr_compose_bwd_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 /* diagnostic: `blocks` workgroups x 4 waves x 2*iters register-only v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) */
 int tpgsr_mfma_probe(float* out, int blocks, int iters, void* stream);

@@ -37,7 +37,7 @@ def test_binding_table_matches_header():
 def test_struct_layouts(lib):
     from tpgsr_amd import _lib
     lib.tpgsr_sizeof.restype = ctypes.c_int
-    for which, st in enumerate((_lib.ConvArgs, _lib.WgradArgs, _lib.PackDesc, _lib.WgradReduceDesc)):
+    for which, st in enumerate((_lib.ConvArgs, _lib.WgradArgs, _lib.PackDesc, _lib.WgradReduceDesc, _lib.ComposeBwdDesc)):
         assert lib.tpgsr_sizeof(which) == ctypes.sizeof(st), st.__name__
 
 

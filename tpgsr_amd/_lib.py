@@ -38,7 +38,13 @@ class WgradArgs(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst_f", vp), ("dst_d", vp), ("Cout", ci), ("Cin", ci), ("KH", ci), ("KW", ci),
-                ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci)]
+                ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci),
+                ("src2", vp), ("src3", vp)]
+
+
+class ComposeBwdDesc(C.Structure):
+    _fields_ = [("dWc", vp), ("dbc", vp), ("W1", vp), ("b1", vp), ("wih0", vp), ("wih1", vp), ("dW1", vp), ("db1", vp),
+                ("dwih0", vp), ("dwih1", vp), ("dbih0", vp), ("dbih1", vp), ("Cin", ci), ("U", ci), ("G", ci), ("blk0", ci)]
 
 
 class WgradReduceDesc(C.Structure):
@@ -74,6 +80,8 @@ _SIGS = {
     "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
     "tpgsr_wgrad_reduce_blocks": (ci, [ci, ci, ci]),
     "tpgsr_wgrad_reduce_program": (ci, [vp, ci, ci, vp]),
+    "tpgsr_compose_bwd_blocks": (ci, [ci, ci, ci]),
+    "tpgsr_compose_bwd_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_pack_conv_weight": (ci, [vp, ci, ci, ci, ci, ci, cf, vp, vp, vp]),
     "tpgsr_pack_tail_weight": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "tpgsr_bn_finalize": (ci, [vp, ci, ci, ll, vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp]),
@@ -147,7 +155,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

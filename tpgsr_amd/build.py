@@ -13,6 +13,10 @@ if os.environ.get("TPGSR_FAST_MATH"):   # A/B switch only: v_exp_f32 / v_rcp_f32
     FLAGS.append("-DTPGSR_FAST_MATH")
 
 
+if os.environ.get("TPGSR_FRAG_PRELOAD") is not None:   # A/B switch: conv fragment preload (conv_mfma.hip)
+    FLAGS.append("-DTPGSR_FRAG_PRELOAD=" + os.environ["TPGSR_FRAG_PRELOAD"])
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

@@ -11,6 +11,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+// 1: all MFMA fragments of a K chunk are read from LDS before its first MFMA (one LDS round trip per chunk, +32 VGPRs:
+// 4 waves / SIMD); 0: the compiler interleaves read pairs with the MFMAs (6 waves / SIMD).  Measured on MI355X: equal
+// on the 768-tile 64->64 convs (45.0 vs 45.5 us), 0 wins on larger grids (3x3 64->256: 137 vs 152 us) -> default 0.
+#ifndef TPGSR_FRAG_PRELOAD
+#define TPGSR_FRAG_PRELOAD 0
+#endif
 #define BM 64
 #define BN 64
 #define KC 32
@@ -330,7 +336,9 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_fwd_kernel(tpgsr_conv_args a
 #pragma unroll
       for (int kk = 0; kk < KC / 2; ++kk) av[kk] = As[arow][acol], bv[kk] = Bs[arow][bcol];
     }
+#if TPGSR_FRAG_PRELOAD
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks each read pair next to its MFMAs again)
+#endif
 #pragma unroll
     for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);   // keep the prologue arithmetic / LDS stores of the next tile behind the MFMAs
@@ -590,7 +598,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
       av[mm] = As[arow][2 * mm + half];
       bv[mm] = Ys[2 * mm + half][bcol];
     }
+#if TPGSR_FRAG_PRELOAD
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int mm = 0; mm < WM / 2; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mm], bv[mm], acc, 0, 0, 0);
     if (want_db) {
@@ -850,6 +860,33 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
   const tpgsr_pack_desc d = descs[s_d];
   long long idx = (long long)(blockIdx.x - d.blk0) * 256 + threadIdx.x;
   if (idx >= d.numel) return;
+  if (d.kind == 5) {  // composed GruBlock operand: one 64-term dot product per output element
+    const int U = d.KH;             // conv1 output channels = GRU input size
+    const int g = (int)(idx / d.Cin), ci = (int)(idx - (long long)g * d.Cin);
+    const float* wr = d.src + (size_t)g * U;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int u = 0; u < U; u += 4) {
+      a0 = fmaf(wr[u], d.src2[(size_t)u * d.Cin + ci], a0);
+      a1 = fmaf(wr[u + 1], d.src2[(size_t)(u + 1) * d.Cin + ci], a1);
+      a2 = fmaf(wr[u + 2], d.src2[(size_t)(u + 2) * d.Cin + ci], a2);
+      a3 = fmaf(wr[u + 3], d.src2[(size_t)(u + 3) * d.Cin + ci], a3);
+    }
+    const float v = (a0 + a1) + (a2 + a3);
+    if (d.dst_f) d.dst_f[(size_t)ci * d.f_ld + d.f_coff + g] = v;
+    if (d.dst_d) d.dst_d[(size_t)(d.f_coff + g) * d.Cin + ci] = v;
+    return;
+  }
+  if (d.kind == 6) {
+    const int U = d.KH, g = (int)idx;
+    const float* wr = d.src + (size_t)g * U;
+    float a0 = 0.f, a1 = 0.f;
+    for (int u = 0; u < U; u += 2) {
+      a0 = fmaf(wr[u], d.src2[u], a0);
+      a1 = fmaf(wr[u + 1], d.src2[u + 1], a1);
+    }
+    d.dst_f[d.f_coff + g] = (a0 + a1) + d.src3[g];
+    return;
+  }
   float v = d.src[idx] * d.wscale;
   if (d.kind == 2) {  // plain copy
     d.dst_f[idx] = v;
@@ -888,6 +925,74 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
   }
   if (d.dst_f) d.dst_f[((size_t)(kh * d.KW + kw) * d.Cin + ci) * d.f_ld + d.f_coff + co] = v;
   if (d.dst_d) d.dst_d[((size_t)((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.Cout + co) * d.Cin + ci] = v;
+}
+
+// chain rule of the composed GruBlock operand (see tpgsr_compose_bwd_desc): one thread per gradient element
+__global__ __launch_bounds__(256) void compose_bwd_program_kernel(const tpgsr_compose_bwd_desc* __restrict__ descs, int ndesc) {
+  __shared__ int s_d;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    s_d = lo;
+  }
+  __syncthreads();
+  const tpgsr_compose_bwd_desc d = descs[s_d];
+  const int Cin = d.Cin, U = d.U, G = d.G;
+  int idx = (int)(blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  const int n_w1 = U * Cin, n_b1 = U, n_wih = 2 * G * U, n_bih = 2 * G;
+  auto wih = [&](int g, int u) { return g < G ? d.wih0[(size_t)g * U + u] : d.wih1[(size_t)(g - G) * U + u]; };
+  if (idx < n_w1) {   // dW1[u][ci] += sum_g Wih[g][u] * dWc[g][ci]
+    const int u = idx / Cin, ci = idx - u * Cin;
+    float a0 = 0.f, a1 = 0.f;
+    for (int g = 0; g < 2 * G; g += 2) {
+      a0 = fmaf(wih(g, u), d.dWc[(size_t)g * Cin + ci], a0);
+      a1 = fmaf(wih(g + 1, u), d.dWc[(size_t)(g + 1) * Cin + ci], a1);
+    }
+    d.dW1[idx] += a0 + a1;
+    return;
+  }
+  idx -= n_w1;
+  if (idx < n_b1) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int g = 0; g < 2 * G; g += 2) {
+      a0 = fmaf(wih(g, idx), d.dbc[g], a0);
+      a1 = fmaf(wih(g + 1, idx), d.dbc[g + 1], a1);
+    }
+    d.db1[idx] += a0 + a1;
+    return;
+  }
+  idx -= n_b1;
+  if (idx < n_wih) {  // dWih[g][u] += sum_ci dWc[g][ci] * W1[u][ci]
+    const int g = idx / U, u = idx - g * U;
+    const float* a = d.dWc + (size_t)g * Cin;
+    const float* b = d.W1 + (size_t)u * Cin;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ci = 0; ci < Cin; ci += 4) {
+      a0 = fmaf(a[ci], b[ci], a0);
+      a1 = fmaf(a[ci + 1], b[ci + 1], a1);
+      a2 = fmaf(a[ci + 2], b[ci + 2], a2);
+      a3 = fmaf(a[ci + 3], b[ci + 3], a3);
+    }
+    float* dst = g < G ? d.dwih0 + (size_t)g * U + u : d.dwih1 + (size_t)(g - G) * U + u;
+    *dst += ((a0 + a1) + (a2 + a3)) + d.dbc[g] * d.b1[u];   // conv output = W1 x + b1
+    return;
+  }
+  idx -= n_wih;
+  if (idx < n_bih) {
+    float* dst = idx < G ? d.dbih0 + idx : d.dbih1 + (idx - G);
+    *dst += d.dbc[idx];
+  }
+}
+
+extern "C" int tpgsr_compose_bwd_blocks(int Cin, int U, int G) { return cdiv((long long)U * Cin + U + 2ll * G * U + 2 * G, 256); }
+
+extern "C" int tpgsr_compose_bwd_program(const tpgsr_compose_bwd_desc* descs_dev, int ndesc, int total_blocks, void* stream) {
+  TPGSR_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0, "tpgsr_compose_bwd_program: bad arguments");
+  hipLaunchKernelGGL(compose_bwd_program_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc);
+  TPGSR_LAUNCH_CHECK("tpgsr_compose_bwd_program");
 }
 
 extern "C" int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream) {

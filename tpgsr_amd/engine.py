@@ -206,39 +206,48 @@ class BNLayer:
 
 class GruLayer:
     """GruBlock (model/tsrn.py:491-508): 1x1 conv -> bidirectional GRU(hidden 32) along one spatial axis.
-    axis 0: sequences along W (gru2); axis 1: along H (gru1, the reference's transpose(-1,-2))."""
+    axis 0: sequences along W (gru2); axis 1: along H (gru1, the reference's transpose(-1,-2)).
+
+    The 1x1 conv and the GRU's input projection are two linear maps back to back, so they run as ONE MFMA conv with the
+    composed operand Wc = W_ih W_1, bc = W_ih b_1 + b_ih (rebuilt from the parameters every step by the pack program):
+    the intermediate 64-channel map of the reference never exists, in either direction.  The gradients of W_1, b_1,
+    W_ih, b_ih follow from dWc / dbc by the chain rule (tpgsr_compose_bwd_program, once per backward pass)."""
 
     def __init__(self, eng, prefix: str, axis: int):
         self.eng, self.prefix, self.axis = eng, prefix, axis
-        self.conv = ConvLayer(eng, prefix + ".conv1.weight", prefix + ".conv1.bias")
         P, dev = eng.P, eng.device
+        self.w1name, self.b1name = prefix + ".conv1.weight", prefix + ".conv1.bias"
+        W1 = P[self.w1name]
+        self.U, self.Cin = W1.shape[0], W1.shape[1]
         gp = prefix + ".gru."
         self.gp = gp
         hid = P[gp + "weight_hh_l0"].shape[1]
         if hid != 32:
             raise NotImplementedError("the fused BiGRU kernel is specialised for hidden_units=32 (the reference default)")
-        self.Cg = Cg = P[gp + "weight_ih_l0"].shape[1]
-        self.wih_f = torch.empty(Cg, 192, dtype=F32, device=dev)   # forward operand [K=Cg][192]
-        self.wih_d = torch.empty(192, Cg, dtype=F32, device=dev)   # dgrad operand  [K'=192][Cg]
-        self.bih = torch.empty(192, dtype=F32, device=dev)
+        assert P[gp + "weight_ih_l0"].shape[1] == self.U and self.U % 4 == 0 and self.Cin % 4 == 0
+        Cin = self.Cin
+        self.wc_f = torch.empty(Cin, 192, dtype=F32, device=dev)    # forward operand [K=Cin][192]
+        self.wc_d = torch.empty(192, Cin, dtype=F32, device=dev)    # dgrad operand  [K'=192][Cin]
+        self.bc = torch.empty(192, dtype=F32, device=dev)
         self.whh = torch.empty(2, 96, 32, dtype=F32, device=dev)
         self.bhh = torch.empty(2, 96, dtype=F32, device=dev)
         for d, suf in enumerate(("", "_reverse")):
-            eng.add_pack(P[gp + "weight_ih_l0" + suf], self.wih_f, self.wih_d[d * 96:(d + 1) * 96], Cout=96, Cin=Cg, KH=1, KW=1,
-                         kind=0, f_ld=192, f_coff=d * 96)
-            eng.add_pack(P[gp + "bias_ih_l0" + suf], self.bih[d * 96:(d + 1) * 96], None, kind=2)
+            wih = P[gp + "weight_ih_l0" + suf]
+            eng.add_pack(wih, self.wc_f, self.wc_d, Cout=96, Cin=Cin, KH=self.U, KW=1, kind=5, f_ld=192, f_coff=d * 96,
+                         src2=W1, numel=96 * Cin)
+            eng.add_pack(wih, self.bc, None, Cout=96, Cin=0, KH=self.U, KW=1, kind=6, f_coff=d * 96, src2=P[self.b1name],
+                         src3=P[gp + "bias_ih_l0" + suf], numel=96)
             eng.add_pack(P[gp + "weight_hh_l0" + suf], self.whh[d], None, kind=2)
             eng.add_pack(P[gp + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
 
-    def fwd(self, N, H, W, x, u, gi, h, gates=None, **loader):
-        """u = conv1x1(loader(x)); gi = u W_ih^T + b_ih; h = BiGRU(gi) (gates: saved for bwd in training plans)"""
-        self.conv.fwd(N, H, W, x, u, **loader)
-        g = ConvGeom(N, H, W, self.Cg, 192)
-        K.conv_fwd(K.make_conv_args(g, u, self.wih_f, gi, bias=self.bih))
+    def fwd(self, N, H, W, x, gi, h, gates=None, **loader):
+        """gi = loader(x) Wc^T + bc; h = BiGRU(gi) (gates: saved for bwd in training plans)"""
+        g = ConvGeom(N, H, W, self.Cin, 192)
+        K.conv_fwd(K.make_conv_args(g, x, self.wc_f, gi, bias=self.bc, **loader))
         K.bigru_fwd(gi, self.whh, self.bhh, N, H, W, self.axis, h, gates)
 
-    def bwd(self, N, H, W, x, u, gates, h, dh, dh2, dgi, dgh, du, dx, **loader):
-        """all parameter gradients of the block + dx = dL/d loader(x)"""
+    def bwd(self, N, H, W, x, gates, h, dh, dh2, dgi, dgh, dx, **loader):
+        """all parameter gradients of the block + dx = dL/d loader(x) (dx None: the caller takes it from dgi / wc_d)"""
         eng, G, gp = self.eng, self.eng.G, self.gp
         K.bigru_bwd(gates, h, dh, dh2, self.whh, N, H, W, self.axis, dgi, dgh)
         with K.side():
@@ -251,18 +260,17 @@ class GruLayer:
                 ca = K.make_conv_args(gh, h, in_ld=64, in_coff=32 * d)
                 K.conv_wgrad(K.make_wgrad_args(ca, dgh, part, dbp, dy_ld=192, dy_coff=96 * d))
                 K.wgrad_reduce(part, dbp, Z, gh, G[gp + "weight_hh_l0" + suf], G[gp + "bias_hh_l0" + suf], accumulate=True)
-                # input side: dW_ih[d] = dgi[:, d]^T u, db_ih[d] = colsum
-                gi_ = ConvGeom(N, H, W, self.Cg, 96)
-                Z = K.wgrad_splits(gi_.M, gi_.K, 96)
-                part, dbp = eng.wgrad_buffers(Z * self.Cg * 96, Z * 96)
-                ca = K.make_conv_args(gi_, u)
-                K.conv_wgrad(K.make_wgrad_args(ca, dgi, part, dbp, dy_ld=192, dy_coff=96 * d))
-                K.wgrad_reduce(part, dbp, Z, gi_, G[gp + "weight_ih_l0" + suf], G[gp + "bias_ih_l0" + suf], accumulate=True)
-        # du = dgi W_ih  (dgrad of the input projection), then the 1x1 conv
-        K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cg), dgi, self.wih_d, du))
-        self.conv.wgrad(N, H, W, x, du, loader=loader)
+            # input side, both directions at once: dWc = dgi^T loader(x), dbc = colsum(dgi); chain rule at the end of the pass
+            gc = ConvGeom(N, H, W, self.Cin, 192)
+            Z = K.wgrad_splits(gc.M, gc.K, 192)
+            part, dbp = eng.wgrad_buffers(Z * self.Cin * 192, Z * 192)
+            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gc, x, **loader), dgi, part, dbp))
+            ws = eng._cur_ws
+            dWc, dbc = ws("dWc_" + self.prefix, 192, self.Cin), ws("dbc_" + self.prefix, 192)
+            K.wgrad_reduce(part, dbp, Z, gc, dWc, dbc, accumulate=False)
+            eng._compose.append((self, dWc, dbc))
         if dx is not None:
-            self.conv.dgrad(N, H, W, du, dx)
+            K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cin), dgi, self.wc_d, dx))
 
 
 class TConvStrip:
@@ -324,6 +332,7 @@ class _EngineBase:
         self._bn_layers: List["BNLayer"] = []
         self._pending_batches = 0
         self._wg_idx, self._cur_ws = 0, None
+        self._compose: List[tuple] = []
 
     # ---- scratch buffers live only between consecutive launches (stream-ordered reuse) ----------------------
     def scratch(self, name, numel):
@@ -345,22 +354,51 @@ class _EngineBase:
             return ws(f"wgp{i}", n_part), (ws(f"wgb{i}", n_db) if n_db else None)
         return self.scratch("wgrad_part", n_part), (self.scratch("wgrad_dbpart", n_db) if n_db else None)
 
-    def add_pack(self, src, dst_f, dst_d, Cout=0, Cin=0, KH=1, KW=1, kind=0, f_ld=0, f_coff=0, wscale=1.0):
-        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale))
+    def flush_compose_bwd(self):
+        """ONE launch: chain rule from every GruBlock's composed-operand gradient to its conv1 / weight_ih gradients."""
+        items, self._compose = self._compose, []
+        if not items:
+            return
+        from ._lib import ComposeBwdDesc, load
+        lib = load()
+        arr = (ComposeBwdDesc * len(items))()
+        blk, keep = 0, []
+        for d, (L, dWc, dbc) in zip(arr, items):
+            P, G, gp = self.P, self.G, L.gp
+            t = dict(dWc=dWc, dbc=dbc, W1=P[L.w1name], b1=P[L.b1name], wih0=P[gp + "weight_ih_l0"], wih1=P[gp + "weight_ih_l0_reverse"],
+                     dW1=G[L.w1name], db1=G[L.b1name], dwih0=G[gp + "weight_ih_l0"], dwih1=G[gp + "weight_ih_l0_reverse"],
+                     dbih0=G[gp + "bias_ih_l0"], dbih1=G[gp + "bias_ih_l0_reverse"])
+            for k, v in t.items():
+                setattr(d, k, v.data_ptr())
+            keep += list(t.values())
+            d.Cin, d.U, d.G, d.blk0 = L.Cin, L.U, 96, blk
+            blk += lib.tpgsr_compose_bwd_blocks(L.Cin, L.U, 96)
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        if K._REC is not None:
+            K._REC.keep += keep
+        with K.side():
+            K.compose_bwd_program(table, len(items), blk)
+
+    def add_pack(self, src, dst_f, dst_d, Cout=0, Cin=0, KH=1, KW=1, kind=0, f_ld=0, f_coff=0, wscale=1.0, src2=None, src3=None,
+                 numel=None):
+        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel))
 
     def _finish_pack_table(self):
         n = len(self._pack)
         arr = (PackDesc * n)()
         blk = 0
         self._pack_keep = []
-        for i, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale) in enumerate(self._pack):
+        for i, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel) in enumerate(self._pack):
             d = arr[i]
             d.src, d.dst_f = src.data_ptr(), dst_f.data_ptr()
             d.dst_d = dst_d.data_ptr() if dst_d is not None else None
+            d.src2 = src2.data_ptr() if src2 is not None else None
+            d.src3 = src3.data_ptr() if src3 is not None else None
             d.Cout, d.Cin, d.KH, d.KW, d.kind, d.f_ld, d.f_coff, d.wscale = Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale
-            d.numel, d.blk0 = src.numel(), blk
-            blk += (src.numel() + 255) // 256
-            self._pack_keep += [src, dst_f, dst_d]
+            cnt = src.numel() if numel is None else numel
+            d.numel, d.blk0 = cnt, blk
+            blk += (cnt + 255) // 256
+            self._pack_keep += [src, dst_f, dst_d, src2, src3]
         raw = bytes(arr)
         self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self._pack_n, self._pack_blocks = n, blk
@@ -435,7 +473,7 @@ class TSRNEngine(_EngineBase):
             self.rrb.append(dict(
                 conv1=ConvLayer(self, p + ".conv1.weight", p + ".conv1.bias", 3, 3, 1, 1), bn1=BNLayer(self, p + ".bn1"),
                 conv2=ConvLayer(self, p + ".conv2.weight", p + ".conv2.bias", 3, 3, 1, 1),
-                bn2=BNLayer(self, p + ".bn2", pad_to=g1.conv.Cin),
+                bn2=BNLayer(self, p + ".bn2", pad_to=g1.Cin),
                 gru1=g1, gru2=GruLayer(self, p + ".gru2", axis=0)))
         if self.tl:
             cfg = [(2, 1), (2, 1), (2, 1), (1, 0)]       # (stride_w, pad_w) of tconv1..4 (model/tsrn.py:89-98)
@@ -479,7 +517,7 @@ class TSRNEngine(_EngineBase):
         fwd.final = bwd.final = final
         bwd.overlap = self.overlap_wgrad
         bwd.deferred = [] if self.defer_reduce else None
-        self._cur_ws, self._wg_idx = ws, 0
+        self._cur_ws, self._wg_idx, self._compose = ws, 0, []
         for bn in self._bn_layers:
             bn.use(ws)
         with recording(fwd):
@@ -489,6 +527,7 @@ class TSRNEngine(_EngineBase):
                 self._record_bwd(N, H, W, ws)
                 if self.defer_reduce:
                     K.flush_wgrad_reduces()
+                self.flush_compose_bwd()
                 bwd.join()
         return dict(fwd=fwd, bwd=bwd, ws=ws)
 
@@ -511,8 +550,8 @@ class TSRNEngine(_EngineBase):
         for i, L in enumerate(self.rrb):
             t = f"r{i}_"
             y1, y2 = ws(t + "y1", P1, Cc), ws(t + "y2", P1, Cc)
-            u1, gi1, h1 = ws(t + "u1", P1, Cc), ws(t + "gi1", P1, 192), ws(t + "h1", P1, Cc)
-            u2, gi2, out = ws(t + "u2", P1, Cc), ws(t + "gi2", P1, 192), ws(t + "out", P1, Cc)
+            gi1, h1 = ws(t + "gi1", P1, 192), ws(t + "h1", P1, Cc)
+            gi2, out = ws(t + "gi2", P1, 192), ws(t + "out", P1, Cc)
             gt1 = ws(t + "gt1", P1, 256) if training else None      # GRU gate values, kept for back-propagation
             gt2 = ws(t + "gt2", P1, 256) if training else None
             part, _ = L["bn1"].partial(P1)
@@ -523,10 +562,10 @@ class TSRNEngine(_EngineBase):
             L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None)
             L["bn2"].finalize(P1, L["conv2"].b, training)
             if self.tl:   # torch.cat([bn2(y2), text strip], 1) inside the 1x1 conv's loader (model/tsrn.py:419-423)
-                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, gt1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
+                L["gru1"].fwd(N, H, W, y2, gi1, h1, gt1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
             else:
-                L["gru1"].fwd(N, H, W, y2, u1, gi1, h1, gt1, **L["bn2"].loader)
-            L["gru2"].fwd(N, H, W, cur, u2, gi2, out, gt2, in2=h1)
+                L["gru1"].fwd(N, H, W, y2, gi1, h1, gt1, **L["bn2"].loader)
+            L["gru2"].fwd(N, H, W, cur, gi2, out, gt2, in2=h1)
             cur = out
         y7 = ws("y7", P1, Cc)
         part, _ = self.bn7.partial(P1)
@@ -656,23 +695,23 @@ class TSRNEngine(_EngineBase):
         for i in range(self.srb - 1, -1, -1):
             L = self.rrb[i]
             p = f"r{i}_"
-            dgi, dgh, du = buf("dgi", p + "g2_", 192), buf("dgh", p + "g2_", 192), buf("du", p + "g2_", Cc)
+            dgi, dgh = buf("dgi", p + "g2_", 192), buf("dgh", p + "g2_", 192)
             X = t[f"r{i - 1}_out"] if i > 0 else t["b1"]
-            y1, y2, u1, gt1, h1, u2, gt2, out = (t[p + n] for n in ("y1", "y2", "u1", "gt1", "h1", "u2", "gt2", "out"))
+            y1, y2, gt1, h1, gt2, out = (t[p + n] for n in ("y1", "y2", "gt1", "h1", "gt2", "out"))
             # gru2 (input X + h1): parameter grads + d(X + h1) -> gA (incoming gA/gB are dead after the scan)
-            L["gru2"].bwd(N, H, W, X, u2, gt2, out, gA, gB if have_B else None, dgi, dgh, du, gA, in2=h1)
+            L["gru2"].bwd(N, H, W, X, gt2, out, gA, gB if have_B else None, dgi, dgh, gA, in2=h1)
             # gru1 (input bn2(y2) [+ text strip]): dh = gA
-            dgi, dgh, du = buf("dgi", p + "g1_", 192), buf("dgh", p + "g1_", 192), buf("du", p + "g1_", Cc)
+            dgi, dgh = buf("dgi", p + "g1_", 192), buf("dgh", p + "g1_", 192)
             if self.tl:
                 g1 = L["gru1"]
-                g1.bwd(N, H, W, y2, u1, gt1, h1, gA, None, dgi, dgh, du, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
-                # data gradient of the 96->64 1x1 conv in two column blocks: image features and text strip
-                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, Cc, Cc), du, g1.conv.wt_d, da, wt_ld=g1.conv.Cin, wt_coff=0))
+                g1.bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
+                # data gradient of the composed 96->192 projection in two column blocks: image features and text strip
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, Cc), dgi, g1.wc_d, da, wt_ld=g1.Cin, wt_coff=0))
                 dtb = ws("d_tb", P1, self.Ct)
-                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, Cc, self.Ct), du, g1.conv.wt_d, dtb, wt_ld=g1.conv.Cin, wt_coff=Cc))
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Ct), dgi, g1.wc_d, dtb, wt_ld=g1.Cin, wt_coff=Cc))
                 K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
-                L["gru1"].bwd(N, H, W, y2, u1, gt1, h1, gA, None, dgi, dgh, du, da, **L["bn2"].loader)
+                L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, da, **L["bn2"].loader)
             dy = buf("dy", p + "c2_", Cc)
             L["bn2"].backward(da, None, y2, P1, "none", dy)
             L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)

@@ -382,6 +382,10 @@ def pack_tail_weight(w, Co, Cc, KS, wt_f=None, wt_d=None):
     _launch("tpgsr_pack_tail_weight", _p(w), Co, Cc, KS, _p(wt_f), _p(wt_d))
 
 
+def compose_bwd_program(descs_dev, ndesc, total_blocks):
+    _launch("tpgsr_compose_bwd_program", _p(descs_dev), ndesc, total_blocks)
+
+
 def pack_program(descs_dev, ndesc, total_blocks):
     _launch("tpgsr_pack_program", _p(descs_dev), ndesc, total_blocks)
 
