@@ -261,3 +261,40 @@ def test_tsrn_tl_gradients_vs_oracle_nostn():
     rel = (pd.grad.cpu() - pr.grad).norm().item() / pr.grad.norm().item()
     print("dprior rel err", rel)
     assert rel < 2e-3
+
+
+def test_full_size_properties_bs48():
+    """BASELINE config 2 at its full size (bs 48, 16x64 -> 32x128), through size-independent properties:
+    batch-permutation equivariance of the eval forward, SR range, train-step determinism across two replicas,
+    gradient accumulation linearity (autograd semantics of the arena)."""
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    lr, hr = O.synthetic_batch(48, 4242)
+    lr, hr = lr.to(DEV), hr.to(DEV)
+    net, _ = _build(stn=True, seed=909)
+    net.eval()
+    with torch.no_grad():
+        y = net(lr)
+        perm = torch.randperm(48, generator=torch.Generator().manual_seed(1)).to(DEV)
+        yp = net(lr[perm].contiguous())
+    assert y.shape == (48, 4, 32, 128) and float(y.abs().max()) <= 1.0      # tanh head
+    assert torch.equal(yp, y[perm])                                           # per-sample computation in eval mode
+    assert np.isfinite(_psnr(y[:, :3], hr[:, :3]))
+    # gradient accumulation: two backward passes of the same loss == 2 x one pass (bitwise up to the fp32 adds of the arena)
+    net.train()
+    crit = ImageLoss(gradient=True, loss_weight=[1, 1e-4])
+    (crit(net(lr), hr).mean() * 100).backward()
+    g1 = net._engine().arena.grad.clone()
+    (crit(net(lr), hr).mean() * 100).backward()
+    g2 = net._engine().arena.grad.clone()
+    assert (g2 - 2 * g1).abs().max() <= 2e-6 * g1.abs().max()
+    # determinism: two replicas, same data -> bitwise identical 3-step trajectories and parameters
+    outs = []
+    for _ in range(2):
+        m, _ = _build(stn=True, seed=909)
+        m.train()
+        ts = TSRNTrainStep(m)
+        losses = [ts.step(lr, hr).item() for _ in range(3)]
+        outs.append((losses, m._engine().arena.flat.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0][2] < outs[0][0][0]                                      # and it trains
