@@ -178,11 +178,6 @@ def main():
     else:
         step = lambda: ts.step(lr_img, hr_img)
 
-    main_stream = None
-    if os.environ.get("TPGSR_MAIN_PRIO"):       # experiment: critical-path stream at high queue priority
-        main_stream = torch.cuda.Stream(priority=-1)
-        main_stream.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(main_stream)
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()

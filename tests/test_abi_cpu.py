@@ -90,3 +90,38 @@ def test_native_plan_records_without_gpu():
         assert lib.tpgsr_plan_size(h) == 4
     finally:
         lib.tpgsr_plan_destroy(h)
+
+
+def test_cu_mask_spec_parsing():
+    from tpgsr_amd import kernels as K
+    assert K.parse_cu_mask("0xff") == [0xFF]
+    assert K.parse_cu_mask("40") == [0xFFFFFFFF, 0xFF]
+    assert K.parse_cu_mask("4/16") == [0x00010001, 0x00010001]
+    assert K.parse_cu_mask("0x1" + "0" * 16) == [0, 0, 1]
+
+
+def test_plan_recording_sections_on_cpu():
+    """Plan bookkeeping without a device: side sections tag launches, fork/join edges are emitted once per section / plan,
+    DynPtr slots are tracked, and the native handle is built lazily (not here)."""
+    from tpgsr_amd import kernels as K
+    plan = K.Plan("t")
+    plan.overlap = True
+    with K.recording(plan):
+        K._launch("tpgsr_zero", 0x1000, 16)
+        with K.side():
+            K._launch("tpgsr_zero", K.DynPtr("buf"), 16)
+            K._launch("tpgsr_zero", 0x3000, 16)
+        K._launch("tpgsr_zero", 0x4000, 16)
+        plan.join()
+        plan.join()                                   # idempotent: nothing to join any more
+    kinds = [(op[0], op[3]) for op in plan.ops]
+    assert kinds == [("tpgsr_zero", 0), ("fork", 0), ("tpgsr_zero", 1), ("tpgsr_zero", 1), ("tpgsr_zero", 0), ("join", 0)]
+    assert plan.dyn == {"buf": [(2, 0)]} and plan._native is None
+    plan.set_ptr("buf", 0x2000)
+    assert plan.ops[2][2][0] == 0x2000
+    plain = K.Plan("p")                               # overlap off: side() is a no-op
+    with K.recording(plain):
+        with K.side():
+            K._launch("tpgsr_zero", 0x1000, 16)
+        plain.join()
+    assert [(op[0], op[3]) for op in plain.ops] == [("tpgsr_zero", 0)]
