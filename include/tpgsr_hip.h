@@ -288,13 +288,19 @@ int tpgsr_pool2d_fwd(const float* x, int N, int H, int W, int C, const float* sc
                      int KW, int SH, int SW, int PH, int PW, float* out, void* stream);
 int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale, const float* shift,
                      int act, int KH, int KW, int SH, int SW, int PH, int PW, float* dz, void* stream);
+/* Recurrent projection of one BiLSTM time step (nn.LSTM, model/crnn/crnn.py:10), both directions in one launch, split
+ * over K into S slabs: slab[sp][d][n][c] = sum_{k in slice sp} A_d[n][k] * B_d[k][c], n < Nrows <= 64 (the batch),
+ * A_d row n at a_d + n*a_stride, B_d row-major [K][Nc] (K %% 32 == 0, Nc %% 64 == 0).  out: [S][2][Nrows][Nc]. */
+int tpgsr_lstm_rec_gemm(const float* a0, const float* a1, long long a_stride, const float* b0, const float* b1, int Nrows,
+                        int K, int Nc, int S, float* out, void* stream);
 /* One BiLSTM time step for both directions (gate order i,f,g,o).  G [N][T][2][4Hh]: input projections in, activated
- * gates out (fwd) / gate gradients out (bwd); gh [2][N][4Hh] = W_hh h_prev of this step (MFMA GEMM, unused at step 0);
- * Cst [N][T][2][Hh]; out [N][T][2Hh].  bwd: dhc [2][N][Hh] = W_hh^T dG of the previous backward step, dcc [N][2][Hh]. */
-int tpgsr_lstm_step_fwd(float* G, const float* gh, const float* bhh /* [2][4Hh], optional */, float* Cst, float* out, int N,
-                        int T, int Hh, int step, void* stream);
-int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, float* dcc, int N, int T, int Hh,
-                        int step, void* stream);
+ * gates out (fwd) / gate gradients out (bwd); gh [nsplit][2][N][4Hh] = W_hh h_prev of this step as K-split slabs
+ * (tpgsr_lstm_rec_gemm; summed in slab order; unused at step 0); Cst [N][T][2][Hh]; out [N][T][2Hh].
+ * bwd: dhc [nsplit][2][N][Hh] = W_hh^T dG of the previous backward step, dcc [N][2][Hh]. */
+int tpgsr_lstm_step_fwd(float* G, const float* gh, int nsplit, const float* bhh /* [2][4Hh], optional */, float* Cst, float* out,
+                        int N, int T, int Hh, int step, void* stream);
+int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, int nsplit, float* dcc, int N, int T,
+                        int Hh, int step, void* stream);
 /* p = softmax(logits [N][T][C]); prior (N,C,1,T) = p with samples [0, drop_n) zeroed (prior dropout); with q: partial
  * sums of SemanticLoss = mean|q-p| + KLDivLoss('mean')(log(p+1e-20), q+1e-20).  bwd: dlogits from dprior (+dp_in) and
  * the semantic loss weighted by wsem. */

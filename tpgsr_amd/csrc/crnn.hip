@@ -209,15 +209,80 @@ extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H,
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Recurrent projection of ONE BiLSTM time step, both directions in one launch, split over K:
+//   slab[sp][d][n][c] = sum_{k in slice sp} A_d[n][k] * B_d[k][c]      (n < Nrows <= 64, c < Nc, Nc % 64 == 0)
+// A_d row n starts at a_d + n * a_stride (K contiguous floats), B_d is row-major [K][Nc].  The step's GEMM is tiny
+// (48 x 256 x 1024) and latency-bound: run as one 64x64 MFMA tile per column block it is 16 workgroups walking 8 K
+// chunks in sequence (27 us); split over K it is 128 workgroups of one chunk each, and the gate kernel adds the slabs in
+// a fixed order.  Grid: (Nc / 64, S, 2).
+// ------------------------------------------------------------------------------------------------------
+#define RG_KC 32
+__global__ __launch_bounds__(256) void lstm_rec_gemm_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                            long long a_stride, const float* __restrict__ b0,
+                                                            const float* __restrict__ b1, int Nrows, int K, int Nc, int S,
+                                                            float* __restrict__ out) {
+  __shared__ float As[RG_KC][65];
+  __shared__ float Bs[RG_KC][64];
+  const int d = blockIdx.z, sp = blockIdx.y, n0 = blockIdx.x * 64;
+  const float* A = d == 0 ? a0 : a1;
+  const float* B = d == 0 ? b0 : b1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int kper = (K / RG_KC + S - 1) / S * RG_KC;          // K slice of this split, whole chunks
+  const int kbeg = sp * kper, kend = min(K, kbeg + kper);
+  const int aq = tid & 7, am0 = tid >> 3, bk0 = tid >> 4, bc = (tid & 15) * 4;
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int arow = lane >> 5, acol = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31);
+  for (int k0 = kbeg; k0 < kend; k0 += RG_KC) {
+    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0;
+    const int k = k0 + aq * 4;
+    if (am0 < Nrows && k < kend) ra0 = *reinterpret_cast<const float4*>(A + (size_t)am0 * a_stride + k);
+    if (am0 + 32 < Nrows && k < kend) ra1 = *reinterpret_cast<const float4*>(A + (size_t)(am0 + 32) * a_stride + k);
+    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
+    if (k0 + bk0 < kend) rb0 = *reinterpret_cast<const float4*>(B + (size_t)(k0 + bk0) * Nc + n0 + bc);
+    if (k0 + bk0 + 16 < kend) rb1 = *reinterpret_cast<const float4*>(B + (size_t)(k0 + bk0 + 16) * Nc + n0 + bc);
+    __syncthreads();   // previous chunk's fragment reads are done
+    As[aq * 4 + 0][am0] = ra0.x; As[aq * 4 + 1][am0] = ra0.y; As[aq * 4 + 2][am0] = ra0.z; As[aq * 4 + 3][am0] = ra0.w;
+    As[aq * 4 + 0][am0 + 32] = ra1.x; As[aq * 4 + 1][am0 + 32] = ra1.y; As[aq * 4 + 2][am0 + 32] = ra1.z; As[aq * 4 + 3][am0 + 32] = ra1.w;
+    *reinterpret_cast<float4*>(&Bs[bk0][bc]) = rb0;
+    *reinterpret_cast<float4*>(&Bs[bk0 + 16][bc]) = rb1;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < RG_KC / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + arow][acol], Bs[2 * kk + arow][bcol], acc, 0, 0, 0);
+  }
+  float* dst = out + ((size_t)(sp * 2 + d) * Nrows) * Nc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < Nrows) dst[(size_t)row * Nc + n0 + bcol] = acc[r];
+  }
+}
+
+extern "C" int tpgsr_lstm_rec_gemm(const float* a0, const float* a1, long long a_stride, const float* b0, const float* b1,
+                                   int Nrows, int K, int Nc, int S, float* out, void* stream) {
+  TPGSR_CHECK_ARG(a0 && a1 && b0 && b1 && out, "tpgsr_lstm_rec_gemm: null pointer");
+  TPGSR_CHECK_ARG(Nrows > 0 && Nrows <= 64 && K > 0 && (K % RG_KC) == 0 && Nc > 0 && (Nc % 64) == 0 && S > 0 && S <= K / RG_KC &&
+                      (a_stride & 3) == 0 && (((uintptr_t)a0 | (uintptr_t)a1 | (uintptr_t)b0 | (uintptr_t)b1) & 15) == 0,
+                  "tpgsr_lstm_rec_gemm: needs Nrows <= 64, K %% 32 == 0, Nc %% 64 == 0, 1 <= S <= K/32, 16-byte aligned operands");
+  hipLaunchKernelGGL(lstm_rec_gemm_kernel, dim3(Nc / 64, S, 2), dim3(256), 0, (hipStream_t)stream, a0, a1, a_stride, b0, b1, Nrows, K,
+                     Nc, S, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_rec_gemm");
+}
+
+// ------------------------------------------------------------------------------------------------------
 // BiLSTM time step (gate order i, f, g, o).  Layouts (batch-major, T = sequence length, Hh = hidden):
 //   G   [N][T][2][4*Hh]  input projections (+b_ih+b_hh) on entry, ACTIVATED gates on exit (saved for backward)
-//   gh  [2][N][4*Hh]     this step's recurrent projections W_hh h_{prev} (ignored at step 0)
+//   gh  [S][2][N][4*Hh]  this step's recurrent projections W_hh h_{prev} as S K-split slabs (tpgsr_lstm_rec_gemm), summed
+//                        here in slab order (ignored at step 0)
 //   Cst [N][T][2][Hh]    cell states,   out [N][T][2*Hh]  hidden states (direction d in columns d*Hh..)
 // step s processes t = s for the forward direction and t = T-1-s for the reverse direction.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ G, const float* __restrict__ gh,
                                                             const float* __restrict__ bhh, float* __restrict__ Cst,
-                                                            float* __restrict__ out, int N, int T, int Hh, int s) {
+                                                            float* __restrict__ out, int N, int T, int Hh, int s, int nsplit) {
   int total = N * 2 * Hh;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -237,11 +302,18 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   }
   float cprev = 0.f;
   if (s > 0) {
-    const float* r = gh + ((size_t)d * N + n) * 4 * Hh;
-    pi += r[j];
-    pf += r[Hh + j];
-    pg += r[2 * Hh + j];
-    po += r[3 * Hh + j];
+    float ri = 0.f, rf = 0.f, rg = 0.f, ro = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float* r = gh + ((size_t)(sp * 2 + d) * N + n) * 4 * Hh;
+      ri += r[j];
+      rf += r[Hh + j];
+      rg += r[2 * Hh + j];
+      ro += r[3 * Hh + j];
+    }
+    pi += ri;
+    pf += rf;
+    pg += rg;
+    po += ro;
     cprev = Cst[(((size_t)n * T + tp) * 2 + d) * Hh + j];
   }
   float ig = sigmoid_f(pi), fg = sigmoid_f(pf), gg = tanh_f(pg), og = sigmoid_f(po);
@@ -255,19 +327,22 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   out[((size_t)n * T + t) * 2 * Hh + d * Hh + j] = h;
 }
 
-extern "C" int tpgsr_lstm_step_fwd(float* G, const float* gh, const float* bhh, float* Cst, float* out, int N, int T, int Hh, int step,
-                                   void* stream) {
-  TPGSR_CHECK_ARG(G && Cst && out && (gh || step == 0) && N > 0 && T > 0 && Hh > 0 && step >= 0 && step < T, "tpgsr_lstm_step_fwd: bad arguments");
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(cdiv((long long)N * 2 * Hh, 256)), dim3(256), 0, (hipStream_t)stream, G, gh, bhh, Cst, out, N, T, Hh, step);
+extern "C" int tpgsr_lstm_step_fwd(float* G, const float* gh, int nsplit, const float* bhh, float* Cst, float* out, int N, int T, int Hh,
+                                   int step, void* stream) {
+  TPGSR_CHECK_ARG(G && Cst && out && ((gh && nsplit > 0) || step == 0) && N > 0 && T > 0 && Hh > 0 && step >= 0 && step < T,
+                  "tpgsr_lstm_step_fwd: bad arguments");
+  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(cdiv((long long)N * 2 * Hh, 256)), dim3(256), 0, (hipStream_t)stream, G, gh, bhh, Cst, out, N, T, Hh,
+                     step, nsplit);
   TPGSR_LAUNCH_CHECK("tpgsr_lstm_step_fwd");
 }
 
 // backward step s' (reverse of the forward order): t = T-1-s' (forward dir), t = s' (reverse dir).
-//   dout [N][T][2*Hh] gradient w.r.t. the hidden states,  dhc [2][N][Hh] recurrent gradient W_hh^T dG[t_next] (ignored at s' = 0)
+//   dout [N][T][2*Hh] gradient w.r.t. the hidden states,  dhc [S][2][N][Hh] recurrent gradient W_hh^T dG[t_next] as K-split slabs
+//   (ignored at s' = 0)
 //   dcc [N][2][Hh] running cell-state gradient (in/out),  G: activated gates in, dG (pre-activation gate gradients) out
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(float* __restrict__ G, const float* __restrict__ Cst,
                                                             const float* __restrict__ dout, const float* __restrict__ dhc,
-                                                            float* __restrict__ dcc, int N, int T, int Hh, int s) {
+                                                            float* __restrict__ dcc, int N, int T, int Hh, int s, int nsplit) {
   int total = N * 2 * Hh;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -284,7 +359,9 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(float* __restrict__ 
   float dh = dout[((size_t)n * T + t) * 2 * Hh + d * Hh + j];
   float dc = 0.f;
   if (s > 0) {
-    dh += dhc[((size_t)d * N + n) * Hh + j];
+    float rh = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) rh += dhc[((size_t)(sp * 2 + d) * N + n) * Hh + j];
+    dh += rh;
     dc = dcc[((size_t)n * 2 + d) * Hh + j];
   }
   float tc = tanh_f(c);
@@ -300,12 +377,12 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(float* __restrict__ 
   g[3 * Hh + j] = dog;
 }
 
-extern "C" int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, float* dcc, int N, int T, int Hh,
-                                   int step, void* stream) {
-  TPGSR_CHECK_ARG(G && Cst && dout && dcc && (dhc || step == 0) && N > 0 && T > 0 && Hh > 0 && step >= 0 && step < T,
+extern "C" int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, int nsplit, float* dcc, int N, int T,
+                                   int Hh, int step, void* stream) {
+  TPGSR_CHECK_ARG(G && Cst && dout && dcc && ((dhc && nsplit > 0) || step == 0) && N > 0 && T > 0 && Hh > 0 && step >= 0 && step < T,
                   "tpgsr_lstm_step_bwd: bad arguments");
   hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(cdiv((long long)N * 2 * Hh, 256)), dim3(256), 0, (hipStream_t)stream, G, Cst, dout, dhc, dcc, N,
-                     T, Hh, step);
+                     T, Hh, step, nsplit);
   TPGSR_LAUNCH_CHECK("tpgsr_lstm_step_bwd");
 }
 

@@ -45,13 +45,12 @@ class LstmLayer:
         """x [N][T][Cin] -> G (gates) -> out [N][T][2Hh] -> e = Linear(out) [N][T][nOut]"""
         Hh, G4, P = self.Hh, 4 * self.Hh, self.eng.P
         K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, self.Cin, 2 * G4), x, self.wih_f, G, bias=self.bih, **loader))
+        S = Hh // 32                                          # one 32-deep K chunk per workgroup: 2 * S * 4Hh/64 workgroups
         for s in range(T):
-            if s > 0:
-                for d in range(2):
-                    tp = s - 1 if d == 0 else T - s          # time index of the previous state of direction d
-                    g = ConvGeom(N, 1, T, Hh, G4, 1, 1, 0, -tp, 1, 1)
-                    K.conv_fwd(K.make_conv_args(g, out, self.whh_f[d], gh[d], in_ld=2 * Hh, in_coff=d * Hh))
-            K.lstm_step_fwd(G, gh if s > 0 else None, self.bhh, Cst, out, N, T, Hh, s)
+            if s > 0:     # gh = h_prev W_hh^T, both directions in one split-K launch (h_prev: time s-1 / T-s of `out`)
+                a = [out.data_ptr() + 4 * ((s - 1 if d == 0 else T - s) * 2 * Hh + d * Hh) for d in range(2)]
+                K.lstm_rec_gemm(a[0], a[1], T * 2 * Hh, self.whh_f[0], self.whh_f[1], N, Hh, G4, S, gh)
+            K.lstm_step_fwd(G, gh if s > 0 else None, S, self.bhh, Cst, out, N, T, Hh, s)
         self.emb.fwd(N, 1, T, out, e)
 
     def bwd(self, N, T, x, G, Cst, out, de, dout, dhc, dcc, dx, **loader):
@@ -60,15 +59,12 @@ class LstmLayer:
         Hh, G4 = self.Hh, 4 * self.Hh
         self.emb.wgrad(N, 1, T, out, de)
         self.emb.dgrad(N, 1, T, de, dout)
+        S = G4 // 32
         for s in range(T):
-            if s > 0:
-                for d in range(2):
-                    tn = T - s if d == 0 else s - 1           # time index processed by the previous backward step
-                    g = ConvGeom(N, 1, T, G4, Hh, 1, 1, 0, -tn, 1, 1)
-                    # dh_prev = dG[tn] @ W_hh  (operand [K=4Hh][Hh] is the PyTorch weight itself)
-                    K.conv_fwd(K.make_conv_args(g, G, P[r + "weight_hh_l0" + ("" if d == 0 else "_reverse")], dhc[d],
-                                                in_ld=2 * G4, in_coff=d * G4))
-            K.lstm_step_bwd(G, Cst, dout, dhc if s > 0 else None, dcc, N, T, Hh, s)
+            if s > 0:     # dh_prev = dG[t_next] W_hh (operand [K=4Hh][Hh] is the PyTorch weight itself), split over K
+                a = [G.data_ptr() + 4 * (((T - s if d == 0 else s - 1) * 2 + d) * G4) for d in range(2)]
+                K.lstm_rec_gemm(a[0], a[1], T * 2 * G4, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], N, G4, Hh, S, dhc)
+            K.lstm_step_bwd(G, Cst, dout, dhc if s > 0 else None, S, dcc, N, T, Hh, s)
         for d, suf in enumerate(("", "_reverse")):
             sgn = 1 if d == 0 else -1
             # hidden side: dW_hh[d] = dG[:, d]^T h_prev, db_hh[d] = colsum(dG[:, d])
@@ -162,7 +158,7 @@ class CRNNEngine(_EngineBase):
         for j, L in enumerate(self.lstm):
             G4 = 4 * L.Hh
             G = ws(f"l{j}_G", N * T, 2 * G4)
-            gh = ws(f"l{j}_gh", 2, N, G4)
+            gh = ws(f"l{j}_gh", L.Hh // 32, 2, N, G4)
             Cst = ws(f"l{j}_C", N * T, 2 * L.Hh)
             out = ws(f"l{j}_out", N * T, 2 * L.Hh)
             e = ws(f"l{j}_e", N * T, L.emb.Cout)
@@ -181,7 +177,7 @@ class CRNNEngine(_EngineBase):
             L = self.lstm[j]
             G4 = 4 * L.Hh
             dout = ws(f"l{j}_dout", N * T, 2 * L.Hh)
-            dhc = ws(f"l{j}_dhc", 2, N, L.Hh)
+            dhc = ws(f"l{j}_dhc", 4 * L.Hh // 32, 2, N, L.Hh)
             dcc = ws(f"l{j}_dcc", N, 2 * L.Hh)
             x = t[f"l{j - 1}_e"] if j == 1 else t["s6"]
             dx = ws(f"l{j}_dx", N * T, L.Cin)

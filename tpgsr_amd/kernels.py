@@ -527,12 +527,17 @@ def pool2d_bwd(x, dout, N, H, W, C_, scale, shift, act, k, s, pd, dz):
             _p(dz))
 
 
-def lstm_step_fwd(G, gh, bhh, Cst, out, N, T, Hh, step):
-    _launch("tpgsr_lstm_step_fwd", _p(G), _p(gh), _p(bhh), _p(Cst), _p(out), N, T, Hh, step)
+def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
+    """a0 / a1: raw device addresses (ints) of row 0 of the two directions' A operands inside a kept-alive tensor"""
+    _launch("tpgsr_lstm_rec_gemm", a0, a1, a_stride, _p(b0), _p(b1), Nrows, Kd, Nc, S, _p(out))
 
 
-def lstm_step_bwd(G, Cst, dout, dhc, dcc, N, T, Hh, step):
-    _launch("tpgsr_lstm_step_bwd", _p(G), _p(Cst), _p(dout), _p(dhc), _p(dcc), N, T, Hh, step)
+def lstm_step_fwd(G, gh, nsplit, bhh, Cst, out, N, T, Hh, step):
+    _launch("tpgsr_lstm_step_fwd", _p(G), _p(gh), nsplit, _p(bhh), _p(Cst), _p(out), N, T, Hh, step)
+
+
+def lstm_step_bwd(G, Cst, dout, dhc, nsplit, dcc, N, T, Hh, step):
+    _launch("tpgsr_lstm_step_bwd", _p(G), _p(Cst), _p(dout), _p(dhc), nsplit, _p(dcc), N, T, Hh, step)
 
 
 def softmax_prior_fwd(logits, q, N, T, C_, drop_n, p, prior, partial, nblk):
