@@ -197,10 +197,14 @@ class TPGSRTrainStep:
         hr = hr_img.contiguous()
         lr_img = lr_img.contiguous()
         self.opt.zero_grad()
-        # teacher on HR (eval mode, no gradient)
-        K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
-        t_logits = self.teacher._engine().forward(st["gray_hr"], False)
-        K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
+        # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
+        # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
+        main, aux = torch.cuda.current_stream(), K.aux_stream(lr_img.device)
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
+            t_logits = self.teacher._engine().forward(st["gray_hr"], False)
+            K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
         cascade, ch, cw = lr_img, H, W
         srs, logits_keep = [], []
         for i in range(self.stu_iter):
@@ -208,6 +212,8 @@ class TPGSRTrainStep:
             srm = self.sr[0 if self.sr_share else i]
             K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
             logits = stu._engine().forward(st["gray"][i], True, slot=i)
+            if i == 0:
+                main.wait_stream(aux)           # the teacher's distribution q is needed from here on
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
             K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
             sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i)

@@ -61,6 +61,19 @@ def side_stream(device=None) -> "torch.cuda.Stream":
     return st
 
 
+_AUX = {}
+
+
+def aux_stream(device=None) -> "torch.cuda.Stream":
+    """A further per-device stream for host-level overlap of independent sub-networks (the frozen teacher recogniser of the
+    text-prior path runs on it next to the student's forward pass)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _AUX.get(idx)
+    if st is None:
+        st = _AUX[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
 class Plan:
     """A recorded, replayable list of kernel launches (static pointers + geometry).  Built once per shape by running
     the wrappers below under ``with recording(plan)``; ``run()`` replays it on the current stream with no Python
