@@ -8,6 +8,7 @@ the flat arena.  The sequence tensor is kept batch-major [N][T][C] (== NHWC with
 recurrence is a 1x1 "conv" that reads pixel t of every image (negative pad_w selects the column)."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -65,21 +66,22 @@ class LstmLayer:
                 a = [G.data_ptr() + 4 * (((T - s if d == 0 else s - 1) * 2 + d) * G4) for d in range(2)]
                 K.lstm_rec_gemm(a[0], a[1], T * 2 * G4, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], N, G4, Hh, S, dhc)
             K.lstm_step_bwd(G, Cst, dout, dhc if s > 0 else None, S, dcc, N, T, Hh, s)
-        for d, suf in enumerate(("", "_reverse")):
-            sgn = 1 if d == 0 else -1
-            # hidden side: dW_hh[d] = dG[:, d]^T h_prev, db_hh[d] = colsum(dG[:, d])
-            gh_ = ConvGeom(N, 1, T, Hh, G4, 1, 1, 0, sgn, 1, T)
-            Z = K.wgrad_splits(gh_.M, gh_.K, G4)
-            part, dbp = eng.scratch("wgrad_part", Z * Hh * G4), eng.scratch("wgrad_dbpart", Z * G4)
-            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gh_, out, in_ld=2 * Hh, in_coff=d * Hh), G, part, dbp,
-                                           dy_ld=2 * G4, dy_coff=d * G4))
-            K.wgrad_reduce(part, dbp, Z, gh_, Gd[r + "weight_hh_l0" + suf], Gd[r + "bias_hh_l0" + suf], accumulate=True)
-            # input side
-            gi_ = ConvGeom(N, 1, T, self.Cin, G4)
-            Z = K.wgrad_splits(gi_.M, gi_.K, G4)
-            part, dbp = eng.scratch("wgrad_part", Z * self.Cin * G4), eng.scratch("wgrad_dbpart", Z * G4)
-            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gi_, x, **loader), G, part, dbp, dy_ld=2 * G4, dy_coff=d * G4))
-            K.wgrad_reduce(part, dbp, Z, gi_, Gd[r + "weight_ih_l0" + suf], Gd[r + "bias_ih_l0" + suf], accumulate=True)
+        with K.side():     # weight gradients: leaves of the graph, on the side stream once the gate gradients are final
+            for d, suf in enumerate(("", "_reverse")):
+                sgn = 1 if d == 0 else -1
+                # hidden side: dW_hh[d] = dG[:, d]^T h_prev, db_hh[d] = colsum(dG[:, d])
+                gh_ = ConvGeom(N, 1, T, Hh, G4, 1, 1, 0, sgn, 1, T)
+                Z = K.wgrad_splits(gh_.M, gh_.K, G4)
+                part, dbp = eng.wgrad_buffers(Z * Hh * G4, Z * G4)
+                K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gh_, out, in_ld=2 * Hh, in_coff=d * Hh), G, part, dbp,
+                                               dy_ld=2 * G4, dy_coff=d * G4))
+                K.wgrad_reduce(part, dbp, Z, gh_, Gd[r + "weight_hh_l0" + suf], Gd[r + "bias_hh_l0" + suf], accumulate=True)
+                # input side
+                gi_ = ConvGeom(N, 1, T, self.Cin, G4)
+                Z = K.wgrad_splits(gi_.M, gi_.K, G4)
+                part, dbp = eng.wgrad_buffers(Z * self.Cin * G4, Z * G4)
+                K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gi_, x, **loader), G, part, dbp, dy_ld=2 * G4, dy_coff=d * G4))
+                K.wgrad_reduce(part, dbp, Z, gi_, Gd[r + "weight_ih_l0" + suf], Gd[r + "bias_ih_l0" + suf], accumulate=True)
         if dx is not None:
             K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, 2 * G4, self.Cin), G, self.wih_d, dx))
 
@@ -122,6 +124,12 @@ class CRNNEngine(_EngineBase):
     def _record(self, N, training, ws, final):
         fwd, bwd = Plan("crnn_fwd"), Plan("crnn_bwd")
         fwd.final = bwd.final = final
+        # weight gradients on the side stream + one batched slab reduce, as in TSRNEngine (every buffer a weight-gradient
+        # launch reads -- ds{i}, saved activations, the LSTM gate gradients after the time loop -- is written once per pass)
+        bwd.overlap = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
+        defer = os.environ.get("TPGSR_DEFER_REDUCE", "1") != "0"
+        bwd.deferred = [] if defer else None
+        self._cur_ws, self._wg_idx = ws, 0
         for bn in self._bn_layers:
             bn.use(ws)
         with recording(fwd):
@@ -129,6 +137,9 @@ class CRNNEngine(_EngineBase):
         if training:
             with recording(bwd):
                 self._record_bwd(N, ws)
+                if defer:
+                    K.flush_wgrad_reduces()
+                bwd.join()
         return dict(fwd=fwd, bwd=bwd, ws=ws)
 
     def _record_fwd(self, N, training, ws):
