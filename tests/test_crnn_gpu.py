@@ -103,6 +103,57 @@ def test_softmax_prior_semantic_loss(golden_dir):
     assert (dl.cpu().permute(1, 0, 2) - lr_.grad).abs().max() < 2e-6 * max(1.0, lr_.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("N,Kd,Nc,S", [(48, 256, 1024, 8), (48, 1024, 256, 32), (5, 64, 128, 1), (64, 96, 64, 2)])
+def test_lstm_rec_gemm_and_step_vs_explicit_cell(N, Kd, Nc, S):
+    """Split-K recurrent projection (both directions in one launch): slabs summed in order == A_d @ B_d; rows are strided
+    views into a [N][T][...] sequence tensor exactly as the engine passes them.  Then one LSTM step (gates from the slabs)
+    against the gate equations of nn.LSTM written out (model/crnn/crnn.py:10)."""
+    from tpgsr_amd import kernels as K
+    g = torch.Generator().manual_seed(N + Kd)
+    T, t0, t1 = 5, 1, 3
+    seq = torch.randn(N, T, 2, Kd, generator=g).to(DEV)           # direction d, time t_d: row n at seq[n, t_d, d]
+    B = (torch.randn(2, Kd, Nc, generator=g) / Kd ** 0.5).to(DEV)
+    out = torch.full((S, 2, N, Nc), float("nan"), device=DEV)
+    a0 = seq.data_ptr() + 4 * ((t0 * 2 + 0) * Kd)
+    a1 = seq.data_ptr() + 4 * ((t1 * 2 + 1) * Kd)
+    K.lstm_rec_gemm(a0, a1, T * 2 * Kd, B[0], B[1], N, Kd, Nc, S, out)
+    torch.cuda.synchronize()
+    ref = torch.stack([seq[:, t0, 0].double().cpu() @ B[0].double().cpu(), seq[:, t1, 1].double().cpu() @ B[1].double().cpu()])
+    got = out.double().cpu().sum(0)
+    assert not torch.isnan(out).any()
+    assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    if Nc % 4 or Nc // 4 * 4 != Nc or Kd * 4 != Nc:
+        return
+    # one forward LSTM step (s = 1 of T = 2) fed by the slabs: Hh = Kd, 4*Hh = Nc
+    Hh, T2 = Kd, 2
+    G = torch.randn(N, T2, 2, 4 * Hh, generator=g).to(DEV)        # input projections (+ b_ih) of both directions
+    bhh = torch.randn(2, 4 * Hh, generator=g).to(DEV)
+    Cst = torch.zeros(N, T2, 2, Hh, device=DEV)
+    hs = torch.zeros(N, T2, 2 * Hh, device=DEV)
+    Gref = G.double().cpu().clone()
+    K.lstm_step_fwd(G, None, 0, bhh, Cst, hs, N, T2, Hh, 0)       # step 0: h_prev = 0
+    Whh = (torch.randn(2, Hh, 4 * Hh, generator=g) / Hh ** 0.5).to(DEV)      # [d][K = Hh][4Hh] = W_hh^T
+    gh = torch.empty(S, 2, N, 4 * Hh, device=DEV)
+    prev = [hs.data_ptr() + 4 * ((0 if d == 0 else 1) * 2 * Hh + d * Hh) for d in range(2)]   # h_prev: t = 0 (fwd), t = 1 (reverse)
+    K.lstm_rec_gemm(prev[0], prev[1], T2 * 2 * Hh, Whh[0], Whh[1], N, Hh, 4 * Hh, S, gh)
+    K.lstm_step_fwd(G, gh, S, bhh, Cst, hs, N, T2, Hh, 1)
+    torch.cuda.synchronize()
+
+    def cell(pre, cprev):
+        i, f, gg, o = pre.split(Hh, -1)
+        c = torch.sigmoid(f) * cprev + torch.sigmoid(i) * torch.tanh(gg)
+        return torch.sigmoid(o) * torch.tanh(c), c
+
+    b, W = bhh.double().cpu(), Whh.double().cpu()
+    for d in range(2):
+        tA, tB = (0, 1) if d == 0 else (1, 0)                      # first / second time index processed by direction d
+        h0, c0 = cell(Gref[:, tA, d] + b[d], torch.zeros(N, Hh, dtype=torch.float64))
+        h1, c1 = cell(Gref[:, tB, d] + b[d] + h0 @ W[d], c0)
+        assert (hs[:, tA, d * Hh:(d + 1) * Hh].double().cpu() - h0).abs().max() < 2e-6
+        assert (hs[:, tB, d * Hh:(d + 1) * Hh].double().cpu() - h1).abs().max() < 5e-6
+        assert (Cst[:, tB, d].double().cpu() - c1).abs().max() < 5e-6
+
+
 def test_crnn_vs_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "model_crnn.npz"))
     net, sd = _build()

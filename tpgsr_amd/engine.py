@@ -670,7 +670,8 @@ class TSRNEngine(_EngineBase):
         dPt = ws("dPt", P4, tl.Cout)
         dbp = self.scratch("tail_dbp", nblk * tl.Co)
         K.tail_bwd(K.DynPtr("sr"), K.DynPtr("dsr"), N, H2, W2, tl.Co, tl.KS, dPt, dbp, nblk)
-        K.reduce_partials(dbp, nblk, tl.Co, self.G[tl.wname.replace(".weight", ".bias")], accumulate=True)
+        with K.side():   # bias gradient: a leaf, off the critical path
+            K.reduce_partials(dbp, nblk, tl.Co, self.G[tl.wname.replace(".weight", ".bias")], accumulate=True)
         tl.wgrad(N, H2, W2, t["mups"], dPt)
         dm = ws("d_ups", P4, Cc)
         tl.dgrad(N, H2, W2, dPt, dm)
@@ -728,7 +729,8 @@ class TSRNEngine(_EngineBase):
         nb = 256
         dap = self.scratch("prelu_dap", nb)
         K.prelu_bwd(t["c1"], self.P["block1.1.weight"], gA, d_s, P1 * Cc, dc1, dap, nb)
-        K.reduce_partials(dap, nb, 1, self.G["block1.1.weight"], accumulate=True)
+        with K.side():
+            K.reduce_partials(dap, nb, 1, self.G["block1.1.weight"], accumulate=True)
         xin = t["xr"] if self.stn else t["x_nhwc"]
         self.block1.wgrad(N, H, W, xin, dc1)
         if self.stn:
