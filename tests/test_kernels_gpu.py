@@ -93,6 +93,36 @@ def test_conv_fwd_plain(case):
     assert relerr(from_nhwc(dx, N, H, W, Ci), xr.grad) < 5e-6
 
 
+@pytest.mark.parametrize("Cout,ks,ps", [(192, 1, False), (256, 3, True), (192, 3, False)])
+def test_conv_fwd_wide_tiles(Cout, ks, ps):
+    """Wide outputs (Cout = 192 / 256: several column tiles per pixel tile) on a grid of > 512 pixel tiles with a ragged
+    last one: loader affine + residual, bias, optional pixel-shuffle store."""
+    k = K()
+    N, H, W, C = 9, 57, 64, 64                       # M = 32832 = 513 tiles
+    g = torch.Generator().manual_seed(Cout + ks)
+    x = torch.randn(N, C, H, W, generator=g)
+    x2 = torch.randn(N, C, H, W, generator=g)
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    w = torch.randn(Cout, C, ks, ks, generator=g) / math.sqrt(C * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    a = x.double() * sc.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double() + x2.double()
+    ref = F.conv2d(a, w.double(), b.double(), padding=ks // 2)
+    geom = k.ConvGeom(N, H, W, C, Cout, ks, ks, ks // 2, ks // 2)
+    assert (geom.M + 63) // 64 >= 512
+    wf, _ = pack_f(w)
+    keep = [to_nhwc(x), b.to(DEV), to_nhwc(x2), sc.to(DEV), sh.to(DEV)]
+    out = torch.full((geom.M * (4 if ps else 1), Cout // (4 if ps else 1)), float("nan"), device=DEV)
+    k.conv_fwd(k.make_conv_args(geom, keep[0], wf, out, bias=keep[1], in2=keep[2], in_scale=keep[3], in_shift=keep[4], out_ps=ps))
+    torch.cuda.synchronize()
+    if ps:
+        got, want = from_nhwc(out, N, 2 * H, 2 * W, Cout // 4), F.pixel_shuffle(ref, 2)
+    else:
+        got, want = from_nhwc(out, N, H, W, Cout), ref
+    assert not torch.isnan(out).any()
+    assert relerr(got, want) < 3e-6
+
+
 def test_conv_fwd_prologue_epilogue_bnstats():
     """loader: mish(scale*x+shift) + in2 ; epilogue: bias, relu, per-block BN partial sums."""
     k = K()
