@@ -406,6 +406,116 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_fwd_kernel(tpgsr_conv_args a
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Weights-stationary 3x3 conv for the 64-channel trunk (RRB conv1/conv2, conv7 and their data gradients: Cin = Cout = 64,
+// pad 1, image width 64 = one 64-pixel tile per image row, plain loader).  One 12-wave workgroup owns three image rows:
+// the 3 x 3 x 32 x 64 weight slice of a 32-channel pass (72 KB) is brought into LDS once by LDS-DMA and shared by the
+// three 4-wave groups, each group brings the 3 x 66-pixel halo of its row (25 KB, zero page for padding); then 9 taps x
+// 16 MFMAs per wave run out of LDS with no barrier in between.  Global traffic 76 MB instead of 226 MB for the C2 shape;
+// 37.5 us vs 45 us for the im2col tile loop (tools/lab/conv_glds_lab.hip).
+//   LDS images: halo [pixel][8 quads], quad position q ^ ((pixel >> 1) & 7) (source-side swizzle: the LDS side of an LDS-DMA
+//   is lane-linear) -> conflict-free ds_read_b128 A fragments; weights [tap][32][64] row-major -> conflict-free b32.
+//   K index of MFMA j for lane half h: 4 * (2 * (j >> 2) + h) + (j & 3) within the 32-channel slice.
+// ------------------------------------------------------------------------------------------------------
+#define WS_HP (3 * 66)
+#define WS_HPAD ((WS_HP + 7) / 8 * 8)
+#define WS_LDS_FLOATS (9 * 32 * 64 + 3 * WS_HPAD * 32)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(768) void conv3x3_wstat_kernel(tpgsr_conv_args a, const float* __restrict__ zero, int M) {
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  float* Ws = ws_smem;                          // [9][32][64]
+  const int tid = threadIdx.x, L = tid & 63, wv = tid >> 6;
+  const int grp = wv >> 2, w = wv & 3;
+  const int wm = w & 1, wn = w >> 1;
+  const int H = a.H, W = 64;
+  const int row = blockIdx.x * 3 + grp;         // image row (n * H + oh) = 64-pixel tile index
+  const int m0 = row * 64;
+  const bool rowok = m0 < M;
+  const int n = rowok ? row / H : 0, oh = rowok ? row - n * H : 0;
+  float* Hs = ws_smem + 9 * 32 * 64 + grp * WS_HPAD * 32;
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int am = wm * 32 + (L & 31), h = L >> 5;
+  const int bn = wn * 32 + (L & 31);
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    for (int g = wv; g < 72; g += 12) {         // weight rows tap*64 + pass*32 + r -> Ws[tap][r][:], 4 rows per LDS-DMA
+      int rr = g * 4 + (L >> 4);
+      int tap = rr >> 5, r = rr & 31;
+      glds16(a.wt + (size_t)(tap * 64 + pass * 32 + r) * 64 + (L & 15) * 4, &Ws[g * 4 * 64]);
+    }
+    for (int g = w; g < WS_HPAD / 8; g += 4) {  // this group's halo, 8 pixels per LDS-DMA
+      int P = g * 8 + (L >> 3);
+      int r = P / 66, cc = P - r * 66;
+      int ih = oh - 1 + r, iw = cc - 1;
+      bool ok = rowok && P < WS_HP && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      int q = (L & 7) ^ ((P >> 1) & 7);
+      const float* src = ok ? a.in + ((size_t)(n * H + ih) * W + iw) * a.in_ld + a.in_coff + pass * 32 + q * 4 : zero + (L & 7) * 4;
+      glds16(src, &Hs[g * 8 * 32]);
+    }
+    __syncthreads();                            // drains the LDS-DMAs (vmcnt(0)) of every wave
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int P = kh * 66 + am + kw;
+      const float* Wt = Ws + tap * 32 * 64;
+      float4 a4[4];
+      float b[16];
+#pragma unroll
+      for (int qi = 0; qi < 4; ++qi) {
+        int pos = (2 * qi + h) ^ ((P >> 1) & 7);
+        a4[qi] = *reinterpret_cast<const float4*>(&Hs[P * 32 + pos * 4]);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) b[j] = Wt[(4 * (2 * (j >> 2) + h) + (j & 3)) * 64 + bn];
+#pragma unroll
+      for (int qi = 0; qi < 4; ++qi) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qi].x, b[4 * qi + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qi].y, b[4 * qi + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qi].z, b[4 * qi + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qi].w, b[4 * qi + 3], acc, 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: bias, store, BN partial statistics (one 64-pixel row block per group, as conv_fwd_kernel) ----
+  const float bias = a.bias ? a.bias[bn] : 0.f;
+  float s = 0.f, ss = 0.f;
+  if (rowok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int rw = (r & 3) + 8 * (r >> 2) + 4 * (L >> 5);
+      int m = m0 + wm * 32 + rw;
+      float raw = acc[r];
+      s += raw;
+      ss += raw * raw;
+      a.out[(size_t)m * a.out_ld + a.out_coff + bn] = raw + bias;
+    }
+  }
+  if (a.bn_partial) {
+    __syncthreads();                            // all groups are done reading their halos: reuse them as reduction scratch
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    float* red = Hs;                            // [wm][2][64]
+    if (L < 32) {
+      red[(wm * 2 + 0) * 64 + bn] = s;
+      red[(wm * 2 + 1) * 64 + bn] = ss;
+    }
+    __syncthreads();
+    const int t = tid & 255;
+    if (rowok && t < 64) {
+      float* dst = a.bn_partial + (size_t)row * 2 * 64;
+      dst[t] = red[0 * 64 + t] + red[2 * 64 + t];
+      dst[64 + t] = red[1 * 64 + t] + red[3 * 64 + t];
+    }
+  }
+}
+
 static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
   TPGSR_CHECK_ARG(a && a->in, "%s: null input", who);
   TPGSR_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0,
@@ -446,6 +556,32 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   int vecB = ((a->Cout & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
+  // the 64-channel 3x3 trunk convs on 64-wide maps: weights-stationary kernel (TPGSR_CONV_WSTAT=0 falls back to the tile loop)
+  static const bool wstat_on = [] { const char* e = getenv("TPGSR_CONV_WSTAT"); return !(e && e[0] == '0'); }();
+  if (wstat_on && ld == 0 && a->KH == 3 && a->KW == 3 && a->pad_h == 1 && a->pad_w == 1 && a->Cin == 64 && a->Cout == 64 &&
+      a->W == 64 && a->OW == 64 && a->OH == a->H && a->in_dil_w <= 1 && a->stride_w <= 1 && !a->out_ps && a->out_act == TPGSR_ACT_NONE &&
+      (a->wt_ld == 0 || a->wt_ld == 64) && a->wt_coff == 0 && (a->in_ld & 3) == 0 && (a->in_coff & 3) == 0 &&
+      (((uintptr_t)a->in | (uintptr_t)a->wt) & 15) == 0) {
+    static float* zero_page = nullptr;        // 256 B of zeros: source of the halo's padding pixels
+    static bool attr_set = false;
+    if (!zero_page) {
+      if (hipMalloc((void**)&zero_page, 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) {
+        tpgsr_set_error("tpgsr_conv_fwd: zero page allocation failed");
+        return TPGSR_ERR_LAUNCH;
+      }
+    }
+    const size_t lds = sizeof(float) * WS_LDS_FLOATS;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)conv3x3_wstat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        tpgsr_set_error("tpgsr_conv_fwd: cannot reserve %zu bytes of LDS", lds);
+        return TPGSR_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    const int rows = (int)(M / 64);
+    hipLaunchKernelGGL(conv3x3_wstat_kernel, dim3((rows + 2) / 3), dim3(768), lds, st, *a, zero_page, (int)M);
+    TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd");
+  }
   vecB = vecB && ((a->wt_ld & 3) == 0) && ((a->wt_coff & 3) == 0);
   // optional (TPGSR_CONV_SPLITK=1): split K over two thread groups of one workgroup (twice the resident waves on grids
   // of few tiles per CU).  Measured neutral on MI355X for the 768-tile 64->64 convs (48.0 vs 47.4 us): the launch is
