@@ -562,24 +562,30 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
       a->W == 64 && a->OW == 64 && a->OH == a->H && a->in_dil_w <= 1 && a->stride_w <= 1 && !a->out_ps && a->out_act == TPGSR_ACT_NONE &&
       (a->wt_ld == 0 || a->wt_ld == 64) && a->wt_coff == 0 && (a->in_ld & 3) == 0 && (a->in_coff & 3) == 0 &&
       (((uintptr_t)a->in | (uintptr_t)a->wt) & 15) == 0) {
-    static float* zero_page = nullptr;        // 256 B of zeros: source of the halo's padding pixels
-    static bool attr_set = false;
-    if (!zero_page) {
-      if (hipMalloc((void**)&zero_page, 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) {
+    // per device: 256 B of zeros (source of the halo's padding pixels) and the opt-in to > 64 KB of dynamic LDS
+    static float* zero_page[64] = {nullptr};
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      tpgsr_set_error("tpgsr_conv_fwd: hipGetDevice failed");
+      return TPGSR_ERR_LAUNCH;
+    }
+    if (!zero_page[dev]) {
+      if (hipMalloc((void**)&zero_page[dev], 256) != hipSuccess || hipMemset(zero_page[dev], 0, 256) != hipSuccess) {
         tpgsr_set_error("tpgsr_conv_fwd: zero page allocation failed");
         return TPGSR_ERR_LAUNCH;
       }
     }
     const size_t lds = sizeof(float) * WS_LDS_FLOATS;
-    if (!attr_set) {
+    if (!attr_set[dev]) {
       if (hipFuncSetAttribute((const void*)conv3x3_wstat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         tpgsr_set_error("tpgsr_conv_fwd: cannot reserve %zu bytes of LDS", lds);
         return TPGSR_ERR_LAUNCH;
       }
-      attr_set = true;
+      attr_set[dev] = true;
     }
     const int rows = (int)(M / 64);
-    hipLaunchKernelGGL(conv3x3_wstat_kernel, dim3((rows + 2) / 3), dim3(768), lds, st, *a, zero_page, (int)M);
+    hipLaunchKernelGGL(conv3x3_wstat_kernel, dim3((rows + 2) / 3), dim3(768), lds, st, *a, zero_page[dev], (int)M);
     TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd");
   }
   vecB = vecB && ((a->wt_ld & 3) == 0) && ((a->wt_coff & 3) == 0);
