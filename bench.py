@@ -1,19 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- training throughput of the TPGSR-TSRN hot path on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], "C2"): TSRN (STN + mask, srb 5, hidden 32) fp32, batch 48 per GPU, 16x64 -> 32x128
-synthetic crops, one FULL training step = forward + ImageLoss(gradient) + backward + [RCCL all-reduce of the flat
-gradient arena] + clip_grad_norm_(0.25) + Adam -- all hand-written HIP kernels behind libtpgsr_hip.so.
+Default workload = the configuration the metric is quoted on, BASELINE.json configs[2] ("C3", = the `north_star` target
+"TPGSR-TSRN training step, bs=48/GPU, 16x64 -> 32x128"): TSRN_TL (STN + mask, srb 5, hidden 32) + frozen teacher CRNN +
+one student CRNN (text prior, stu_iter 1), batch 48 per GPU, one FULL training step of
+interfaces/super_resolution.py:295-424 = teacher forward, student forward, softmax / distill loss / prior + prior dropout,
+SR forward, ImageLoss(gradient), backward through SR net and student, [RCCL all-reduce of the flat gradient buffer in two
+buckets, the SR bucket overlapped with the student backward], clip_grad_norm_(0.25) on the SR net, one Adam over SR net +
+student -- all hand-written HIP kernels behind libtpgsr_hip.so.  `--gpus N` runs the same step data-parallel (= C4).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `value` = whole-job img/s with inputs resident in HBM.  `roofline` is measured live
-with HIP events around the dominant kernel's launches (the fp32-MFMA implicit-GEMM conv) on the stream they run on;
-`cpu_baseline` times the CPU oracle (oracle/tpgsr_oracle.py, a port of the reference's step) on this box's host cores
-(rank 0, N=1 only, bounded sample)."""
+  --config c2: TSRN without text prior (BASELINE configs[1], fp32)       --config c5: stu_iter 3, sr_share, bs 32 (configs[4])
+
+Prints ONE JSON line (rank 0).  `value` = whole-job img/s with inputs resident in HBM.  `roofline` is measured live:
+the dominant kernel's launches (the MFMA implicit-GEMM conv: every conv / linear forward + data-gradient launch of the
+step, taken from the recorded plans of all networks) are replayed between HIP events on the stream they run on;
+`traffic` is null here (PMC counters need rocprofv3: the per-launch HBM bytes measured that way are in profiles/).
+`cpu_baseline` times the CPU oracle (oracle/tpgsr_oracle.py, a port of the reference's step pinned against the imported
+reference) on this box's host cores -- rank 0, N=1 only, a bounded sample."""
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -24,9 +31,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BATCH = 48
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (= the fp32 vector rate)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 LR_HW = (16, 64)
+
+# algorithmic bytes / FLOPs per image per training step (fp32 activations = 2x the bf16 figures)
+CONFIGS = {
+    "c2": dict(batch=48, stu_iter=1, tl=False, mb_per_img=58.8, gflop_per_img=5.5,
+               name="C2: TSRN (STN+mask, srb 5, hidden 32) fp32 train step: fwd + ImageLoss(gradient) + bwd + clip 0.25 + Adam"),
+    "c3": dict(batch=48, stu_iter=1, tl=True, mb_per_img=84.4, gflop_per_img=11.5,
+               name="C3: TPGSR-TSRN = TSRN_TL (STN+mask) + CRNN teacher/student text prior, stu_iter 1, full train step "
+                    "(teacher fwd, student fwd+bwd, distill loss, prior dropout, SR fwd+bwd, ImageLoss(gradient), clip 0.25, Adam)"),
+    "c5": dict(batch=32, stu_iter=3, tl=True, mb_per_img=242.0, gflop_per_img=31.7,
+               name="C5: TPGSR-TSRN multi-stage, stu_iter 3, sr_share, three CRNN students + frozen teacher, full train step"),
+}
+DOMINANT = ("tpgsr_conv_fwd", "tpgsr_conv_fwd_bf")   # forward + data-gradient instances of the MFMA implicit-GEMM conv
 
 
 def synthetic_batch(n, seed, device):
@@ -42,19 +61,50 @@ def synthetic_batch(n, seed, device):
     return add_mask(lr).contiguous().to(device), add_mask(hr).contiguous().to(device)
 
 
-def conv_roofline(eng, N, H, W, reps=5):
-    """Replay only the conv_fwd launches (forward + data-gradient instances of the MFMA implicit-GEMM kernel) of one
-    training step, bracketed by HIP events on the launch stream; algorithmic FLOPs = 2*M*K*Cout per launch."""
-    from tpgsr_amd._lib import ConvArgs
-    pl = eng.plans(N, H, W, True)
-    ops = []
-    flops = 0.0
-    for plan in (pl["fwd"], pl["bwd"]):
-        for name, fn, args, _sid in plan.ops:
-            if name == "tpgsr_conv_fwd":
-                a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
-                flops += 2.0 * (a.N * a.OH * a.OW) * (a.KH * a.KW * a.Cin) * a.Cout
-                ops.append((fn, args))
+def build_step(cfg_key, dev, world=1, pg=None):
+    """networks (weights by recipe: no pretrained files exist) + the train-step driver of the chosen configuration"""
+    from oracle import tpgsr_oracle as O  # weights-by-recipe only (no oracle compute in the timed path)
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep, TSRNTrainStep
+    from tpgsr_amd.model import tsrn
+    from tpgsr_amd.model.crnn import crnn
+    cfg = CONFIGS[cfg_key]
+    if not cfg["tl"]:
+        net = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
+        net.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 1234, tps_hw=LR_HW))
+        net = net.to(dev).train()
+        ts = TSRNTrainStep(net, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
+                           process_group=pg, world_size=world)
+        return ts, [net]
+    sr = tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
+    sr.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 11, tps_hw=LR_HW))
+    teacher = crnn.CRNN(32, 1, 37, 256)
+    teacher.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 12))
+    students = []
+    for k in range(cfg["stu_iter"]):
+        s = crnn.CRNN(32, 1, 37, 256)
+        s.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 13 + k))
+        students.append(s.to(dev).train())
+    ts = TPGSRTrainStep([sr.to(dev).train()], students, teacher.to(dev).eval(), stu_iter=cfg["stu_iter"], sr_share=True,
+                        tpg_share=False, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
+                        process_group=pg, world_size=world)
+    return ts, [sr] + students + [teacher]
+
+
+def conv_roofline(nets, reps=5):
+    """Replay only the dominant kernel's launches (forward + data-gradient instances of the MFMA implicit-GEMM conv) of one
+    training step -- every recorded plan of every network -- bracketed by HIP events on the launch stream;
+    algorithmic FLOPs = 2*M*K*Cout per launch from the recorded launch geometry."""
+    ops, flops, by_kernel = [], 0.0, {}
+    for net in nets:
+        for pl in net._engine()._plans.values():
+            for plan in (pl["fwd"], pl["bwd"]):
+                for name, fn, args, _sid in plan.ops:
+                    if name in DOMINANT:
+                        a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
+                        f = 2.0 * (a.N * a.OH * a.OW) * (a.KH * a.KW * a.Cin) * a.Cout
+                        flops += f
+                        ops.append((fn, args))
+                        by_kernel[name] = by_kernel.get(name, 0) + 1
     s = torch.cuda.current_stream().cuda_stream
     for fn, args in ops:      # warm
         fn(*args, s)
@@ -67,7 +117,7 @@ def conv_roofline(eng, N, H, W, reps=5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    return dict(launches=len(ops), flops_per_step=flops, ms_per_step=ms,
+    return dict(launches=len(ops), flops_per_step=flops, ms_per_step=ms, by_entry_point=by_kernel,
                 avg_us_per_launch=1e3 * ms / len(ops), tflops=flops / (ms * 1e-3) / 1e12)
 
 
@@ -90,40 +140,50 @@ def mfma_probe_tflops():
     return blocks * 4 * 2.0 * iters * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
-def cpu_baseline_subprocess(timeout_s=150):
+def cpu_baseline_subprocess(cfg_key, timeout_s=240):
     """Run the CPU-oracle timing in a child process with a hard timeout (a mis-sized thread pool must never stall the bench)."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
-                           timeout=timeout_s)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", cfg_key],
+                           capture_output=True, text=True, timeout=timeout_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:  # timeout / parse failure: report, never hide
         return {"value": None, "unit": "img/s", "cores": None, "kind": "port", "sample": f"cpu baseline failed: {type(e).__name__}: {e}"[:200]}
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(cfg_key, seconds_budget=25.0, max_steps=6):
+    """The oracle's train step of the same configuration on the host cores (same batch size, same synthetic inputs)."""
     from oracle import tpgsr_oracle as O
     try:
         ncores = len(os.sched_getaffinity(0))
     except Exception:
         ncores = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(ncores, 64)))
-    sd = O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 1234, tps_hw=LR_HW)
-    p = O.as_params(sd)
-    opt = O.AdamState([p[k] for k in O.trainable_keys(p)])
-    lr, hr = O.synthetic_batch(BATCH, 1234)
-    O.tsrn_train_step(p, opt, lr, hr)          # warm-up
+    cfg = CONFIGS[cfg_key]
+    B = cfg["batch"]
+    lr, hr = O.synthetic_batch(B, 1234)
+    if not cfg["tl"]:
+        p = O.as_params(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 1234, tps_hw=LR_HW))
+        opt = O.AdamState([p[k] for k in O.trainable_keys(p)])
+        step = lambda: O.tsrn_train_step(p, opt, lr, hr)
+    else:
+        ps = O.as_params(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 11, tps_hw=LR_HW))
+        pt = O.as_params(O.recipe_state_dict(O.crnn_spec(), 12), False)
+        pu = [O.as_params(O.recipe_state_dict(O.crnn_spec(), 13 + k)) for k in range(cfg["stu_iter"])]
+        opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
+        step = lambda: O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=cfg["stu_iter"], sr_share=True, tpg_share=False)
+    step()          # warm-up
     t0 = time.perf_counter()
     n = 0
     while True:
-        O.tsrn_train_step(p, opt, lr, hr)
+        step()
         n += 1
-        if time.perf_counter() - t0 > seconds_budget or n >= 8:
+        if time.perf_counter() - t0 > seconds_budget or n >= max_steps:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(BATCH * n / dt, 2), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full C2 train steps (bs {BATCH}) of oracle/tpgsr_oracle.py on the host CPU, {dt:.1f} s"}
+    return {"value": round(B * n / dt, 2), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full {cfg_key.upper()} train steps (bs {B}) of oracle/tpgsr_oracle.py on the host CPU, {dt:.1f} s"}
 
 
 def main():
@@ -131,16 +191,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as a captured hipGraph (default: plain launches on two HIP streams; measured faster "
-                         "because ROCm executes the graph's fork/join branches serially)")
-    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)   # old spelling of the default
+                    help="replay the step as a captured hipGraph (default: plain launches on several HIP streams; measured "
+                         "faster because ROCm executes the graph's fork/join branches serially)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()), flush=True)
+        print(json.dumps(cpu_baseline(args.config)), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,22 +217,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
-    from tpgsr_amd.model import tsrn
-    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
-    from oracle import tpgsr_oracle as O  # weights-by-recipe only (no oracle compute in the timed path)
-
+    cfg = CONFIGS[args.config]
+    B = cfg["batch"]
     torch.manual_seed(0)
-    net = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
-    net.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 1234, tps_hw=LR_HW))
-    net = net.to(dev).train()
-    ts = TSRNTrainStep(net, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
-                       process_group=pg, world_size=world)
+    ts, nets = build_step(args.config, dev, world, pg)
     ts.broadcast_parameters(0)
-    lr_img, hr_img = synthetic_batch(BATCH, 1234 + rank, dev)
+    lr_img, hr_img = synthetic_batch(B, 1234 + rank, dev)
 
-    use_graph = args.graph and not args.no_graph
-    _log(f"rank {rank}/{world}: model on {dev}, capturing={use_graph}")
-    if use_graph:
+    _log(f"rank {rank}/{world}: {args.config} on {dev}, capturing={args.graph}")
+    if args.graph:
         ts.capture(lr_img, hr_img, warmup=2)
         step = lambda: ts.replay()
     else:
@@ -206,43 +259,38 @@ def main():
     out = None
     if rank == 0:
         ms = 1e3 * dt / args.steps
-        value = BATCH * world * args.steps / dt
-        eng = net._engine()
+        value = B * world * args.steps / dt
+        n_launch = sum(len(p) for m in nets for pl in m._engine()._plans.values() for p in (pl["fwd"], pl["bwd"]))
         out = {
-            "metric": "training img/s (16x64->32x128, bs=48/GPU), TSRN STN+mask fp32 full train step",
+            "metric": "training img/s (16x64->32x128, bs=%d/GPU), %s full train step" % (B, "TPGSR-TSRN" if cfg["tl"] else "TSRN"),
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: TSRN (STN+mask, srb 5, hidden 32) fp32 train step: fwd + ImageLoss(gradient) + bwd + "
-                                   "clip 0.25 + Adam", "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+            "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay" if use_graph else "recorded plan, plain launches: main stream + weight-gradient stream",
-                       "kernel_launches_per_step": len(eng.plans(BATCH, *LR_HW, True)["fwd"]) + len(eng.plans(BATCH, *LR_HW, True)["bwd"])},
+                       "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
+                       "kernel_launches_per_step": n_launch,
+                       "gradient_exchange": None if world == 1 else "one flat fp32 buffer, 2 RCCL all-reduce buckets (SR net overlapped with the student backward)"},
             "final_loss": round(final_loss, 5),
         }
         _log(f"timed region done: {ms:.3f} ms/step")
         if not args.no_roofline:
-            r = conv_roofline(eng, BATCH, *LR_HW)
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"kernel": "conv_fwd_kernel<true> (fp32-MFMA implicit GEMM: all conv/linear fwd + dgrad launches)",
+            r = conv_roofline(nets)
+            out["roofline"] = {"kernel": "MFMA implicit-GEMM conv (all conv / linear forward + data-gradient launches of the step: "
+                                         "SR net, student and teacher recognisers)",
                                "bound": "mfma", "achieved": round(r["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(r["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "launches_per_step": r["launches"], "avg_us_per_launch": round(r["avg_us_per_launch"], 2),
+                               "unit": "TFLOP/s", "frac": round(r["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": r["launches"], "by_entry_point": r["by_entry_point"],
+                               "avg_us_per_launch": round(r["avg_us_per_launch"], 2),
                                "gflop_per_launch": round(r["flops_per_step"] / r["launches"] / 1e9, 4),
                                "share_of_step_ms": round(r["ms_per_step"], 4),
                                "measured_mfma_only_peak": round(mfma_probe_tflops(), 1)}
-            # whole-step view against SURVEY 8d's algorithmic constants (58.8 MB, 5.5 GFLOP per image per C2 step)
-            out["step_roofline"] = {"hbm_frac": round(value / world * 58.8e6 / 8.0e12, 4),
-                                    "fp32_flop_frac": round(value / world * 5.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)}
+            # whole-step view against SURVEY 8d's algorithmic constants (fp32 bytes / FLOPs per image per step)
+            out["step_roofline"] = {"hbm_frac": round(value / world * cfg["mb_per_img"] * 1e6 / 8.0e12, 4),
+                                    "fp32_flop_frac": round(value / world * cfg["gflop_per_img"] * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)}
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
-            out["cpu_baseline"] = cpu_baseline_subprocess()
+            out["cpu_baseline"] = cpu_baseline_subprocess(args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

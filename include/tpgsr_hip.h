@@ -115,6 +115,9 @@ typedef struct tpgsr_wgrad_reduce_desc {
   int Z, K, Cin, Cout, KH, KW, layout, accumulate;
   float gscale;
   int blk0;
+  int cin_ld;             /* slab row k = tap*cin_ld + ci (0 = Cin); rows with ci >= Cin or tap >= KH*KW (K may exceed
+                             KH*KW*cin_ld) belong to a zero-padded operand and are skipped */
+  int reserved;
 } tpgsr_wgrad_reduce_desc;
 int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias);
 int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_dev, int ndesc, int total_blocks, void* stream);
@@ -130,7 +133,8 @@ int tpgsr_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, in
 int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, float* wt_d, void* stream);
 
 /* All operand packing of a model in ONE launch: a device-resident table of descriptors.
- *   kind 0: conv/linear weight [Cout][Cin][KH][KW] -> dst_f[k*f_ld + f_coff + co] and/or dst_d (dgrad operand)
+ *   kind 0: conv/linear weight [Cout][Cin][KH][KW] -> dst_f[k*f_ld + f_coff + co] and/or dst_d (dgrad operand;
+ *           rows of d_ld floats when d_ld > 0, columns >= Cin untouched: allocate zero-filled)
  *   kind 1: tail conv [Co][C][KS][KS] folded (Cout = Co, KH = KW = KS)     kind 2: plain copy of numel floats
  *   kind 3: ConvTranspose2d weight [Cin][Cout][KH][KW] as its equivalent conv
  *   kind 4: ConvTranspose2d weight [Cin][Cout][3][3] on an H=1 strip -> 1x3 conv operand (kh=1 slice, taps flipped)
@@ -149,6 +153,8 @@ typedef struct {
   int numel, blk0;
   const float* src2;
   const float* src3;
+  int d_ld;               /* kinds 0/3/4: row stride of dst_d (0 = Cin): a zero-padded dgrad operand */
+  int cin_ld;             /* kinds 0/3/4: channel stride of dst_f's k index, k = tap*cin_ld + ci (0 = Cin): zero-padded input channels */
 } tpgsr_pack_desc;
 /* Chain rule of the composed GruBlock operand, for many blocks in one launch.  Given dWc [2*G][Cin] / dbc [2*G] (the
  * weight / bias gradient of the composed 1x1 conv, both directions stacked, G = 96):
@@ -283,6 +289,13 @@ int tpgsr_hsum(const float* d, int N, int H, int W, int C, float* dstrip, int ac
  * in: NCHW [N][Ctot>=3][H][W]  ->  out [N][OH][OW] (= NHWC with C = 1).  bwd: adjoint into din (NCHW, zero-filled here). */
 int tpgsr_bicubic_gray_fwd(const float* in_nchw, int N, int Ctot, int H, int W, int OH, int OW, float* out, void* stream);
 int tpgsr_bicubic_gray_bwd(const float* dout, int N, int Ctot, int H, int W, int OH, int OW, float* din_nchw, void* stream);
+/* CRNN conv0 (nn.Conv2d(1, 64, 3, 1, 1), model/crnn/crnn.py:45-46) as a 1x1 conv over a 12-channel neighbourhood map:
+ * col[n][y][x][kh*3+kw] = in[n][y+kh-1][x+kw-1] (zero padded; channels 9..11 = 0); col2im is its gather-form adjoint. */
+int tpgsr_im2col3x3_c1(const float* in, int N, int H, int W, float* col /* [N*H*W][12] */, void* stream);
+int tpgsr_col2im3x3_c1(const float* dcol, int N, int H, int W, float* din, void* stream);
+/* dst[m][c] = c < Cs ? src[m][c] : 0: pads the 37-class tensors (logits gradient, text prior) to 40 channels so their
+ * consumers (Linear(512,37) crnn.py:12, InfoGen tconv1 tsrn.py:89) run on the 16-byte loaders */
+int tpgsr_pad_channels(const float* src, long long M, int Cs, int Cd, float* dst, void* stream);
 /* nn.MaxPool2d((KH,KW),(SH,SW),(PH,PW)) of act(scale*x+shift), NHWC; bwd returns d(pre-activation) (first arg-max wins) */
 int tpgsr_pool2d_fwd(const float* x, int N, int H, int W, int C, const float* scale, const float* shift, int act, int KH,
                      int KW, int SH, int SW, int PH, int PW, float* out, void* stream);
@@ -309,6 +322,10 @@ int tpgsr_softmax_prior_fwd(const float* logits, const float* q, int N, int T, i
 int tpgsr_semantic_loss_finalize(const float* partial, int nblk, long long count, float w, float* loss, void* stream);
 int tpgsr_softmax_prior_bwd(const float* p, const float* q, const float* dprior_nchw, const float* dp_in, int N, int T, int C,
                             int drop_n, float wsem, float* dlogits, int nblk, void* stream);
+/* SemanticLoss.forward(pred, gt) on probability tensors (loss/semantic_loss.py:21-39, the nn.Module entry point):
+ * partial [nblk][2] = (sum|q-p|, sum q'(log q' - log p')) -> tpgsr_semantic_loss_finalize; bwd: dp = dloss*(-sign(q-p) - q'/p')/n */
+int tpgsr_semantic_loss_fwd(const float* p, const float* q, long long n, float* partial, int nblk, void* stream);
+int tpgsr_semantic_loss_bwd(const float* p, const float* q, const float* dloss, long long n, float* dp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tail: out = tanh(bias + sum_kw P[h][w+kw-4][kw][co])  (model/tsrn.py:159,213), NCHW output

@@ -31,17 +31,38 @@ def test_parse_crnn_data_kernel(golden_dir):
     K.bicubic_gray_fwd(hr, N, C, H, W, 32, 100, out)
     torch.cuda.synchronize()
     assert (out.cpu() - torch.tensor(g["gray"])).abs().max() < 2e-6
-    # adjoint vs autograd
-    x = torch.rand(2, 4, 16, 64)
-    xr = x.clone().requires_grad_(True)
-    y = O.parse_crnn_data(xr)
-    gy = torch.randn(y.shape)
-    y.backward(gy)
-    din = torch.empty(2, 4, 16, 64, device=DEV)
-    gyd = gy.to(DEV).contiguous()
-    K.bicubic_gray_bwd(gyd, 2, 4, 16, 64, 32, 100, din)
-    torch.cuda.synchronize()
-    assert (din.cpu() - xr.grad).abs().max() < 1e-5
+    # adjoint (gather form, deterministic) vs autograd: the LR geometry (up-sampling) and the SR geometry of the later
+    # cascade stages (32x128 -> 32x100, the only place the training step runs it), plus odd sizes that hit the border clamps
+    for (n, c, h, w) in [(2, 4, 16, 64), (3, 4, 32, 128), (1, 3, 7, 11), (2, 3, 40, 250)]:
+        x = torch.rand(n, c, h, w)
+        xr = x.clone().requires_grad_(True)
+        y = O.parse_crnn_data(xr)
+        gy = torch.randn(y.shape)
+        y.backward(gy)
+        din = torch.full((n, c, h, w), 7.0, device=DEV)            # the kernel owns every element (no pre-zeroing)
+        din2 = torch.full((n, c, h, w), -3.0, device=DEV)
+        gyd = gy.to(DEV).contiguous()
+        K.bicubic_gray_bwd(gyd, n, c, h, w, 32, 100, din)
+        K.bicubic_gray_bwd(gyd, n, c, h, w, 32, 100, din2)
+        torch.cuda.synchronize()
+        assert (din.cpu() - xr.grad).abs().max() < 2e-5, (n, c, h, w)
+        assert torch.equal(din, din2)                              # no atomics: bitwise reproducible
+
+
+def test_semantic_loss_module_on_probabilities(golden_dir):
+    """SemanticLoss.forward / backward as kernels on probability tensors, incl. rows that do NOT sum to 1"""
+    from tpgsr_amd.loss.semantic_loss import SemanticLoss
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    p_ref, q = torch.tensor(g["p"]), torch.tensor(g["q"])
+    for scale in (1.0, 0.7):
+        pr = (p_ref * scale).clone().requires_grad_(True)
+        ref = O.semantic_loss(pr, q)
+        ref.backward()
+        pd = (p_ref * scale).to(DEV).requires_grad_(True)
+        out = SemanticLoss()(pd, q.to(DEV))
+        (out * 3.0).backward()
+        assert abs(out.item() - ref.item()) < 2e-6 * abs(ref.item())
+        assert (pd.grad.cpu() / 3.0 - pr.grad).abs().max() < 1e-5 * pr.grad.abs().max()
 
 
 @pytest.mark.parametrize("cfg", [((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))])
@@ -264,8 +285,7 @@ def test_cascade_two_stages_vs_oracle():
     opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
     ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=2, sr_share=True, tpg_share=False, stn=False)
     ts = TPGSRTrainStep(srs, stus, teacher, stu_iter=2, sr_share=True, tpg_share=False)
-    for m in srs + stus:
-        m._engine().bind(torch.device(DEV, 0))
+    ts.pool.bind(torch.device(DEV, 0))
     teacher._engine().bind(torch.device(DEV, 0))
     loss = ts._phase_a(lr.to(DEV), hr.to(DEV))            # forward + backward only (no optimiser): raw gradients
     torch.cuda.synchronize()

@@ -85,3 +85,74 @@ def test_two_rank_exchange_matches_gradient_accumulation():
         acc = gr if acc is None else acc + gr
     acc /= 2
     assert (acc - g0).abs().max() <= 1e-5 * acc.abs().max()
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tpgsr_amd.distributed import GradientExchanger
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(1000, generator=g)
+    mine = flat.clone()
+    ex = GradientExchanger(flat, [(0, 384), (384, 1000)], None)
+    ex.launch(0)                       # the SR-net bucket leaves while "the student backward" still writes bucket 1
+    flat[384:] += 1.0
+    try:
+        ex.launch(0)
+        twice = False
+    except RuntimeError:
+        twice = True
+    ex.finish()                        # launches bucket 1, waits for both, averages
+    ex.launch(0)                       # next step: buckets can be launched again
+    ex.finish()
+    q.put((rank, mine, flat.clone(), twice))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_overlapped_exchange_two_ranks():
+    """GradientExchanger (the host logic of TPGSRTrainStep._exchange): early launch of bucket 0, late bucket 1, average,
+    re-usable every step; both ranks end with identical buffers = the mean of their inputs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+    (_, a0, f0, tw0), (_, a1, f1, tw1) = res
+    assert tw0 and tw1, "launching a bucket twice in one step must raise"
+    want = (a0 + a1) / 2
+    want[384:] += 1.0
+    # second exchange of already identical buffers is the identity
+    assert torch.equal(f0, f1)
+    assert (f0 - want).abs().max() < 1e-6
+
+
+def test_arena_pool_and_dataparallel_wrapper_cpu():
+    """ArenaPool layout (contiguous, 256-byte aligned slices, SR nets before students) and the .module-exposing wrapper's
+    state_dict prefix -- host logic only, no kernels (the engines bind lazily on the GPU)."""
+    sys.path.insert(0, ROOT)
+    from tpgsr_amd.distributed import DataParallel
+    from tpgsr_amd.engine import ArenaPool, ParamArena
+    from tpgsr_amd.model import tsrn
+    from tpgsr_amd.model.crnn import crnn
+    sr = tsrn.TSRN_TL(STN=True, mask=True)
+    stu = crnn.CRNN(32, 1, 37, 256)
+    pool = ArenaPool([sr, stu, sr])                     # duplicates collapse (sr_share)
+    assert len(pool.modules) == 2
+    n_sr = ParamArena(sr).layout()[1]
+    n_stu = ParamArena(stu).layout()[1]
+    assert n_sr >= sum(p.numel() for p in sr.parameters()) and n_sr % 4 == 0
+    assert n_stu >= sum(p.numel() for p in stu.parameters())
+    dp = DataParallel(sr)
+    assert dp.module is sr
+    keys = list(dp.state_dict().keys())
+    assert keys and all(k.startswith("module.") for k in keys)
+    assert [k[len("module."):] for k in keys] == list(sr.state_dict().keys())   # save_checkpoint's netG.module.state_dict()

@@ -528,3 +528,54 @@ def test_clip_and_adam():
         torch.cuda.synchronize()
         assert abs(nrm.item() - tot.item()) < 1e-4 * tot.item()
         assert (pd.cpu() - pr).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("N,H,dgrad,bias,bn,concat", [(2, 5, False, True, True, False), (1, 16, True, False, False, False),
+                                                       (3, 7, False, True, True, True), (2, 3, True, True, False, True)])
+def test_conv3x3_wstat_kernel_direct(N, H, dgrad, bias, bn, concat, monkeypatch):
+    """The weights-stationary kernel of the 64-channel 3x3 trunk convs in isolation: N*H not divisible by
+    3 (ragged last workgroup), concat-style in_ld / in_coff and out_ld / out_coff, with and without bias and BN partials,
+    forward and data-gradient geometry -- against the fp64 restatement AND against the tile-loop kernel (TPGSR_CONV_WSTAT
+    is read once per process, so the comparison kernel is reached through a shape the fast path rejects: a residual add of zeros)."""
+    from tpgsr_amd import kernels as K
+    W, C = 64, 64
+    g = torch.Generator().manual_seed(N * 100 + H)
+    in_ld, in_coff = (96, 32) if concat else (64, 0)
+    out_ld, out_coff = (128, 64) if concat else (64, 0)
+    xfull = torch.randn(N * H * W, in_ld, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(C, generator=g) if bias else None
+    x = xfull[:, in_coff:in_coff + C].reshape(N, H, W, C).permute(0, 3, 1, 2).double()
+    if not dgrad:
+        ref = F.conv2d(x, w.double(), None, padding=1)
+        wt = w.permute(2, 3, 1, 0).reshape(9 * C, C).contiguous()                 # [(kh*3+kw)*Cin+ci][co]
+    else:   # data gradient of a conv with weight w: conv of dy with the flipped, transposed taps
+        ref = F.conv_transpose2d(x, w.double(), None, padding=1)
+        wt = w.flip(2, 3).permute(2, 3, 0, 1).reshape(9 * C, C).contiguous()      # [((2-kh)*3+(2-kw))*Cout+co][ci]
+    ref_nb = ref.permute(0, 2, 3, 1).reshape(-1, C)
+    xd, wd = xfull.to(DEV), wt.to(DEV)
+    bd = b.to(DEV) if bias else None
+    geom = K.ConvGeom(N, H, W, C, C, 3, 3, 1, 1)
+    outs = []
+    for force_tile_loop in (False, True):
+        out = torch.full((N * H * W, out_ld), 9.0, device=DEV)
+        nblk = (N * H * W + 63) // 64
+        part = torch.zeros(nblk, 2, C, device=DEV) if bn else None
+        kw = dict(bias=bd, in_ld=in_ld, in_coff=in_coff, out_ld=out_ld, out_coff=out_coff, bn_partial=part)
+        if force_tile_loop:
+            kw["in2"] = torch.zeros(N * H * W, C, device=DEV)
+        K.conv_fwd(K.make_conv_args(geom, xd, wd, out, **kw))
+        torch.cuda.synchronize()
+        got = out[:, out_coff:out_coff + C].cpu().double()
+        want = ref_nb + (b.double() if bias else 0.0)
+        assert (got - want).abs().max() < 2e-4 * max(1.0, want.abs().max().item())
+        if concat:
+            assert (out[:, :out_coff] == 9.0).all()            # neighbouring channels untouched
+        if bn:
+            s = part.sum(0).cpu().double()
+            assert (s[0] - ref_nb.sum(0)).abs().max() < 1e-3 * ref_nb.abs().sum(0).max()
+            assert (s[1] - (ref_nb ** 2).sum(0)).abs().max() < 1e-3 * (ref_nb ** 2).sum(0).max()
+        outs.append((got, part.clone() if bn else None))
+    assert (outs[0][0] - outs[1][0]).abs().max() < 2e-5 * max(1.0, outs[1][0].abs().max().item())
+    if bn:   # same [row block][2][C] layout from both kernels
+        assert (outs[0][1] - outs[1][1]).abs().max() < 1e-3 * outs[1][1].abs().max()

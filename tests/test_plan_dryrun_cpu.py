@@ -1,0 +1,91 @@
+"""CPU: the plan-recording host logic of every engine / train-step driver, without a GPU (TPGSR_PLAN_DRYRUN=1, see
+tpgsr_amd/kernels.py): each wrapper's argument list is checked against the C-ABI signature, the recorded plans are handed
+to the native executor (entry point + argument count), and the recorded launch geometry is inspected -- nothing is
+computed.  Runs in a subprocess so the dry-run switch never leaks into other tests."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+SCRIPT = r'''
+import json, sys, torch
+sys.path.insert(0, %(root)r)
+from oracle import tpgsr_oracle as O
+from tpgsr_amd import kernels as K
+assert K.DRYRUN
+from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep, TSRNTrainStep
+from tpgsr_amd.model import tsrn
+from tpgsr_amd.model.crnn import crnn
+
+def conv_stats(nets):
+    n, scalar, names = 0, [], {}
+    for net in nets:
+        for pl in net._engine()._plans.values():
+            for plan in [v for k, v in pl.items() if k != "ws"]:
+                if len(plan):
+                    plan.run()                      # builds the native plan: validates symbol + argument count
+                for name, fn, args, sid in plan.ops:
+                    names[name] = names.get(name, 0) + 1
+                    if name in ("tpgsr_conv_fwd", "tpgsr_conv_wgrad"):
+                        a = args[0]._obj
+                        c = a.c if name == "tpgsr_conv_wgrad" else a
+                        n += 1
+                        wld = c.wt_ld if c.wt_ld > 0 else c.Cout
+                        if c.Cin %% 4 != 0 or (name == "tpgsr_conv_fwd" and wld %% 4 != 0) or \
+                           (name == "tpgsr_conv_wgrad" and not a.dy_ps and a.dy_ld %% 4 != 0):
+                            scalar.append((name, c.Cin, c.Cout, c.KH, c.KW))
+    return n, scalar, names
+
+out = {}
+N = 4
+lr, hr = O.synthetic_batch(N, 1)
+# C2
+net = tsrn.TSRN(STN=True, mask=True).train()
+ts = TSRNTrainStep(net)
+ts.step(lr, hr)
+out["c2"] = conv_stats([net])
+# C3 / C5 shape
+sr = tsrn.TSRN_TL(STN=True, mask=True).train()
+teacher = crnn.CRNN(32, 1, 37, 256).eval()
+stus = [crnn.CRNN(32, 1, 37, 256).train() for _ in range(3)]
+ts = TPGSRTrainStep([sr], stus[:1], teacher, stu_iter=1)
+ts.step(lr, hr)
+out["c3"] = conv_stats([sr, stus[0], teacher])
+sr5 = tsrn.TSRN_TL(STN=True, mask=True).train()
+ts5 = TPGSRTrainStep([sr5], stus, teacher, stu_iter=3, sr_share=True)
+ts5.step(lr, hr)
+out["c5"] = conv_stats([sr5] + stus + [teacher])
+out["pool"] = [ts5.pool.flat.numel(), sum(ts5.pool.ranges[id(m)][1] - ts5.pool.ranges[id(m)][0] for m in ts5.pool.modules)]
+# parameters are views of ONE buffer, SR net first
+base = ts5.pool.flat.data_ptr()
+out["views"] = all(base <= p.data_ptr() < base + 4 * ts5.pool.flat.numel() for m in [sr5] + stus for p in m.parameters())
+out["sr_first"] = ts5.pool.ranges[id(sr5)][0] == 0
+# module API (autograd) in dry-run: slots are acquired and released
+x = lr.clone()
+y = sr5(x, torch.zeros(N, 37, 1, 26))
+y.sum().backward()
+out["live_after_bwd"] = len(sr5._engine()._live)
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.timeout(600)
+def test_record_all_plans_without_gpu():
+    env = dict(os.environ, TPGSR_PLAN_DRYRUN="1")
+    r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT)], capture_output=True, text=True, env=env, timeout=550)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for cfg in ("c2", "c3", "c5"):
+        n, scalar, names = res[cfg]
+        assert n > 50
+        # no MFMA GEMM of the training step is left on the scalar (dword-gather) loaders: 1-channel and 37-class operands
+        # are zero-padded / im2col'ed to multiples of 4 (CRNN conv0, Linear(512,37), InfoGen tconv1)
+        assert scalar == [], (cfg, scalar)
+    assert res["c3"][2].get("tpgsr_im2col3x3_c1", 0) == 2          # student + teacher conv0
+    assert res["c3"][2].get("tpgsr_pad_channels", 0) >= 2          # prior 37 -> 40, dlogits 37 -> 40
+    assert res["pool"][0] >= res["pool"][1] and res["views"] and res["sr_first"]
+    assert res["live_after_bwd"] == 0

@@ -39,7 +39,7 @@ class WgradArgs(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst_f", vp), ("dst_d", vp), ("Cout", ci), ("Cin", ci), ("KH", ci), ("KW", ci),
                 ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci),
-                ("src2", vp), ("src3", vp)]
+                ("src2", vp), ("src3", vp), ("d_ld", ci), ("cin_ld", ci)]
 
 
 class ComposeBwdDesc(C.Structure):
@@ -49,7 +49,8 @@ class ComposeBwdDesc(C.Structure):
 
 class WgradReduceDesc(C.Structure):
     _fields_ = [("part", vp), ("dbpart", vp), ("dw", vp), ("db", vp), ("Z", ci), ("K", ci), ("Cin", ci), ("Cout", ci),
-                ("KH", ci), ("KW", ci), ("layout", ci), ("accumulate", ci), ("gscale", cf), ("blk0", ci)]
+                ("KH", ci), ("KW", ci), ("layout", ci), ("accumulate", ci), ("gscale", cf), ("blk0", ci), ("cin_ld", ci),
+                ("reserved", ci)]
 
 
 class PlanArg(C.Union):
@@ -129,6 +130,11 @@ _SIGS = {
     "tpgsr_adam_step": (ci, [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]),
     "tpgsr_step_inc": (ci, [vp, vp]),
     "tpgsr_scale_": (ci, [vp, ll, vp, vp]),
+    "tpgsr_im2col3x3_c1": (ci, [vp, ci, ci, ci, vp, vp]),
+    "tpgsr_col2im3x3_c1": (ci, [vp, ci, ci, ci, vp, vp]),
+    "tpgsr_pad_channels": (ci, [vp, ll, ci, ci, vp, vp]),
+    "tpgsr_semantic_loss_fwd": (ci, [vp, vp, ll, vp, ci, vp]),
+    "tpgsr_semantic_loss_bwd": (ci, [vp, vp, vp, ll, vp, vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["tpgsr_last_error"])

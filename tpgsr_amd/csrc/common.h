@@ -35,24 +35,26 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- activations -----------------------------------------------------------------------------------------------
-// One exponential + one reciprocal per value; every form below is cancellation-free, so the results stay within a
-// few fp32 ulp of ATen's softplus/tanh/sigmoid compositions:
+// One exponential + one reciprocal per value, within a few fp32 ulp of ATen's softplus/tanh/sigmoid compositions:
 //   e = exp(x),  n = e*(e+2):   tanh(softplus(x)) = n/(n+2)        (softplus threshold 20 as in F.softplus)
-//   sigmoid(x) = 1/(1+exp(-x)),  tanh(x) = sign(x)*(1-q)/(1+q), q = exp(-2|x|)
+//   sigmoid(x) = 1/(1+exp(-x)),  tanh(x) = sign(x) * -expm1(-2|x|) / (1+q), q = exp(-2|x|)
+// (1 - q would cancel for small |x|: relative error ~3e-4 at |x| = 1e-4; expm1 keeps full relative accuracy there)
 #ifndef TPGSR_FAST_MATH
 // default: libm-accurate exp + IEEE division.  Measured (tools/dbg/dbg_cascade.py): with v_exp_f32 / v_rcp_f32 the
 // gradient w.r.t. the text prior drifts 6e-4 from the oracle (20x the oracle's own fp32-vs-fp64 noise) and the
 // cascade amplifies it to percent level in the student gradients; with these it sits at 2.6e-5.
 __device__ __forceinline__ float fast_rcp(float x) { return 1.f / x; }
 #define TPGSR_EXP expf
+#define TPGSR_EXPM1 expm1f
 #else
 __device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
 #define TPGSR_EXP __expf
+#define TPGSR_EXPM1(x) (__expf(x) - 1.f)
 #endif
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.f + TPGSR_EXP(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {
-  float q = TPGSR_EXP(-2.f * fabsf(x));
-  float t = (1.f - q) * fast_rcp(1.f + q);
+  float em1 = TPGSR_EXPM1(-2.f * fabsf(x));   // q - 1, accurate near 0
+  float t = -em1 * fast_rcp(2.f + em1);      // (1 - q) / (1 + q)
   return copysignf(t, x);
 }
 __device__ __forceinline__ float mish_f(float x) {
@@ -66,8 +68,10 @@ __device__ __forceinline__ float mish_grad_f(float x) {
   if (x > 20.f) return 1.f;
   float e = TPGSR_EXP(x);
   float n = e * (e + 2.f);
-  float t = n * fast_rcp(n + 2.f);
-  float sg = e * fast_rcp(1.f + e);
+  float d1 = n + 2.f, d2 = 1.f + e;          // one division for both quotients (x <= 20: d1*d2 < 2e26, no overflow)
+  float r = fast_rcp(d1 * d2);
+  float t = n * d2 * r;
+  float sg = e * d1 * r;
   return t + x * (1.f - t * t) * sg;
 }
 

@@ -10,6 +10,7 @@
 // (lane l reads row k0 + (l>>5), column (l&31)).  fp32 in, fp32 accumulate: bit-for-bit an fmaf chain.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 // 1: all MFMA fragments of a K chunk are read from LDS before its first MFMA (one LDS round trip per chunk, +32 VGPRs:
 // 4 waves / SIMD); 0: the compiler interleaves read pairs with the MFMAs (6 waves / SIMD).  Measured on MI355X: equal
@@ -553,7 +554,8 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   int K = a->KH * a->KW * a->Cin;
   TPGSR_CHECK_ARG(M < (1ll << 31), "tpgsr_conv_fwd: M too large");
   dim3 grid(cdiv(M, BM) * cdiv(a->Cout, BN));
-  int vecB = ((a->Cout & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;
+  const int wld_ = a->wt_ld > 0 ? a->wt_ld : a->Cout;
+  int vecB = ((wld_ & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;   // rows padded to a multiple of 4 floats
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
   // the 64-channel 3x3 trunk convs on 64-wide maps: weights-stationary kernel (TPGSR_CONV_WSTAT=0 falls back to the tile loop)
@@ -562,33 +564,40 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
       a->W == 64 && a->OW == 64 && a->OH == a->H && a->in_dil_w <= 1 && a->stride_w <= 1 && !a->out_ps && a->out_act == TPGSR_ACT_NONE &&
       (a->wt_ld == 0 || a->wt_ld == 64) && a->wt_coff == 0 && (a->in_ld & 3) == 0 && (a->in_coff & 3) == 0 &&
       (((uintptr_t)a->in | (uintptr_t)a->wt) & 15) == 0) {
-    // per device: 256 B of zeros (source of the halo's padding pixels) and the opt-in to > 64 KB of dynamic LDS
+    // per device, set up once under a lock: 256 B of zeros (source of the halo's padding pixels; zeroed on the launch
+    // stream and waited for, so every later launch on any stream sees it) and the opt-in to > 64 KB of dynamic LDS
     static float* zero_page[64] = {nullptr};
-    static bool attr_set[64] = {false};
+    static std::mutex init_mu;
+    const size_t lds = sizeof(float) * WS_LDS_FLOATS;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
       tpgsr_set_error("tpgsr_conv_fwd: hipGetDevice failed");
       return TPGSR_ERR_LAUNCH;
     }
-    if (!zero_page[dev]) {
-      if (hipMalloc((void**)&zero_page[dev], 256) != hipSuccess || hipMemset(zero_page[dev], 0, 256) != hipSuccess) {
-        tpgsr_set_error("tpgsr_conv_fwd: zero page allocation failed");
-        return TPGSR_ERR_LAUNCH;
+    {
+      std::lock_guard<std::mutex> lock(init_mu);
+      if (!zero_page[dev]) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+          tpgsr_set_error("tpgsr_conv_fwd: first use of the weights-stationary conv on device %d happens inside a stream capture; "
+                          "run one eager step before capturing", dev);
+          return TPGSR_ERR_LAUNCH;
+        }
+        float* zp = nullptr;
+        if (hipMalloc((void**)&zp, 256) != hipSuccess || hipMemsetAsync(zp, 0, 256, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_wstat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          tpgsr_set_error("tpgsr_conv_fwd: zero page / %zu-byte LDS set-up failed", lds);
+          return TPGSR_ERR_LAUNCH;
+        }
+        zero_page[dev] = zp;
       }
-    }
-    const size_t lds = sizeof(float) * WS_LDS_FLOATS;
-    if (!attr_set[dev]) {
-      if (hipFuncSetAttribute((const void*)conv3x3_wstat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        tpgsr_set_error("tpgsr_conv_fwd: cannot reserve %zu bytes of LDS", lds);
-        return TPGSR_ERR_LAUNCH;
-      }
-      attr_set[dev] = true;
     }
     const int rows = (int)(M / 64);
     hipLaunchKernelGGL(conv3x3_wstat_kernel, dim3((rows + 2) / 3), dim3(768), lds, st, *a, zero_page[dev], (int)M);
     TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd");
   }
-  vecB = vecB && ((a->wt_ld & 3) == 0) && ((a->wt_coff & 3) == 0);
+  vecB = vecB && ((a->wt_coff & 3) == 0);
   // optional (TPGSR_CONV_SPLITK=1): split K over two thread groups of one workgroup (twice the resident waves on grids
   // of few tiles per CU).  Measured neutral on MI355X for the 768-tile 64->64 convs (48.0 vs 47.4 us): the launch is
   // bound by per-launch fixed costs, not by occupancy, so it is off by default.
@@ -802,7 +811,9 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   int Z, MB;
   wgrad_plan(M, K, a->Cout, &Z, &MB);
   dim3 grid(cdiv(K, WK) * cdiv(a->Cout, BN) * Z);
-  int vecY = (!w->dy_ps && (a->Cout & 3) == 0 && (w->dy_ld & 3) == 0 && (w->dy_coff & 3) == 0 &&
+  // rows padded to a multiple of 4 floats keep an odd channel count (the 37 classes) on the vector path: the loads of the
+  // last quad stay inside the padded row, columns >= Cout are never stored
+  int vecY = (!w->dy_ps && (w->dy_ld & 3) == 0 && (w->dy_coff & 3) == 0 && w->dy_ld >= ((a->Cout + 3) & ~3) + w->dy_coff &&
               ((uintptr_t)w->dy & 15) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
@@ -823,8 +834,7 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
 
 // dw (+)= sum_z part[z][k][co], scattered into the PyTorch layout.  256 threads = 32 outputs x 8 z-lanes: the Z partial
 // slabs are summed by 8 lanes in parallel (independent, unrolled loads) and combined through LDS in a fixed order.
-__device__ __forceinline__ size_t wgrad_out_index(int k, int co, int Cin, int Cout, int KH, int KW, int layout) {
-  int tap = k / Cin, ci = k - tap * Cin;
+__device__ __forceinline__ size_t wgrad_out_index(int tap, int ci, int co, int Cin, int Cout, int KH, int KW, int layout) {
   int kh = tap / KW, kw = tap - kh * KW;
   if (layout == 0) return (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
   if (layout == 1)  // ConvTranspose2d weight wT[ci][co][KH-1-kh][KW-1-kw] == equivalent-conv w_eq[co][ci][kh][kw]
@@ -840,14 +850,18 @@ __device__ __forceinline__ size_t wgrad_out_index(int k, int co, int Cin, int Co
 __device__ __forceinline__ void wgrad_reduce_body(float (*red)[33], const float* __restrict__ part,
                                                   const float* __restrict__ dbpart, int Z, int K, int Cin, int Cout, int KH,
                                                   int KW, int layout, float* dw, float* db, int accumulate, float gscale,
-                                                  unsigned blk) {
+                                                  unsigned blk, int cin_ld) {
+  if (cin_ld <= 0) cin_ld = Cin;   // k = tap * cin_ld + ci; rows with ci >= Cin or tap >= KH*KW belong to a zero-padded operand
   const int tx = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const size_t total = (size_t)K * Cout;
   const size_t ndb = (db && dbpart) ? (size_t)Cout : 0;
   // logical index space: [0, total) = weight entries, [total, total + ndb) = bias entries
   size_t idx = (size_t)blk * 32 + tx;
-  const bool is_w = idx < total;
-  const bool is_b = !is_w && idx < total + ndb;
+  const bool in_w = idx < total;
+  const int k_ = in_w ? (int)(idx / Cout) : 0;
+  const int tap_ = k_ / cin_ld, ci_ = k_ - tap_ * cin_ld;
+  const bool is_w = in_w && ci_ < Cin && tap_ < KH * KW;          // padded slab rows carry no gradient
+  const bool is_b = !in_w && idx < total + ndb;
   const float* src = is_w ? part + idx : dbpart + (idx - total);
   const size_t stride = is_w ? total : (size_t)Cout;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -868,8 +882,8 @@ __device__ __forceinline__ void wgrad_reduce_body(float (*red)[33], const float*
 #pragma unroll
     for (int i = 1; i < 8; ++i) s += red[i][tx];
     if (is_w) {
-      int k = (int)(idx / Cout), co = (int)(idx - (size_t)k * Cout);
-      size_t o = wgrad_out_index(k, co, Cin, Cout, KH, KW, layout);
+      int co = (int)(idx - (size_t)k_ * Cout);
+      size_t o = wgrad_out_index(tap_, ci_, co, Cin, Cout, KH, KW, layout);
       s *= gscale;
       dw[o] = accumulate ? dw[o] + s : s;
     } else {
@@ -883,7 +897,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int Z, int K, int Cin, int Cout, int KH, int KW, int layout,
                                                            float* dw, float* db, int accumulate, float gscale) {
   __shared__ float red[8][33];
-  wgrad_reduce_body(red, part, dbpart, Z, K, Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale, blockIdx.x);
+  wgrad_reduce_body(red, part, dbpart, Z, K, Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale, blockIdx.x, 0);
 }
 
 // every slab reduce of a backward pass in ONE launch (device-resident descriptor table, like pack_program): the
@@ -902,7 +916,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_program_kernel(const tpgsr_w
   __syncthreads();
   const tpgsr_wgrad_reduce_desc d = descs[s_d];
   wgrad_reduce_body(red, d.part, d.dbpart, d.Z, d.K, d.Cin, d.Cout, d.KH, d.KW, d.layout, d.dw, d.db, d.accumulate, d.gscale,
-                    blockIdx.x - (unsigned)d.blk0);
+                    blockIdx.x - (unsigned)d.blk0, d.cin_ld);
 }
 
 extern "C" int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias) {
@@ -917,7 +931,7 @@ extern "C" int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_d
 
 extern "C" int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
                                   int layout, float* dw, float* db, int accumulate, float gscale, void* stream) {
-  TPGSR_CHECK_ARG(part && dw && Z > 0 && K == KH * KW * Cin, "tpgsr_wgrad_reduce: bad arguments");
+  TPGSR_CHECK_ARG(part && dw && Z > 0 && K >= KH * KW * Cin, "tpgsr_wgrad_reduce: bad arguments");
   size_t total = (size_t)K * Cout + ((db && dbpart) ? (size_t)Cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, (hipStream_t)stream, part, dbpart, Z, K,
                      Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale);
@@ -1051,8 +1065,8 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
     int ci = (int)(r / d.Cout);
     if (kh != 1) return;
     int kwp = d.KW - 1 - kw;  // tap of the equivalent stride-1 conv over the zero-dilated strip
-    if (d.dst_f) d.dst_f[((size_t)kwp * d.Cin + ci) * d.f_ld + d.f_coff + co] = v;
-    if (d.dst_d) d.dst_d[((size_t)kw * d.Cout + co) * d.Cin + ci] = v;   // strided-conv operand of the data gradient
+    if (d.dst_f) d.dst_f[((size_t)kwp * (d.cin_ld > 0 ? d.cin_ld : d.Cin) + ci) * d.f_ld + d.f_coff + co] = v;
+    if (d.dst_d) d.dst_d[((size_t)kw * d.Cout + co) * (d.d_ld > 0 ? d.d_ld : d.Cin) + ci] = v;   // strided-conv operand of the data gradient
     return;
   }
   int co, ci;
@@ -1065,8 +1079,8 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
     kh = d.KH - 1 - kh;
     kw = d.KW - 1 - kw;
   }
-  if (d.dst_f) d.dst_f[((size_t)(kh * d.KW + kw) * d.Cin + ci) * d.f_ld + d.f_coff + co] = v;
-  if (d.dst_d) d.dst_d[((size_t)((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.Cout + co) * d.Cin + ci] = v;
+  if (d.dst_f) d.dst_f[((size_t)(kh * d.KW + kw) * (d.cin_ld > 0 ? d.cin_ld : d.Cin) + ci) * d.f_ld + d.f_coff + co] = v;
+  if (d.dst_d) d.dst_d[((size_t)((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.Cout + co) * (d.d_ld > 0 ? d.d_ld : d.Cin) + ci] = v;
 }
 
 // chain rule of the composed GruBlock operand (see tpgsr_compose_bwd_desc): one thread per gradient element

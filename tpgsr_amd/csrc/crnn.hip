@@ -68,41 +68,141 @@ extern "C" int tpgsr_bicubic_gray_fwd(const float* in_nchw, int N, int Ctot, int
   TPGSR_LAUNCH_CHECK("tpgsr_bicubic_gray_fwd");
 }
 
-// scatter form of the adjoint (din must be zero-filled for channels 0..2; other channels receive no gradient)
+// Gather form of the adjoint (deterministic: every input pixel sums, in a fixed order, the output pixels whose 4x4
+// footprint -- border-clamped like the forward -- touches it).  One thread per (n, y, x); the three colour channels
+// differ only by the luminance weight, further channels (the mask) receive zero.
+__device__ __forceinline__ float bicubic_tap_weight(int o, int in_size, int out_size, int target) {
+  int i0;
+  float w[4];
+  bicubic_src(o, in_size, out_size, i0, w);
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) s += clampi(i0 - 1 + a, 0, in_size - 1) == target ? w[a] : 0.f;
+  return s;
+}
+// conservative range of output indices whose (unclamped) taps [src-2, src+3) can reach input index i (border indices also
+// collect the clamped taps, which lie inside the same range)
+__device__ __forceinline__ void bicubic_out_range(int i, int in_size, int out_size, int& lo, int& hi) {
+  float inv = (float)out_size / (float)in_size;
+  lo = (int)floorf(((float)i - 3.f + 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 3.f + 0.5f) * inv - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
+
 __global__ __launch_bounds__(256) void bicubic_gray_bwd_kernel(const float* __restrict__ dout, int N, int Ctot, int H, int W, int OH,
-                                                               int OW, float* din) {
-  long long total = (long long)N * OH * OW;
+                                                               int OW, float* __restrict__ din) {
+  long long total = (long long)N * H * W;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  int ow = (int)(i % OW);
-  long long r = i / OW;
-  int oh = (int)(r % OH);
-  int n = (int)(r / OH);
-  int y0, x0;
-  float wy[4], wx[4];
-  bicubic_src(oh, H, OH, y0, wy);
-  bicubic_src(ow, W, OW, x0, wx);
-  const float lum[3] = {0.299f, 0.587f, 0.114f};
-  float g = dout[i];
-  for (int c = 0; c < 3; ++c) {
-    float* p = din + ((size_t)n * Ctot + c) * H * W;
-    for (int a = 0; a < 4; ++a) {
-      int yy = clampi(y0 - 1 + a, 0, H - 1);
-      for (int b = 0; b < 4; ++b) atomicAdd(p + (size_t)yy * W + clampi(x0 - 1 + b, 0, W - 1), g * lum[c] * wy[a] * wx[b]);
+  int x = (int)(i % W);
+  long long r = i / W;
+  int y = (int)(r % H);
+  int n = (int)(r / H);
+  int oh_lo, oh_hi, ow_lo, ow_hi;
+  bicubic_out_range(y, H, OH, oh_lo, oh_hi);
+  bicubic_out_range(x, W, OW, ow_lo, ow_hi);
+  float s = 0.f;
+  for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+    const float wy = bicubic_tap_weight(oh, H, OH, y);
+    if (wy == 0.f) continue;
+    const float* row = dout + ((size_t)n * OH + oh) * OW;
+    float rs = 0.f;
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      const float wx = bicubic_tap_weight(ow, W, OW, x);
+      rs += wx * row[ow];
     }
+    s += wy * rs;
   }
+  const float lum[3] = {0.299f, 0.587f, 0.114f};
+  for (int c = 0; c < Ctot; ++c) din[(((size_t)n * Ctot + c) * H + y) * W + x] = c < 3 ? lum[c] * s : 0.f;
 }
 
 extern "C" int tpgsr_bicubic_gray_bwd(const float* dout, int N, int Ctot, int H, int W, int OH, int OW, float* din_nchw, void* stream) {
-  TPGSR_CHECK_ARG(dout && din_nchw && N > 0 && Ctot >= 3, "tpgsr_bicubic_gray_bwd: bad arguments");
-  hipError_t e = hipMemsetAsync(din_nchw, 0, (size_t)N * Ctot * H * W * sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) {
-    tpgsr_set_error("tpgsr_bicubic_gray_bwd: memset failed: %s", hipGetErrorString(e));
-    return TPGSR_ERR_LAUNCH;
-  }
-  long long total = (long long)N * OH * OW;
+  TPGSR_CHECK_ARG(dout && din_nchw && N > 0 && Ctot >= 3 && H > 0 && W > 0 && OH > 0 && OW > 0, "tpgsr_bicubic_gray_bwd: bad arguments");
+  long long total = (long long)N * H * W;
   hipLaunchKernelGGL(bicubic_gray_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, N, Ctot, H, W, OH, OW, din_nchw);
   TPGSR_LAUNCH_CHECK("tpgsr_bicubic_gray_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// CRNN conv0 (1 -> 64 channels, 3x3, pad 1; crnn.py:45): with Cin = 1 the implicit-GEMM loader would gather single
+// floats, so the 3x3 neighbourhood is written out once as a 12-channel map (9 taps + 3 zero channels) and the conv runs
+// as a 1x1 conv with Cin = 12 on the vector loader.  col2im is the gather-form adjoint (for d gray of later cascade stages).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_c1_kernel(const float* __restrict__ in, int N, int H, int W, float* __restrict__ col) {
+  long long total = (long long)N * H * W;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int x = (int)(i % W);
+  long long r = i / W;
+  int y = (int)(r % H);
+  int n = (int)(r / H);
+  const float* p = in + (size_t)n * H * W;
+  float v[12];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      int yy = y + kh - 1, xx = x + kw - 1;
+      v[kh * 3 + kw] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? p[(size_t)yy * W + xx] : 0.f;
+    }
+  v[9] = v[10] = v[11] = 0.f;
+  float4* d = reinterpret_cast<float4*>(col + i * 12);
+  d[0] = make_float4(v[0], v[1], v[2], v[3]);
+  d[1] = make_float4(v[4], v[5], v[6], v[7]);
+  d[2] = make_float4(v[8], v[9], v[10], v[11]);
+}
+
+extern "C" int tpgsr_im2col3x3_c1(const float* in, int N, int H, int W, float* col, void* stream) {
+  TPGSR_CHECK_ARG(in && col && N > 0 && H > 0 && W > 0 && ((uintptr_t)col & 15) == 0, "tpgsr_im2col3x3_c1: bad arguments");
+  long long total = (long long)N * H * W;
+  hipLaunchKernelGGL(im2col3x3_c1_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, col);
+  TPGSR_LAUNCH_CHECK("tpgsr_im2col3x3_c1");
+}
+
+__global__ __launch_bounds__(256) void col2im3x3_c1_kernel(const float* __restrict__ dcol, int N, int H, int W, float* __restrict__ din) {
+  long long total = (long long)N * H * W;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int x = (int)(i % W);
+  long long r = i / W;
+  int y = (int)(r % H);
+  int n = (int)(r / H);
+  float s = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      int oy = y - kh + 1, ox = x - kw + 1;   // output pixel whose tap (kh, kw) read (y, x)
+      if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) s += dcol[(((size_t)n * H + oy) * W + ox) * 12 + kh * 3 + kw];
+    }
+  din[i] = s;
+}
+
+extern "C" int tpgsr_col2im3x3_c1(const float* dcol, int N, int H, int W, float* din, void* stream) {
+  TPGSR_CHECK_ARG(dcol && din && N > 0 && H > 0 && W > 0, "tpgsr_col2im3x3_c1: bad arguments");
+  long long total = (long long)N * H * W;
+  hipLaunchKernelGGL(col2im3x3_c1_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, N, H, W, din);
+  TPGSR_LAUNCH_CHECK("tpgsr_col2im3x3_c1");
+}
+
+// dst[m][c] = c < Cs ? src[m][c] : 0  (Cd >= Cs): pads a channel count that is not a multiple of 4 (the 37 classes of the
+// recogniser / text prior) so the consumers stay on the vector loaders
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ src, long long M, int Cs, int Cd, float* __restrict__ dst) {
+  long long total = M * Cd;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cd);
+    long long m = i / Cd;
+    dst[i] = c < Cs ? src[m * Cs + c] : 0.f;
+  }
+}
+
+extern "C" int tpgsr_pad_channels(const float* src, long long M, int Cs, int Cd, float* dst, void* stream) {
+  TPGSR_CHECK_ARG(src && dst && M > 0 && Cs > 0 && Cd >= Cs, "tpgsr_pad_channels: bad arguments");
+  int grid = (int)min((long long)4096, (M * Cd + 255) / 256);
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, M, Cs, Cd, dst);
+  TPGSR_LAUNCH_CHECK("tpgsr_pad_channels");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -495,4 +595,57 @@ extern "C" int tpgsr_softmax_prior_bwd(const float* p, const float* q, const flo
   hipLaunchKernelGGL(softmax_prior_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, q, dprior_nchw, dp_in, N, T, C, drop_n, wc,
                      dlogits);
   TPGSR_LAUNCH_CHECK("tpgsr_softmax_prior_bwd");
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// SemanticLoss on probability tensors (loss/semantic_loss.py:21-39, the nn.Module API): no softmax involved, rows need
+// not sum to 1.  partial[blk] = (sum |q - p|, sum q' (log q' - log p')), p' = p + 1e-20, q' = q + 1e-20;
+// backward: dp = dloss * (-sign(q - p) - q'/p') / count
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void semantic_loss_fwd_kernel(const float* __restrict__ p, const float* __restrict__ q, long long n,
+                                                                float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  float l1 = 0.f, kl = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float pv = p[i], qv = q[i];
+    l1 += fabsf(qv - pv);
+    float qp = qv + 1e-20f;
+    kl += qp * (logf(qp) - logf(pv + 1e-20f));
+  }
+  l1 = wave_sum(l1);
+  kl = wave_sum(kl);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = l1;
+    red[1][threadIdx.x >> 6] = kl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+extern "C" int tpgsr_semantic_loss_fwd(const float* p, const float* q, long long n, float* partial, int nblk, void* stream) {
+  TPGSR_CHECK_ARG(p && q && partial && n > 0 && nblk > 0, "tpgsr_semantic_loss_fwd: bad arguments");
+  hipLaunchKernelGGL(semantic_loss_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, q, n, partial);
+  TPGSR_LAUNCH_CHECK("tpgsr_semantic_loss_fwd");
+}
+
+__global__ __launch_bounds__(256) void semantic_loss_bwd_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                                const float* __restrict__ dloss, long long n, float* __restrict__ dp) {
+  const float w = dloss[0] / (float)n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float pv = p[i], qv = q[i];
+    float diff = qv - pv;
+    float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+    dp[i] = w * (-sg - (qv + 1e-20f) / (pv + 1e-20f));
+  }
+}
+
+extern "C" int tpgsr_semantic_loss_bwd(const float* p, const float* q, const float* dloss, long long n, float* dp, void* stream) {
+  TPGSR_CHECK_ARG(p && q && dloss && dp && n > 0, "tpgsr_semantic_loss_bwd: bad arguments");
+  int grid = (int)min((long long)1024, (n + 255) / 256);
+  hipLaunchKernelGGL(semantic_loss_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, q, dloss, n, dp);
+  TPGSR_LAUNCH_CHECK("tpgsr_semantic_loss_bwd");
 }

@@ -29,7 +29,9 @@ F32 = torch.float32
 # flat parameter / gradient arenas
 # =================================================================================================================
 class ParamArena:
-    """All parameters of a module as views of ONE flat fp32 buffer (and their .grad as views of a second one)."""
+    """All parameters of a module as views of ONE flat fp32 buffer (and their .grad as views of a second one).
+    With `external` set (ArenaPool) the two buffers are slices of a pool shared by several modules, so the whole
+    job's gradients are one contiguous RCCL bucket."""
 
     def __init__(self, module: torch.nn.Module):
         self.module = module
@@ -37,11 +39,24 @@ class ParamArena:
         self.grad: Optional[torch.Tensor] = None
         self.offsets: Dict[str, int] = {}
         self.numel = 0
+        self.external = None      # (flat slice, grad slice) handed out by an ArenaPool
+
+    def layout(self):
+        """name -> offset (floats) with every tensor 16-byte aligned; total size"""
+        off, offsets = 0, {}
+        for name, p in self.module.named_parameters():
+            if p.dtype != F32:
+                raise TypeError(f"tpgsr_amd runs fp32 parameters (got {p.dtype} for {name})")
+            offsets[name] = off
+            off += (p.numel() + 3) // 4 * 4
+        return offsets, off
 
     def ensure(self, device) -> bool:
         """(Re)build the arenas if the parameters are not (any more) views of them on `device`.  True if rebuilt."""
         params = list(self.module.named_parameters())
         ok = self.flat is not None and self.flat.device == device
+        if ok and self.external is not None:
+            ok = self.flat.data_ptr() == self.external[0].data_ptr() and self.external[0].device == device
         if ok:
             base = self.flat.data_ptr()
             for name, p in params:
@@ -50,16 +65,16 @@ class ParamArena:
                     break
         if ok:
             return False
-        off = 0
-        self.offsets = {}
-        for name, p in params:
-            if p.dtype != F32:
-                raise TypeError(f"tpgsr_amd runs fp32 parameters (got {p.dtype} for {name})")
-            self.offsets[name] = off
-            off += (p.numel() + 3) // 4 * 4  # every tensor stays 16-byte aligned
+        self.offsets, off = self.layout()
         self.numel = off
-        flat = torch.zeros(off, dtype=F32, device=device)
-        grad = torch.zeros(off, dtype=F32, device=device)
+        if self.external is not None and self.external[0].device == device:
+            flat, grad = self.external
+            assert flat.numel() == off and grad.numel() == off
+            grad.zero_()
+        else:
+            self.external = None
+            flat = torch.zeros(off, dtype=F32, device=device)
+            grad = torch.zeros(off, dtype=F32, device=device)
         with torch.no_grad():
             for name, p in params:
                 o, n = self.offsets[name], p.numel()
@@ -81,6 +96,48 @@ class ParamArena:
                     fresh = True
                 p.grad = self.grad[o:o + n].view(p.shape)
         return fresh
+
+
+class ArenaPool:
+    """ONE flat parameter buffer and ONE flat gradient buffer for a list of modules (SR nets first, then the student
+    recognisers): the gradient exchange of a data-parallel step is then one contiguous range per bucket
+    (tpgsr_amd.distributed.GradientExchanger), zero_grad is one memset, and the modules' own ParamArena / engines keep
+    working on their slices.  Slices start on 256-byte boundaries."""
+
+    ALIGN = 64
+
+    def __init__(self, modules):
+        self.modules = []
+        for m in modules:
+            if all(m is not q for q in self.modules):
+                self.modules.append(m)
+        self.flat = self.grad = None
+        self.ranges: Dict[int, tuple] = {}
+
+    def bind(self, device):
+        sizes = [m._engine().arena.layout()[1] for m in self.modules]
+        if self.flat is not None and self.flat.device == device and [self.ranges[id(m)][1] - self.ranges[id(m)][0]
+                                                                      for m in self.modules] == sizes:
+            for m in self.modules:
+                m._engine().bind(device)
+            return
+        off, self.ranges = 0, {}
+        for m, n in zip(self.modules, sizes):
+            self.ranges[id(m)] = (off, off + n)
+            off = (off + n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        for m in self.modules:
+            a, b = self.ranges[id(m)]
+            eng = m._engine()
+            eng.arena.external = (self.flat[a:b], self.grad[a:b])
+            eng.device = None          # force a re-bind against the pooled storage
+            eng.bind(device)
+
+    def span(self, modules):
+        """[begin, end) in floats covering the given (adjacent) modules"""
+        r = [self.ranges[id(m)] for m in modules]
+        return min(a for a, _ in r), max(b for _, b in r)
 
 
 class _Ws:
@@ -277,23 +334,26 @@ class TConvStrip:
     """ConvTranspose2d(Cin, Cout, 3, stride (s_h, s_w), padding (1, p_w), bias=False) on an H=1 strip (InfoGen,
     model/tsrn.py:81-108): only the kh=1 kernel row meets data, so it is a 1-D transposed conv along W, run as a
     stride-1 1x3 conv over the zero-dilated strip (forward / weight gradient) and as a stride-s_w conv over dy
-    (data gradient)."""
+    (data gradient).  An input channel count that is not a multiple of 4 (tconv1: the 37 classes) is zero-padded to
+    Cp channels in the operands; the caller then hands in the padded strip [N][W][Cp]."""
 
     def __init__(self, eng, wname: str, stride_w: int, pad_w: int):
         self.eng, self.wname, self.sw, self.pw = eng, wname, stride_w, pad_w
         self.w = eng.P[wname]
         self.Cin, self.Cout = self.w.shape[0], self.w.shape[1]
+        self.Cp = (self.Cin + 3) // 4 * 4
         assert tuple(self.w.shape[2:]) == (3, 3)
         dev = eng.device
-        self.wt_f = torch.empty(3 * self.Cin, self.Cout, dtype=F32, device=dev)
-        self.wt_d = torch.empty(3 * self.Cout, self.Cin, dtype=F32, device=dev)
-        eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=3, KW=3, kind=4, f_ld=self.Cout)
+        self.wt_f = torch.zeros(3 * self.Cp, self.Cout, dtype=F32, device=dev)
+        self.wt_d = torch.zeros(3 * self.Cout, self.Cp, dtype=F32, device=dev)
+        eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=3, KW=3, kind=4, f_ld=self.Cout,
+                     d_ld=self.Cp, cin_ld=self.Cp)
 
     def out_w(self, Win):
         return (Win - 1) * self.sw - 2 * self.pw + 3
 
     def geom(self, N, Win) -> ConvGeom:
-        return ConvGeom(N, 1, (Win - 1) * self.sw + 1, self.Cin, self.Cout, 1, 3, 0, 2 - self.pw)
+        return ConvGeom(N, 1, (Win - 1) * self.sw + 1, self.Cp, self.Cout, 1, 3, 0, 2 - self.pw)
 
     def fwd(self, N, Win, x, out, **kw):
         g = self.geom(N, Win)
@@ -308,12 +368,13 @@ class TConvStrip:
         ca = K.make_conv_args(g, x, in_dil_w=self.sw, **(loader or {}))
         with K.side():
             K.conv_wgrad(K.make_wgrad_args(ca, dy, part, None))
-            K.wgrad_reduce(part, None, Z, g, eng.G[self.wname], None, layout=3, accumulate=True)
+            K.wgrad_reduce(part, None, Z, g, eng.G[self.wname], None, layout=3, accumulate=True,
+                           real=(self.Cin, 1, 3, self.Cp) if self.Cp != self.Cin else None)
 
     def dgrad(self, N, Win, dy, dx):
         """dx[N][1][Win][Cin] = strided conv of dy[N][1][OW][Cout] with the un-flipped taps"""
         g = ConvGeom(N, 1, self.out_w(Win), self.Cout, self.Cin, 1, 3, 0, self.pw, 1, Win)
-        K.conv_fwd(K.make_conv_args(g, dy, self.wt_d, dx, stride_w=self.sw))
+        K.conv_fwd(K.make_conv_args(g, dy, self.wt_d, dx, stride_w=self.sw, wt_ld=self.Cp))
 
 
 # =================================================================================================================
@@ -333,6 +394,34 @@ class _EngineBase:
         self._pending_batches = 0
         self._wg_idx, self._cur_ws = 0, None
         self._compose: List[tuple] = []
+        self._live: Dict[int, int] = {}      # module-API workspace slot -> generation of the forward that owns it
+        self._gen = 0
+
+    # ---- workspace slots of the nn.Module API --------------------------------------------------------------------
+    # A training-mode forward saves its activations / BN statistics / GRU-LSTM gates in a workspace slot until its
+    # backward ran.  The train-step drivers name their slots explicitly (stage index); autograd-driven callers may run
+    # several forwards of one module before the first backward (fwd, fwd, bwd, bwd; a cascade with --sr_share), so every
+    # such forward takes a free slot and its backward releases it.  More than MAX_LIVE outstanding forwards recycle the
+    # oldest slot; a backward whose slot was recycled raises instead of using overwritten activations.
+    MAX_LIVE = 8
+    SLOT_BASE = 1000
+
+    def acquire_slot(self):
+        self._gen += 1
+        free = [s for s in range(self.MAX_LIVE) if s not in self._live]
+        s = free[0] if free else min(self._live, key=self._live.get)
+        self._live[s] = self._gen
+        return self.SLOT_BASE + s, self._gen
+
+    def check_slot(self, slot, gen):
+        if self._live.get(slot - self.SLOT_BASE) != gen:
+            raise RuntimeError(
+                f"{type(self.module).__name__}: the activations saved by this forward were overwritten (more than "
+                f"{self.MAX_LIVE} training-mode forwards without a backward, or the module was re-bound in between)")
+
+    def release_slot(self, slot, gen):
+        if self._live.get(slot - self.SLOT_BASE) == gen:
+            del self._live[slot - self.SLOT_BASE]
 
     # ---- scratch buffers live only between consecutive launches (stream-ordered reuse) ----------------------
     def scratch(self, name, numel):
@@ -380,21 +469,22 @@ class _EngineBase:
             K.compose_bwd_program(table, len(items), blk)
 
     def add_pack(self, src, dst_f, dst_d, Cout=0, Cin=0, KH=1, KW=1, kind=0, f_ld=0, f_coff=0, wscale=1.0, src2=None, src3=None,
-                 numel=None):
-        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel))
+                 numel=None, d_ld=0, cin_ld=0):
+        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld))
 
     def _finish_pack_table(self):
         n = len(self._pack)
         arr = (PackDesc * n)()
         blk = 0
         self._pack_keep = []
-        for i, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel) in enumerate(self._pack):
+        for i, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld) in enumerate(self._pack):
             d = arr[i]
             d.src, d.dst_f = src.data_ptr(), dst_f.data_ptr()
             d.dst_d = dst_d.data_ptr() if dst_d is not None else None
             d.src2 = src2.data_ptr() if src2 is not None else None
             d.src3 = src3.data_ptr() if src3 is not None else None
             d.Cout, d.Cin, d.KH, d.KW, d.kind, d.f_ld, d.f_coff, d.wscale = Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale
+            d.d_ld, d.cin_ld = d_ld, cin_ld
             cnt = src.numel() if numel is None else numel
             d.numel, d.blk0 = cnt, blk
             blk += (cnt + 255) // 256
@@ -413,6 +503,7 @@ class _EngineBase:
         self.device = device
         self._plans.clear()
         self._scratch.clear()
+        self._live.clear()
         self._pack = []
         self._bn_layers = []
         m = self.module
@@ -590,6 +681,10 @@ class TSRNEngine(_EngineBase):
         -> text strip [N][W][Ct] (all H rows of the reference's spatial_t_emb are identical)."""
         pri = ws("prior_nhwc", N * Wp, self.emb_cls)
         K.nchw_to_nhwc(K.DynPtr("prior"), N, self.emb_cls, 1, Wp, pri)
+        if self.ig[0].Cp != self.emb_cls:     # 37 classes -> 40 channels: tconv1 stays on the 16-byte loaders
+            prp = ws("prior_p", N * Wp, self.ig[0].Cp)
+            K.pad_channels(pri, N * Wp, self.emb_cls, self.ig[0].Cp, prp)
+            pri = prp
         widths = self._ig_widths(Wp)
         cur, loader = pri, {}
         for i, (tc, bn) in enumerate(zip(self.ig, self.ig_bn)):
@@ -613,7 +708,7 @@ class TSRNEngine(_EngineBase):
             M = N * widths[i + 1]
             dy = ws(f"ig_dy{i}", M, tc.Cout)
             bn.backward(da, None, t[f"ig_t{i}"], M, act, dy)
-            xin = t[f"ig_t{i - 1}"] if i > 0 else t["prior_nhwc"]
+            xin = t[f"ig_t{i - 1}"] if i > 0 else t.get("prior_p", t["prior_nhwc"])
             loader = dict(in_act="relu", **self.ig_bn[i - 1].loader) if i > 0 else {}
             tc.wgrad(N, widths[i], xin, dy, loader=loader)
             da = ws(f"ig_da{i}", N * widths[i], tc.Cin)
@@ -781,7 +876,7 @@ class TSRNEngine(_EngineBase):
     def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.module.in_planes:
             raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
-        if not x.is_cuda:
+        if not x.is_cuda and not K.DRYRUN:
             raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
         self.bind(x.device)
         N, _, H, W = x.shape
@@ -792,7 +887,7 @@ class TSRNEngine(_EngineBase):
         fwd.set_ptr("x", x.data_ptr())
         fwd.set_ptr("sr", sr.data_ptr())
         if self.tl:
-            if prior is None or tuple(prior.shape) != (N, self.emb_cls, 1, 26) or not prior.is_cuda:
+            if prior is None or tuple(prior.shape) != (N, self.emb_cls, 1, 26) or not (prior.is_cuda or K.DRYRUN):
                 raise ValueError(f"TSRN_TL needs a CUDA text prior of shape ({N}, {self.emb_cls}, 1, 26)")
             prior = prior.contiguous().float()
             fwd.set_ptr("prior", prior.data_ptr())

@@ -18,6 +18,69 @@ from .engine import BNLayer, ConvLayer, F32, _EngineBase
 from .kernels import ConvGeom, Plan, recording
 
 
+class Conv0Im2col:
+    """cnn.conv0 = nn.Conv2d(1, 64, 3, 1, 1) (crnn.py:45-46).  With one input channel the implicit-GEMM loader would gather
+    single floats (the scalar loader: 100 us per launch at bs 48), so the 3x3 neighbourhood is written out once as a
+    12-channel map (tpgsr_im2col3x3_c1: 9 taps + 3 zero channels) and the conv runs as a 1x1 conv with Cin = 12 on the
+    vector loader; weight gradient = the 1x1 conv's (slab rows 9..11 skipped), d gray = col2im of the 1x1 data gradient."""
+
+    def __init__(self, eng, wname, bname):
+        self.eng, self.wname, self.bname = eng, wname, bname
+        self.w, self.b = eng.P[wname], eng.P[bname]
+        assert tuple(self.w.shape[1:]) == (1, 3, 3)
+        self.Cout, self.Cin = self.w.shape[0], 12
+        dev = eng.device
+        self.wt_f = torch.zeros(12, self.Cout, dtype=F32, device=dev)      # rows 9..11 stay zero
+        self.wt_d = torch.zeros(self.Cout, 12, dtype=F32, device=dev)      # columns 9..11 stay zero
+        eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=9, KH=1, KW=1, kind=0, f_ld=self.Cout, d_ld=12)
+
+    def fwd(self, N, H, W, gray, col, out, **kw):
+        K.im2col3x3_c1(gray, N, H, W, col)
+        K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 12, self.Cout), col, self.wt_f, out, bias=self.b, **kw))
+
+    def wgrad(self, N, H, W, col, dy):
+        eng, g = self.eng, ConvGeom(N, H, W, 12, self.Cout)
+        Z = K.wgrad_splits(g.M, g.K, g.Cout)
+        part, dbp = eng.wgrad_buffers(Z * g.K * g.Cout, Z * g.Cout)
+        with K.side():
+            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, col), dy, part, dbp))
+            K.wgrad_reduce(part, dbp, Z, g, eng.G[self.wname], eng.G[self.bname], accumulate=True, real=(9, 1, 1, 0))
+
+    def dgrad(self, N, H, W, dy, dcol, dgray):
+        K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, self.Cout, 12), dy, self.wt_d, dcol))
+        K.col2im3x3_c1(dcol, N, H, W, dgray)
+
+
+class PaddedLinear:
+    """nn.Linear(Cin, Cout) with Cout % 4 != 0 (the 37-class embedding, crnn.py:12): both packed operands are zero-padded
+    to Cp = 4*ceil(Cout/4) columns / rows so the forward, data-gradient and weight-gradient GEMMs stay on the 16-byte
+    loaders.  The output gradient is handed in padded: dy [M][Cp], columns >= Cout zero."""
+
+    def __init__(self, eng, wname, bname):
+        self.eng, self.wname, self.bname = eng, wname, bname
+        self.w, self.b = eng.P[wname], eng.P[bname]
+        self.Cout, self.Cin = self.w.shape
+        self.Cp = (self.Cout + 3) // 4 * 4
+        dev = eng.device
+        self.wt_f = torch.zeros(self.Cin, self.Cp, dtype=F32, device=dev)
+        self.wt_d = torch.zeros(self.Cp, self.Cin, dtype=F32, device=dev)
+        eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, kind=0, f_ld=self.Cp)
+
+    def fwd(self, N, H, W, x, out, **kw):
+        K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, self.Cin, self.Cout), x, self.wt_f, out, bias=self.b, wt_ld=self.Cp, **kw))
+
+    def dgrad(self, N, H, W, dy_p, dx):
+        K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, self.Cp, self.Cin), dy_p, self.wt_d, dx))
+
+    def wgrad(self, N, H, W, x, dy_p):
+        eng, g = self.eng, ConvGeom(N, H, W, self.Cin, self.Cout)
+        Z = K.wgrad_splits(g.M, g.K, g.Cout)
+        part, dbp = eng.wgrad_buffers(Z * g.K * g.Cout, Z * g.Cout)
+        with K.side():
+            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, x), dy_p, part, dbp, dy_ld=self.Cp))
+            K.wgrad_reduce(part, dbp, Z, g, eng.G[self.wname], eng.G[self.bname], accumulate=True)
+
+
 class LstmLayer:
     """BidirectionalLSTM (crnn.py:5-26): nn.LSTM(nIn, Hh, bidirectional) + Linear(2*Hh, nOut)."""
 
@@ -40,7 +103,8 @@ class LstmLayer:
             eng.add_pack(P[r + "bias_ih_l0" + suf], self.bih[d * G4:(d + 1) * G4], None, kind=2)
             eng.add_pack(P[r + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
             eng.add_pack(P[r + "weight_hh_l0" + suf], self.whh_f[d], None, Cout=G4, Cin=Hh, kind=0, f_ld=G4)
-        self.emb = ConvLayer(eng, prefix + ".embedding.weight", prefix + ".embedding.bias")
+        nout = P[prefix + ".embedding.weight"].shape[0]
+        self.emb = (ConvLayer if nout % 4 == 0 else PaddedLinear)(eng, prefix + ".embedding.weight", prefix + ".embedding.bias")
 
     def fwd(self, N, T, x, G, gh, Cst, out, e, **loader):
         """x [N][T][Cin] -> G (gates) -> out [N][T][2Hh] -> e = Linear(out) [N][T][nOut]"""
@@ -96,7 +160,10 @@ class CRNNEngine(_EngineBase):
         self.convs, self.bns = [], {}
         for i in range(7):
             k, pad = (3, 1) if i < 6 else (2, 0)
-            self.convs.append(ConvLayer(self, f"cnn.conv{i}.weight", f"cnn.conv{i}.bias", k, k, pad, pad, need_dgrad=True))
+            if i == 0:
+                self.convs.append(Conv0Im2col(self, "cnn.conv0.weight", "cnn.conv0.bias"))
+            else:
+                self.convs.append(ConvLayer(self, f"cnn.conv{i}.weight", f"cnn.conv{i}.bias", k, k, pad, pad, need_dgrad=True))
             if i in self.BN_AT:
                 self.bns[i] = BNLayer(self, f"cnn.batchnorm{i}")
         self.lstm = [LstmLayer(self, "rnn.0"), LstmLayer(self, "rnn.1")]
@@ -122,8 +189,8 @@ class CRNNEngine(_EngineBase):
         return self._two_pass((N, bool(training), slot), lambda ws, final: self._record(N, training, ws, final))
 
     def _record(self, N, training, ws, final):
-        fwd, bwd = Plan("crnn_fwd"), Plan("crnn_bwd")
-        fwd.final = bwd.final = final
+        fwd, bwd, dgp = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_dgray")
+        fwd.final = bwd.final = dgp.final = final
         # weight gradients on the side stream + one batched slab reduce, as in TSRNEngine (every buffer a weight-gradient
         # launch reads -- ds{i}, saved activations, the LSTM gate gradients after the time loop -- is written once per pass)
         bwd.overlap = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
@@ -140,20 +207,23 @@ class CRNNEngine(_EngineBase):
                 if defer:
                     K.flush_wgrad_reduces()
                 bwd.join()
-        return dict(fwd=fwd, bwd=bwd, ws=ws)
+            with recording(dgp):   # d gray: only later cascade stages ask for it (their input is the previous SR image)
+                self._record_dgray(N, ws)
+        return dict(fwd=fwd, bwd=bwd, dgray=dgp, ws=ws)
 
     def _record_fwd(self, N, training, ws):
         self.pack_all()
         dims = self._dims()
-        gray = ws("gray", N * self.IMG_HW[0] * self.IMG_HW[1], 1)   # launch structs hold static pointers: stage the input
-        K.copy(K.DynPtr("gray"), gray, gray.numel())
-        cur, loader = gray, {}
+        cur, loader = K.DynPtr("gray"), {}        # conv0's im2col reads the caller's tensor directly (patched per call)
         for i, conv in enumerate(self.convs):
             (h, w), (oh, ow), (ph, pw) = dims[i]
             s = ws(f"s{i}", N * oh * ow, conv.Cout)
             bn = self.bns.get(i)
             part = bn.partial(N * oh * ow)[0] if (bn and training) else None
-            conv.fwd(N, h, w, cur, s, bn_partial=part, **loader)
+            if i == 0:
+                conv.fwd(N, h, w, cur, ws("col0", N * h * w, 12), s)
+            else:
+                conv.fwd(N, h, w, cur, s, bn_partial=part, **loader)
             if bn:
                 bn.finalize(N * oh * ow, conv.b, training)
             if i in self.POOLS:
@@ -181,8 +251,9 @@ class CRNNEngine(_EngineBase):
         t = ws.t
         dims = self._dims()
         T = self.T
-        de = ws("dlogits", N * T, self.nclass)
-        K.copy(K.DynPtr("dlogits"), de, N * T * self.nclass)
+        cp = self.lstm[1].emb.Cp if isinstance(self.lstm[1].emb, PaddedLinear) else self.nclass
+        de = ws("dlogits", N * T, cp)                 # zero-padded to a multiple of 4 classes (PaddedLinear)
+        K.pad_channels(K.DynPtr("dlogits"), N * T, self.nclass, cp, de)
         cnn_loader = dict(in_act="relu", **self.bns[6].loader)
         for j in (1, 0):
             L = self.lstm[j]
@@ -214,7 +285,8 @@ class CRNNEngine(_EngineBase):
                 K.act_bwd(s, da, M * conv.Cout, "relu", ds)
             # the conv's own input and the loader it was read through
             if i == 0:
-                xin, ld = t["gray"], {}
+                conv.wgrad(N, h, w, t["col0"], ds)
+                continue
             else:
                 pi, pbn = i - 1, self.bns.get(i - 1)
                 if pi in self.POOLS:
@@ -222,18 +294,18 @@ class CRNNEngine(_EngineBase):
                 else:
                     xin, ld = t[f"s{pi}"], (dict(in_act="relu", **pbn.loader) if pbn else dict(in_act="relu"))
             conv.wgrad(N, h, w, xin, ds, loader=ld)
-            if i > 0:
-                da = ws(f"da{i - 1}", N * h * w, conv.Cin)
-                conv.dgrad(N, h, w, ds, da)
-            else:
-                dg = ws("dgray", N * h * w, 1)
-                conv.dgrad(N, h, w, ds, dg)
-                K.copy(dg, K.DynPtr("dgray"), N * h * w)
+            da = ws(f"da{i - 1}", N * h * w, conv.Cin)
+            conv.dgrad(N, h, w, ds, da)
+
+    def _record_dgray(self, N, ws):
+        h, w = self.IMG_HW
+        dcol = ws("dcol0", N * h * w, 12)
+        self.convs[0].dgrad(N, h, w, ws.t["ds0"], dcol, K.DynPtr("dgray"))
 
     # ---- execution ----------------------------------------------------------------------------------------------
     def forward(self, gray: torch.Tensor, training: bool, slot: int = 0) -> torch.Tensor:
         """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major; the module returns the (T, N, C) view)"""
-        if not gray.is_cuda:
+        if not gray.is_cuda and not K.DRYRUN:
             raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
         if gray.dim() != 4 or gray.shape[1] != 1 or tuple(gray.shape[2:]) != self.IMG_HW:
             raise ValueError(f"CRNN expects (N, 1, {self.IMG_HW[0]}, {self.IMG_HW[1]}) input, got {tuple(gray.shape)}")
@@ -256,8 +328,11 @@ class CRNNEngine(_EngineBase):
         self.arena.attach_grads()
         bwd = pl["bwd"]
         dlogits = dlogits.contiguous().float()
-        dgray = torch.empty_like(gray)
         bwd.set_ptr("dlogits", dlogits.data_ptr())
-        bwd.set_ptr("dgray", dgray.data_ptr())
         bwd.run()
-        return dgray if need_dgray else None
+        if not need_dgray:
+            return None
+        dgray = torch.empty_like(gray)
+        pl["dgray"].set_ptr("dgray", dgray.data_ptr())
+        pl["dgray"].run()
+        return dgray

@@ -10,7 +10,8 @@ from typing import Optional
 import torch
 
 from .. import kernels as K
-from ..distributed import broadcast_state, exchange_gradients
+from ..distributed import GradientExchanger, broadcast_state
+from ..engine import ArenaPool
 from ..optim import FusedAdam
 
 _NBLK = 128
@@ -21,10 +22,12 @@ class TSRNTrainStep:
                  process_group=None, world_size: int = 1):
         self.model = model
         self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
-        self.opt = FusedAdam([model], lr=lr, betas=betas, clip_modules=[model], max_norm=max_norm)
+        self.pool = ArenaPool([model])
+        self.opt = FusedAdam([model], lr=lr, betas=betas, clip_modules=[model], max_norm=max_norm, pool=self.pool)
         self.pg, self.world = process_group, world_size
         self._graph = None
         self._static = None
+        self._exch = None
 
     # -- one step as plain launches ---------------------------------------------------------------------------
     def _buffers(self, lr_img):
@@ -55,22 +58,26 @@ class TSRNTrainStep:
         self.last_sr = sr
         return st["loss"]
 
+    def _exchanger(self):
+        if self._exch is None or self._exch.flat.data_ptr() != self.pool.grad.data_ptr():
+            inv = self._static["inv_world"]
+            self._exch = GradientExchanger(self.pool.grad, [(0, self.pool.grad.numel())], self.pg,
+                                           scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv))
+        return self._exch
+
     def _exchange(self):
-        """ONE flat bucket: RCCL all-reduce (sum) of the gradient arena over xGMI; the 1/world average is in phase B"""
+        """ONE flat bucket: RCCL all-reduce (sum) of the gradient arena over xGMI, then the 1/world average"""
         if self.world > 1:
-            exchange_gradients(self.model._engine().arena.grad, self.pg)
+            self._exchanger().finish()
 
     def _phase_b(self):
-        eng = self.model._engine()
-        if self.world > 1:
-            K.scale_(eng.arena.grad, eng.arena.numel, self._static["inv_world"])
         self.opt.step()
 
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
         """Returns the (device) loss scalar = ImageLoss(sr, hr).mean() * 100 of this step (this rank's shard)."""
         if not self.model.training:
             raise RuntimeError("TSRNTrainStep.step needs model.train()")
-        self.model._engine().bind(lr_img.device)
+        self.pool.bind(lr_img.device)
         loss = self._phase_a(lr_img, hr_img)
         self._exchange()
         self._phase_b()
@@ -79,9 +86,8 @@ class TSRNTrainStep:
     def broadcast_parameters(self, src: int = 0):
         """DDP start-up: every rank adopts rank `src`'s parameters and BN buffers (one flat broadcast + buffers)."""
         if self.world > 1:
-            eng = self.model._engine()
-            eng.bind(next(self.model.parameters()).device)
-            broadcast_state(eng.arena.flat, self.model.buffers(), src, self.pg)
+            self.pool.bind(next(self.model.parameters()).device)
+            broadcast_state(self.pool.flat, self.model.buffers(), src, self.pg)
 
     # -- hipGraph replay ----------------------------------------------------------------------------------------
     def capture(self, lr_img: torch.Tensor, hr_img: torch.Tensor, warmup: int = 2):
@@ -165,11 +171,15 @@ class TPGSRTrainStep:
         self.stu_iter, self.sr_share, self.tpg_share = stu_iter, sr_share, tpg_share
         self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
         mods = self.sr + self.stu
-        self.opt = FusedAdam(mods, lr=lr, betas=betas, clip_modules=self.sr, max_norm=max_norm)
+        # one flat parameter / gradient buffer: SR net(s) first, then the students = the order their gradients become final
+        self.pool = ArenaPool(mods)
+        self.opt = FusedAdam(mods, lr=lr, betas=betas, clip_modules=self.sr, max_norm=max_norm, pool=self.pool)
         self.pg, self.world = process_group, world_size
         self._static = None
         self._graph = None
         self._dbg = {}
+        self._exch = None
+        self._overlap_exchange = True      # False while capturing hipGraphs (the all-reduce stays between the graphs)
 
     def _buffers(self, lr_img):
         dev, N = lr_img.device, lr_img.shape[0]
@@ -199,9 +209,9 @@ class TPGSRTrainStep:
         self.opt.zero_grad()
         # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
         # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
-        main, aux = torch.cuda.current_stream(), K.aux_stream(lr_img.device)
+        main, aux = K.current_stream(), K.aux_stream(lr_img.device)
         aux.wait_stream(main)
-        with torch.cuda.stream(aux):
+        with K.stream_ctx(aux):
             K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
             t_logits = self.teacher._engine().forward(st["gray_hr"], False)
             K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
@@ -236,6 +246,9 @@ class TPGSRTrainStep:
             if i < self.stu_iter - 1:      # gradient arriving through the next stage's parse_crnn_data
                 K.add(st["dsr"][i], st["dcas"], st["dsr"][i].numel(), st["dsr"][i])
             dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i)
+            if i == 0 and self.world > 1 and self._overlap_exchange:
+                # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
+                self._exchanger().launch(0)
             K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
             if getattr(self, "_debug", False):
                 self._dbg.setdefault("dprior", {})[i] = dprior.clone()
@@ -247,23 +260,37 @@ class TPGSRTrainStep:
         self.last_sr, self.last_p = srs[-1], st["p"][self.stu_iter - 1]
         return st["loss"]
 
+    def _exchanger(self):
+        if self._exch is None or self._exch.flat.data_ptr() != self.pool.grad.data_ptr():
+            inv = self._static["inv_world"]
+            b_sr, b_stu = self.pool.span(self.sr), self.pool.span(self.stu)
+            self._exch = GradientExchanger(self.pool.grad, [b_sr, (b_sr[1], b_stu[1])], self.pg,
+                                           scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv))
+        return self._exch
+
     def _exchange(self):
+        """two buckets of ONE flat buffer (SR nets | students); bucket 0 was launched inside the backward pass"""
         if self.world > 1:
-            for m in self.sr + self.stu:
-                exchange_gradients(m._engine().arena.grad, self.pg)
+            self._exchanger().finish()
 
     def _phase_b(self):
-        if self.world > 1:
-            for m in self.sr + self.stu:
-                a = m._engine().arena
-                K.scale_(a.grad, a.numel, self._static["inv_world"])
         self.opt.step()
+
+    def broadcast_parameters(self, src: int = 0):
+        """DDP start-up: every rank adopts rank `src`'s parameters (one flat broadcast) and BN buffers."""
+        if self.world > 1:
+            dev = next(self.sr[0].parameters()).device
+            self.pool.bind(dev)
+            self.teacher._engine().bind(dev)
+            bufs = [b for m in self.pool.modules + [self.teacher] for b in m.buffers()]
+            broadcast_state(self.pool.flat, bufs, src, self.pg)
+            broadcast_state(self.teacher._engine().arena.flat, [], src, self.pg)
 
     def step(self, lr_img, hr_img):
         for m in self.sr + self.stu:
             if not m.training:
                 raise RuntimeError("TPGSRTrainStep.step needs the SR nets and students in train() mode")
-            m._engine().bind(lr_img.device)
+        self.pool.bind(lr_img.device)
         self.teacher._engine().bind(lr_img.device)
         loss = self._phase_a(lr_img, hr_img)
         self._exchange()
@@ -280,6 +307,7 @@ class TPGSRTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()
+        self._overlap_exchange = False
         with torch.cuda.graph(ga):
             self._graph_loss = self._phase_a(self._lr, self._hr)
             if self.world == 1:

@@ -16,6 +16,35 @@ from . import _lib
 from ._lib import ConvArgs, WgradArgs, act_code, check
 
 
+# TPGSR_PLAN_DRYRUN=1: record and validate launch plans WITHOUT a GPU -- every wrapper checks its argument list against the
+# C-ABI signature, plans are handed to the native executor (which checks entry point and argument count), workspaces are
+# host tensors, and NOTHING is computed (outputs are uninitialised).  It exists so that the plan-recording host logic is
+# covered by the CPU test suite (tests/test_plan_dryrun_cpu.py); it is not a fallback and no product entry point enables it.
+DRYRUN = os.environ.get("TPGSR_PLAN_DRYRUN") == "1"
+
+
+class _DummyStream:
+    cuda_stream = None
+    device = torch.device("cpu")
+
+    def wait_stream(self, other):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def current_stream():
+    return _DummyStream() if DRYRUN else torch.cuda.current_stream()
+
+
+def stream_ctx(st):
+    return st if DRYRUN else torch.cuda.stream(st)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -67,6 +96,8 @@ _AUX = {}
 def aux_stream(device=None) -> "torch.cuda.Stream":
     """A further per-device stream for host-level overlap of independent sub-networks (the frozen teacher recogniser of the
     text-prior path runs on it next to the student's forward pass)."""
+    if DRYRUN:
+        return _DummyStream()
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _AUX.get(idx)
     if st is None:
@@ -150,6 +181,8 @@ class Plan:
     def run(self):
         if not self._native:
             self._build_native()
+        if DRYRUN:
+            return
         main = torch.cuda.current_stream()
         side = side_stream(main.device).cuda_stream if self._has_side else None
         rc = _lib.load().tpgsr_plan_run(self._native, main.cuda_stream, side)
@@ -251,13 +284,19 @@ def _launch(name, *args):
                 args[ai] = None
         _REC.ops.append([name, fn, args, _REC.sid])
         return
+    if DRYRUN:
+        if len(args) + 1 != len(fn.argtypes):
+            raise TypeError(f"{name}: {len(args)} arguments + stream, the C ABI takes {len(fn.argtypes)}")
+        for t, a in zip(fn.argtypes, args):
+            t.from_param(a)
+        return
     check(fn(*args, _stream()), name)
 
 
 def _p(t):
     if t is None or isinstance(t, (int, DynPtr)):
         return t
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8) and t.is_contiguous(), \
+    assert (t.is_cuda or DRYRUN) and t.dtype in (torch.float32, torch.int32, torch.uint8) and t.is_contiguous(), \
         f"tpgsr kernels need contiguous fp32 CUDA tensors (got {t.dtype}, cuda={t.is_cuda}, contiguous={t.is_contiguous()})"
     if _REC is not None:
         _REC.keep.append(t)
@@ -354,37 +393,45 @@ def deferring() -> bool:
     return _REC is not None and getattr(_REC, "deferred", None) is not None
 
 
-def wgrad_reduce(part, dbpart, Z, g: ConvGeom, dw, db=None, *, layout=0, accumulate=True, gscale=1.0):
+def wgrad_reduce(part, dbpart, Z, g: ConvGeom, dw, db=None, *, layout=0, accumulate=True, gscale=1.0, real=None):
+    """real = (Cin, KH, KW, cin_ld) of the parameter when the GEMM ran on a zero-padded operand (slab rows k = tap*cin_ld + ci
+    with ci >= Cin or tap >= KH*KW are skipped); default: the geometry's own"""
+    Cin, KH, KW, cin_ld = real if real is not None else (g.Cin, g.KH, g.KW, 0)
+    item = (part, dbpart, Z, g.K, Cin, g.Cout, KH, KW, layout, dw, db, int(accumulate), float(gscale), cin_ld)
     if deferring():   # the caller gave this layer its own slab buffers; reduced by flush_wgrad_reduces()
-        _REC.deferred.append((part, dbpart, Z, g.K, g.Cin, g.Cout, g.KH, g.KW, layout, dw, db, int(accumulate), float(gscale)))
-        return
-    _launch("tpgsr_wgrad_reduce", _p(part), _p(dbpart), Z, g.K, g.Cin, g.Cout, g.KH, g.KW, layout, _p(dw), _p(db),
-                                         int(accumulate), gscale)
+        _REC.deferred.append(item)
+    elif real is not None:
+        _reduce_program([item])
+    else:
+        _launch("tpgsr_wgrad_reduce", _p(part), _p(dbpart), Z, g.K, Cin, g.Cout, KH, KW, layout, _p(dw), _p(db),
+                int(accumulate), gscale)
+
+
+def _reduce_program(items):
+    lib = _lib.load()
+    arr = (_lib.WgradReduceDesc * len(items))()
+    blk = 0
+    seen = set()
+    for d, (part, dbpart, Z, Kd, Cin, Cout, KH, KW, layout, dw, db, acc, gscale, cin_ld) in zip(arr, items):
+        has_b = db is not None and dbpart is not None
+        d.part, d.dbpart = _p(part), (_p(dbpart) if has_b else None)
+        d.dw, d.db = _p(dw), (_p(db) if has_b else None)
+        d.Z, d.K, d.Cin, d.Cout, d.KH, d.KW, d.layout, d.accumulate, d.gscale, d.blk0 = Z, Kd, Cin, Cout, KH, KW, layout, acc, gscale, blk
+        d.cin_ld = cin_ld
+        blk += lib.tpgsr_wgrad_reduce_blocks(Kd, Cout, int(has_b))
+        assert dw.data_ptr() not in seen, "two deferred reduces of one program target the same gradient"
+        seen.add(dw.data_ptr())
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][0].device)
+    with (side() if (_REC is None or _REC.sid == 0) else _NoSide()):   # already inside a side section: stay there
+        _launch("tpgsr_wgrad_reduce_program", _p(table), len(items), blk)
 
 
 def flush_wgrad_reduces():
     """Emit ONE tpgsr_wgrad_reduce_program launch (side stream) for every reduce deferred so far in this plan."""
     rec = _REC
-    items = rec.deferred
-    if not items:
-        return
-    lib = _lib.load()
-    arr = (_lib.WgradReduceDesc * len(items))()
-    blk = 0
-    seen = set()
-    for d, (part, dbpart, Z, Kd, Cin, Cout, KH, KW, layout, dw, db, acc, gscale) in zip(arr, items):
-        has_b = db is not None and dbpart is not None
-        d.part, d.dbpart = _p(part), (_p(dbpart) if has_b else None)
-        d.dw, d.db = _p(dw), (_p(db) if has_b else None)
-        d.Z, d.K, d.Cin, d.Cout, d.KH, d.KW, d.layout, d.accumulate, d.gscale, d.blk0 = Z, Kd, Cin, Cout, KH, KW, layout, acc, gscale, blk
-        blk += lib.tpgsr_wgrad_reduce_blocks(Kd, Cout, int(has_b))
-        assert dw.data_ptr() not in seen, "two deferred reduces of one program target the same gradient"
-        seen.add(dw.data_ptr())
-    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][0].device)
-    n = len(items)
-    rec.deferred = []
-    with side():
-        _launch("tpgsr_wgrad_reduce_program", _p(table), n, blk)
+    items, rec.deferred = rec.deferred, []
+    if items:
+        _reduce_program(items)
 
 
 def pack_conv_weight(w, Cout, Cin, KH, KW, wt_f=None, wt_d=None, *, transposed=False, wscale=1.0):
@@ -608,3 +655,23 @@ def step_inc(step_dev):
 
 def scale_(x, n, coef):
     _launch("tpgsr_scale_", _p(x), n, _p(coef))
+
+
+def im2col3x3_c1(inp, N, H, W, col):
+    _launch("tpgsr_im2col3x3_c1", _p(inp), N, H, W, _p(col))
+
+
+def col2im3x3_c1(dcol, N, H, W, din):
+    _launch("tpgsr_col2im3x3_c1", _p(dcol), N, H, W, _p(din))
+
+
+def pad_channels(src, M, Cs, Cd, dst):
+    _launch("tpgsr_pad_channels", _p(src), M, Cs, Cd, _p(dst))
+
+
+def semantic_loss_fwd(p, q, n, partial, nblk):
+    _launch("tpgsr_semantic_loss_fwd", _p(p), _p(q), n, _p(partial), nblk)
+
+
+def semantic_loss_bwd(p, q, dloss, n, dp):
+    _launch("tpgsr_semantic_loss_bwd", _p(p), _p(q), _p(dloss), n, _p(dp))

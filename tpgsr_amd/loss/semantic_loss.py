@@ -1,7 +1,8 @@
 """SemanticLoss with the reference's signature (reference: loss/semantic_loss.py:10-39):
 mean|gt - pred| + KLDivLoss(reduction='mean')(log(pred + 1e-20), gt + 1e-20) on probability tensors of shape
 (T, N, C) (what interfaces/super_resolution.py:372 passes).  The fused training step computes the same quantity inside
-tpgsr_softmax_prior_fwd; this module serves callers that hold probabilities."""
+tpgsr_softmax_prior_fwd; this module serves callers that hold probabilities (forward and backward are the
+tpgsr_semantic_loss_fwd / _bwd kernels: no renormalisation, rows need not sum to 1)."""
 import torch
 from torch import nn
 
@@ -13,30 +14,25 @@ _NBLK = 64
 class _SemLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt):
-        if not pred.is_cuda:
+        if not (pred.is_cuda and gt.is_cuda):
             raise RuntimeError("tpgsr_amd losses run on the GPU only (no CPU fallback)")
-        # the kernels work on logits: log(pred) reproduces pred through the softmax when rows sum to 1; rows that do
-        # not sum to 1 (not produced on the TPGSR path) are not supported by the fused kernel
-        C = pred.shape[-1]
-        rows = pred.numel() // C
-        logits = torch.log(pred.detach().reshape(rows, C).float().clamp_min(1e-30)).contiguous()
-        gtc = gt.detach().reshape(rows, C).float().contiguous()
-        p = torch.empty(rows, C, device=pred.device)
+        if pred.shape != gt.shape:
+            raise ValueError(f"SemanticLoss: pred {tuple(pred.shape)} vs gt {tuple(gt.shape)}")
+        p = pred.detach().contiguous().float()
+        q = gt.detach().contiguous().float()
         part = torch.empty(_NBLK, 2, device=pred.device)
         loss = torch.empty((), device=pred.device)
-        K.softmax_prior_fwd(logits, gtc, rows, 1, C, 0, p, None, part, _NBLK)
-        K.semantic_loss_finalize(part, _NBLK, rows * C, 1.0, loss)
-        ctx.save_for_backward(p, gtc)
-        ctx.shape = pred.shape
+        K.semantic_loss_fwd(p, q, p.numel(), part, _NBLK)
+        K.semantic_loss_finalize(part, _NBLK, p.numel(), 1.0, loss)
+        ctx.save_for_backward(p, q)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         p, q = ctx.saved_tensors
-        count = p.numel()
-        diff = q - p
-        dp = (-torch.sign(diff) - (q + 1e-20) / (p + 1e-20)) / count      # tiny (T*N*37 elements): host-side torch ops
-        return (dp * dloss).reshape(ctx.shape), None
+        dp = torch.empty_like(p)
+        K.semantic_loss_bwd(p, q, dloss.contiguous().float().reshape(1), p.numel(), dp)
+        return dp, None
 
 
 class SemanticLoss(nn.Module):

@@ -22,7 +22,9 @@ class _CRNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gray, anchor, net):
         eng = net._engine()
-        logits = eng.forward(gray, net.training)
+        eng.bind(gray.device)
+        ctx.slot, ctx.gen = eng.acquire_slot() if net.training else (0, 0)
+        logits = eng.forward(gray, net.training, slot=ctx.slot)
         ctx.net, ctx.mode, ctx.N = net, net.training, gray.shape[0]
         ctx.save_for_backward(gray.contiguous().float())
         ctx.need_dgray = gray.requires_grad
@@ -33,7 +35,13 @@ class _CRNNFunction(torch.autograd.Function):
         if not ctx.mode:
             raise RuntimeError("backward through an eval-mode CRNN forward is not supported")
         (gray,) = ctx.saved_tensors
-        dgray = ctx.net._engine().backward(ctx.N, gray, dlogits_tnc.permute(1, 0, 2).contiguous(), ctx.need_dgray)
+        eng = ctx.net._engine()
+        eng.check_slot(ctx.slot, ctx.gen)
+        dgray = eng.backward(ctx.N, gray, dlogits_tnc.permute(1, 0, 2).contiguous(), ctx.need_dgray, slot=ctx.slot)
+        eng.release_slot(ctx.slot, ctx.gen)
+        sync = getattr(ctx.net, "_grad_sync", None)   # set by tpgsr_amd.distributed.DataParallel
+        if sync is not None:
+            sync(eng)
         return dgray, None, None
 
 
@@ -67,7 +75,8 @@ class CRNN(nn.Module):
         return eng
 
     def forward(self, input):
-        if not input.is_cuda:
+        from ... import kernels as _K
+        if not input.is_cuda and not _K.DRYRUN:
             raise RuntimeError("tpgsr_amd.model.crnn runs on an MI355X only (no CPU / stock-PyTorch fallback)")
         needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or input.requires_grad)
         if not needs_grad:

@@ -99,7 +99,9 @@ class _TSRNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, net, prior):
         eng = net._engine()
-        sr = eng.forward(x, net.training, prior)
+        eng.bind(x.device)
+        ctx.slot, ctx.gen = eng.acquire_slot() if net.training else (0, 0)
+        sr = eng.forward(x, net.training, prior, slot=ctx.slot)
         ctx.net, ctx.x_shape, ctx.mode = net, tuple(x.shape), net.training
         ctx.save_for_backward(sr)
         ctx.has_prior = prior is not None
@@ -111,7 +113,13 @@ class _TSRNFunction(torch.autograd.Function):
         if not ctx.mode:
             raise RuntimeError("backward through an eval-mode TSRN forward is not supported (the reference only "
                                "back-propagates in training mode)")
-        dprior = ctx.net._engine().backward(ctx.x_shape, sr, dsr)
+        eng = ctx.net._engine()
+        eng.check_slot(ctx.slot, ctx.gen)
+        dprior = eng.backward(ctx.x_shape, sr, dsr, slot=ctx.slot)
+        eng.release_slot(ctx.slot, ctx.gen)
+        sync = getattr(ctx.net, "_grad_sync", None)   # set by tpgsr_amd.distributed.DataParallel
+        if sync is not None:
+            sync(eng)
         return None, None, None, (dprior if ctx.has_prior else None)
 
 
@@ -125,7 +133,8 @@ class _TSRNBase(nn.Module):
         return eng
 
     def _run(self, x, prior=None):
-        if not x.is_cuda:
+        from .. import kernels as _K
+        if not x.is_cuda and not _K.DRYRUN:
             raise RuntimeError("tpgsr_amd.model.tsrn runs on an MI355X only (no CPU / stock-PyTorch fallback); "
                                "call .cuda() on the module and its inputs")
         needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())

@@ -12,11 +12,22 @@ _NBLK = 256
 
 class FusedAdam:
     def __init__(self, modules: Sequence[torch.nn.Module], lr=1e-3, betas=(0.5, 0.999), eps=1e-8,
-                 clip_modules: Iterable[torch.nn.Module] = (), max_norm=0.25):
-        self.modules = list(modules)
+                 clip_modules: Iterable[torch.nn.Module] = (), max_norm=0.25, pool=None):
+        self.modules = []
+        for m in modules:
+            if all(m is not q for q in self.modules):
+                self.modules.append(m)
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
         self.clip = set(id(m) for m in clip_modules)
         self.state = {}
+        self.pool = pool          # engine.ArenaPool: all gradient arenas are slices of one buffer (one memset)
+        for m in self.modules:
+            frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+            if frozen:
+                # the fused step walks the whole flat arena; torch.optim.Adam would skip these tensors
+                raise NotImplementedError(
+                    f"FusedAdam updates every parameter of a module; {type(m).__name__} has frozen parameters "
+                    f"({frozen[0]}, ...): drive it with torch.optim.Adam through the nn.Module API instead")
 
     def _st(self, m):
         eng = m._engine()
@@ -34,6 +45,9 @@ class FusedAdam:
         return a, st
 
     def zero_grad(self):
+        if self.pool is not None and self.pool.grad is not None:
+            K.zero(self.pool.grad, self.pool.grad.numel())
+            return
         for m in self.modules:
             a, _ = self._st(m)
             K.zero(a.grad, a.numel)
