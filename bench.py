@@ -45,7 +45,14 @@ CONFIGS = {
     "c5": dict(batch=32, stu_iter=3, tl=True, mb_per_img=242.0, gflop_per_img=31.7,
                name="C5: TPGSR-TSRN multi-stage, stu_iter 3, sr_share, three CRNN students + frozen teacher, full train step"),
 }
-DOMINANT = ("tpgsr_conv_fwd", "tpgsr_conv_fwd_bf")   # forward + data-gradient instances of the MFMA implicit-GEMM conv
+DOMINANT = ("tpgsr_conv_fwd",)   # forward + data-gradient instances of the MFMA implicit-GEMM conv
+K_POLICY = "f32"
+ARITH = {"f32": "fp32 operands on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), fp32 accumulate",
+         "x3": "fp32-equivalent: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product block, fp32 accumulate "
+               "(csrc/conv_xbf.hip); everything else fp32",
+         "bf16": "bf16 operands (RNE from fp32) on the bf16 matrix cores with fp32 accumulation in the SR network and all backward "
+                 "GEMMs; the text-prior generator's forward stays fp32-equivalent (split operands) so arg-max priors are identical "
+                 "to the fp32 oracle; activations / statistics / recurrences / losses / optimiser fp32"}
 
 
 def synthetic_batch(n, seed, device):
@@ -90,35 +97,50 @@ def build_step(cfg_key, dev, world=1, pg=None):
     return ts, [sr] + students + [teacher]
 
 
+PEAK_BY_TERMS = {0: FP32_MFMA_PEAK_TFLOPS,          # v_mfma_f32_32x32x2_f32
+                 3: BF16_MFMA_PEAK_TFLOPS / 6.0,    # fp32-equivalent: six v_mfma_f32_32x32x16_bf16 per product block
+                 1: BF16_MFMA_PEAK_TFLOPS}          # bf16 operands
+
+
 def conv_roofline(nets, reps=5):
     """Replay only the dominant kernel's launches (forward + data-gradient instances of the MFMA implicit-GEMM conv) of one
-    training step -- every recorded plan of every network -- bracketed by HIP events on the launch stream;
-    algorithmic FLOPs = 2*M*K*Cout per launch from the recorded launch geometry."""
-    ops, flops, by_kernel = [], 0.0, {}
+    training step -- every recorded plan of every network -- bracketed by HIP events on the launch stream, one timed pass
+    per arithmetic class (fp32 MFMA / split-operand bf16 MFMA / bf16 operands: they have different peaks);
+    algorithmic FLOPs = 2*M*K*Cout per launch from the recorded launch geometry.
+    frac = (time the launches would take at their class's peak) / (measured time)."""
+    classes = {}
     for net in nets:
         for pl in net._engine()._plans.values():
             for plan in (pl["fwd"], pl["bwd"]):
                 for name, fn, args, _sid in plan.ops:
                     if name in DOMINANT:
                         a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
-                        f = 2.0 * (a.N * a.OH * a.OW) * (a.KH * a.KW * a.Cin) * a.Cout
-                        flops += f
-                        ops.append((fn, args))
-                        by_kernel[name] = by_kernel.get(name, 0) + 1
+                        t = a.terms if (a.terms and a.wt_bf) else 0
+                        c = classes.setdefault(t, dict(ops=[], flops=0.0))
+                        c["flops"] += 2.0 * (a.N * a.OH * a.OW) * (a.KH * a.KW * a.Cin) * a.Cout
+                        c["ops"].append((fn, args))
     s = torch.cuda.current_stream().cuda_stream
-    for fn, args in ops:      # warm
-        fn(*args, s)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        for fn, args in ops:
+    out = {}
+    for t, c in sorted(classes.items()):
+        for fn, args in c["ops"]:      # warm
             fn(*args, s)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    return dict(launches=len(ops), flops_per_step=flops, ms_per_step=ms, by_entry_point=by_kernel,
-                avg_us_per_launch=1e3 * ms / len(ops), tflops=flops / (ms * 1e-3) / 1e12)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for fn, args in c["ops"]:
+                fn(*args, s)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[t] = dict(launches=len(c["ops"]), gflop=c["flops"] / 1e9, ms=ms, tflops=c["flops"] / (ms * 1e-3) / 1e12,
+                      peak=PEAK_BY_TERMS[t])
+    flops = sum(c["gflop"] for c in out.values()) * 1e9
+    ms = sum(c["ms"] for c in out.values())
+    ms_at_peak = sum(c["gflop"] * 1e9 / (c["peak"] * 1e12) * 1e3 for c in out.values())
+    n = sum(c["launches"] for c in out.values())
+    return dict(launches=n, flops_per_step=flops, ms_per_step=ms, by_class=out, avg_us_per_launch=1e3 * ms / n,
+                tflops=flops / (ms * 1e-3) / 1e12, frac=ms_at_peak / ms, peak=flops / (ms_at_peak * 1e-3) / 1e12)
 
 
 def _log(msg):
@@ -192,6 +214,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--prec", choices=["f32", "x3", "bf16"], default=None,
+                    help="arithmetic of the MFMA GEMMs (default: TPGSR_CONV_PREC or the library default), see tpgsr_amd/kernels.py")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured hipGraph (default: plain launches on several HIP streams; measured "
                          "faster because ROCm executes the graph's fork/join branches serially)")
@@ -217,6 +241,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
+    from tpgsr_amd import kernels as K
+    if args.prec:
+        K.set_conv_prec(args.prec)
+    global K_POLICY
+    K_POLICY = K.POLICY
     cfg = CONFIGS[args.config]
     B = cfg["batch"]
     torch.manual_seed(0)
@@ -265,26 +294,34 @@ def main():
             "metric": "training img/s (16x64->32x128, bs=%d/GPU), %s full train step" % (B, "TPGSR-TSRN" if cfg["tl"] else "TSRN"),
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "x3": "f32", "bf16": "bf16"}[K_POLICY], "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
-                       "kernel_launches_per_step": n_launch,
+                       "kernel_launches_per_step": n_launch, "arithmetic": ARITH[K_POLICY],
                        "gradient_exchange": None if world == 1 else "one flat fp32 buffer, 2 RCCL all-reduce buckets (SR net overlapped with the student backward)"},
             "final_loss": round(final_loss, 5),
         }
         _log(f"timed region done: {ms:.3f} ms/step")
         if not args.no_roofline:
             r = conv_roofline(nets)
+            names = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 3: "fp32-equivalent: split operands, 6 x v_mfma_f32_32x32x16_bf16",
+                     1: "bf16 operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate"}
             out["roofline"] = {"kernel": "MFMA implicit-GEMM conv (all conv / linear forward + data-gradient launches of the step: "
                                          "SR net, student and teacher recognisers)",
-                               "bound": "mfma", "achieved": round(r["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(r["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": r["launches"], "by_entry_point": r["by_entry_point"],
+                               "bound": "mfma", "achieved": round(r["tflops"], 2), "peak": round(r["peak"], 1),
+                               "unit": "TFLOP/s", "frac": round(r["frac"], 4), "traffic": None,
+                               "peak_note": "time-weighted over the arithmetic classes of the launches: fp32 MFMA 157.3; "
+                                            "split-operand (fp32-equivalent) 2500/6 = 416.7; bf16 operands 2500 (dense)",
+                               "frac_of_fp32_mfma_peak": round(r["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "launches_per_step": r["launches"],
+                               "by_class": {names[t]: {"launches": c["launches"], "gflop": round(c["gflop"], 2), "ms": round(c["ms"], 4),
+                                                       "tflops": round(c["tflops"], 2), "peak": round(c["peak"], 1)}
+                                            for t, c in r["by_class"].items()},
                                "avg_us_per_launch": round(r["avg_us_per_launch"], 2),
                                "gflop_per_launch": round(r["flops_per_step"] / r["launches"] / 1e9, 4),
                                "share_of_step_ms": round(r["ms_per_step"], 4),
-                               "measured_mfma_only_peak": round(mfma_probe_tflops(), 1)}
+                               "measured_fp32_mfma_only_peak": round(mfma_probe_tflops(), 1)}
             # whole-step view against SURVEY 8d's algorithmic constants (fp32 bytes / FLOPs per image per step)
             out["step_roofline"] = {"hbm_frac": round(value / world * cfg["mb_per_img"] * 1e6 / 8.0e12, 4),
                                     "fp32_flop_frac": round(value / world * cfg["gflop_per_img"] * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)}

@@ -32,7 +32,7 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
-/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc): a binding can verify its mirror */
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc): a binding can verify its mirror */
 int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -73,6 +73,14 @@ typedef struct {
                              stride-s ConvTranspose2d of InfoGen run as a stride-1 conv over the dilated strip */
   int wt_ld, wt_coff;     /* row stride / column offset of `wt` (0 = Cout / 0): lets a dgrad run on a column block */
   int stride_w;           /* output stride along W (0/1 = dense): iw = ow*stride_w + kw - pad_w (dgrad of a ConvTranspose2d) */
+  /* --- bf16 matrix-core path with split fp32 operands (csrc/conv_xbf.hip) --- */
+  int terms;              /* 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  3: fp32-equivalent on the bf16 matrix cores: every fp32
+                             operand is the exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product block.
+                             1: plain bf16 operands, fp32 accumulate.  Needs the vector loader (Cin % 4 == 0) and, for
+                             tpgsr_conv_fwd, wt_bf; otherwise the call silently stays on the fp32 kernel. */
+  int kp;                 /* K rounded up to a multiple of 32 = row length of wt_bf */
+  const void* wt_bf;      /* `wt` pre-split by tpgsr_split_bf_program: bf16 planes [3][rows][kp], rows = wt_ld (or Cout),
+                             row r = column r of `wt`, k contiguous, zero padded */
 } tpgsr_conv_args;
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);
@@ -180,6 +188,19 @@ typedef struct tpgsr_compose_bwd_desc {
 int tpgsr_compose_bwd_blocks(int Cin, int U, int G);
 int tpgsr_compose_bwd_program(const tpgsr_compose_bwd_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+/* Split every packed fp32 MFMA operand of a network into bf16 planes for the bf16 matrix-core path, in ONE launch right
+ * after tpgsr_pack_program: src fp32 [K][ld] (k-major, N <= ld columns used) -> dst bf16 [3][N][kp], kp = 32*ceil(K/32),
+ * x = dst[0] + dst[1] + dst[2] exactly, zero padded in k.  blk0 = prefix sum of tpgsr_split_bf_blocks(K, N). */
+typedef struct tpgsr_split_desc {
+  const float* src;
+  void* dst;
+  int K, N, ld, kp, blk0, reserved;
+} tpgsr_split_desc;
+int tpgsr_split_bf_blocks(int K, int N);
+int tpgsr_split_bf_program(const tpgsr_split_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+/* diagnostic: out[lane*4 + j] = what ds_read_b64_tr_b16 hands lane `lane` as element j from a [16 rows][16] image of
+ * consecutive integers, addressed like the weight-gradient fragment fetch (64 lanes, 256 ints) */
+int tpgsr_tr_probe(int* out, void* stream);
 /* diagnostic: `blocks` workgroups x 4 waves x 2*iters register-only v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) */
 int tpgsr_mfma_probe(float* out, int blocks, int iters, void* stream);
 int tpgsr_copy(const float* src, float* dst, long long n, void* stream);   /* async D2D copy (graph memcpy node) */

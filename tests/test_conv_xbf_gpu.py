@@ -1,0 +1,236 @@
+"""GPU: the bf16 matrix-core path with split fp32 operands (csrc/conv_xbf.hip).
+
+* what ds_read_b64_tr_b16 delivers (the weight-gradient fragment fetch depends on it);
+* tpgsr_split_bf_program: x == plane0 + plane1 + plane2 EXACTLY, [3][N][Kp] layout, zero padding;
+* the whole networks / train steps under TPGSR_CONV_PREC=x3 must pass the SAME parity gates as the fp32 matrix-core path
+  (the per-kernel checks are the `prec` parametrisation of tests/test_kernels_gpu.py);
+* plain bf16 operands (TERMS = 1): kernel-level tolerance, and the north_star gates (|dPSNR| < 1e-3 dB, arg-max priors)
+  measured and reported on the full-size C3 step."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tpgsr_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def K():
+    from tpgsr_amd import kernels
+    return kernels
+
+
+@pytest.fixture
+def x3():
+    import test_crnn_gpu, test_tsrn_gpu
+    k = K()
+    k.set_conv_prec("x3")
+    test_crnn_gpu.NOISE = test_tsrn_gpu.NOISE = 1.5      # ill-conditioned gradient checks only, see test_tsrn_gpu.NOISE
+    yield
+    test_crnn_gpu.NOISE = test_tsrn_gpu.NOISE = 1.0
+    k.set_conv_prec("f32")
+
+
+@pytest.fixture
+def bf16():
+    k = K()
+    k.set_conv_prec("bf16")
+    yield
+    k.set_conv_prec("f32")
+
+
+def test_tr_read_semantics():
+    """lane l of a 16-lane group receives column (l & 15) of the [4][16] block the group addresses, element j = row j."""
+    from tpgsr_amd import _lib
+    out = torch.full((256,), -1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.load().tpgsr_tr_probe(out.data_ptr(), torch.cuda.current_stream().cuda_stream), "tr_probe")
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 4)
+    print("tr probe, lanes 0..19:", got[:20].tolist())
+    want = torch.tensor([[((l >> 4) * 4 + j) * 16 + (l & 15) for j in range(4)] for l in range(64)], dtype=torch.int32)
+    assert torch.equal(got, want), got.tolist()
+
+
+def test_split_program_exact():
+    k = K()
+    g = torch.Generator().manual_seed(3)
+    for (Kd, N) in [(576, 64), (36, 37 + 3), (100, 192), (4608, 512)]:
+        w = (torch.randn(Kd, N, generator=g) * torch.exp(torch.randn(Kd, N, generator=g) * 3)).to(DEV)
+        twin, kp = k.make_bf_twin(w)
+        torch.cuda.synchronize()
+        assert kp == (Kd + 31) // 32 * 32
+        planes = twin.view(3, N, kp).float().cpu()
+        rec = (planes[0].double() + planes[1].double() + planes[2].double())
+        assert torch.equal(rec[:, :Kd].t().contiguous().float(), w.cpu()), (Kd, N)      # exact three-term split
+        assert (planes[:, :, Kd:] == 0).all()
+        assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-45).all()
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 64, 64, 3, 3, 1, 1), (3, 7, 13, 64, 96, 1, 1, 0, 0), (2, 2, 27, 512, 512, 2, 2, 0, 0),
+                                  (3, 1, 5, 512, 37, 1, 1, 0, 0)])
+def test_bf16_operands_kernel_level(case, bf16):
+    """TERMS = 1: error of bf16-rounded operands with exact products and fp32 accumulation, against fp64 on the bf16-ROUNDED
+    operands (tight) and on the original operands (bf16 level)."""
+    k = K()
+    N, H, W, Ci, Co, KH, KW, ph, pw = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, KH, KW, generator=g) / math.sqrt(Ci * KH * KW)
+    ref = F.conv2d(x.double(), w.double(), None, padding=(ph, pw))
+    ref_r = F.conv2d(x.bfloat16().double(), w.bfloat16().double(), None, padding=(ph, pw))
+    geom = k.ConvGeom(N, H, W, Ci, Co, KH, KW, ph, pw)
+    Cp = (Co + 3) // 4 * 4
+    wf = torch.zeros(KH * KW * Ci, Cp, device=DEV)
+    wf[:, :Co] = w.permute(2, 3, 1, 0).reshape(-1, Co).to(DEV)
+    k.make_bf_twin(wf)
+    out = torch.full((geom.M, Co), float("nan"), device=DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    k.conv_fwd(k.make_conv_args(geom, xd, wf, out, wt_ld=Cp))
+    torch.cuda.synchronize()
+    got = out.reshape(N, geom.OH, geom.OW, Co).permute(0, 3, 1, 2).cpu().double()
+    e_r = ((got - ref_r).abs().max() / ref_r.abs().max()).item()
+    e = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f"bf16 operands {case}: vs rounded-operand fp64 {e_r:.2e}, vs fp64 {e:.2e}")
+    assert e_r < 5e-6 and e < 2e-2
+    # weight gradient with bf16 operands
+    dy = torch.randn(ref.shape, generator=g)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(x.bfloat16().double(), wr, None, padding=(ph, pw)).backward(dy.bfloat16().double())
+    Z = k.wgrad_splits(geom.M, geom.K, Co)
+    part = torch.full((Z, geom.K, Co), float("nan"), device=DEV)
+    dyp = torch.zeros(geom.M, Cp, device=DEV)
+    dyp[:, :Co] = dy.permute(0, 2, 3, 1).reshape(-1, Co).to(DEV)
+    k.conv_wgrad(k.make_wgrad_args(k.make_conv_args(geom, xd), dyp, part, None, dy_ld=Cp))
+    dw = torch.zeros(Co, Ci, KH, KW, device=DEV)
+    k.wgrad_reduce(part, None, Z, geom, dw, None, accumulate=False)
+    torch.cuda.synchronize()
+    e_w = ((dw.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max()).item()
+    print(f"   wgrad vs rounded-operand fp64 {e_w:.2e}")
+    assert e_w < 2e-5
+
+
+def test_gradient_error_vs_fp64_truth():
+    """How far each arithmetic mode is from the TRUTH (the oracle evaluated in fp64) on the recogniser's parameter
+    gradients -- the most rounding-sensitive quantity of the path (7 convs + 2 BiLSTMs deep): the oracle's own fp32 run, the fp32
+    matrix cores, the split-operand bf16 matrix cores (x3) and plain bf16 operands.  x3 must not be further from the truth
+    than the fp32 modes are."""
+    from tpgsr_amd.model.crnn import crnn
+    k = K()
+    sd = O.recipe_state_dict(O.crnn_spec(), 19)
+    lr, _ = O.synthetic_batch(3, 8)
+    gray = O.parse_crnn_data(lr)
+    gl = torch.randn(26, 3, 37, generator=torch.Generator().manual_seed(2))
+
+    def oracle(dt):
+        p = O.as_params({a: (b.to(dt) if b.is_floating_point() else b) for a, b in sd.items()})
+        y = O.crnn_forward(p, gray.to(dt), training=True)
+        (y * gl.to(dt)).sum().backward()
+        return {a: b.grad.double() for a, b in p.items() if b.requires_grad}
+
+    truth, o32 = oracle(torch.float64), oracle(torch.float32)
+
+    def dist(g):
+        num = sum(float((g[a] - truth[a]).pow(2).sum()) for a in truth)
+        den = sum(float(truth[a].pow(2).sum()) for a in truth)
+        return (num / den) ** 0.5
+
+    res = {"oracle fp32 (CPU)": dist(o32)}
+    for prec in ("f32", "x3", "bf16"):
+        k.set_conv_prec(prec)
+        try:
+            net = crnn.CRNN(32, 1, 37, 256)
+            net.load_state_dict(sd)
+            net = net.to(DEV).train()
+            y = net(gray.to(DEV))
+            (y * gl.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            res[prec] = dist({a: b.grad.detach().cpu().double() for a, b in net.named_parameters()})
+        finally:
+            k.set_conv_prec("f32")
+    print("CRNN parameter-gradient distance to the fp64 truth (global relative L2):", {a: f"{b:.3e}" for a, b in res.items()})
+    assert res["x3"] <= 2.0 * max(res["f32"], res["oracle fp32 (CPU)"]) and res["x3"] < 5e-3
+    assert res["bf16"] < 0.2
+
+
+# ---- whole networks under the fp32-equivalent split path: the fp32 gates, unchanged ------------------------------------
+def test_tsrn_golden_x3(golden_dir, x3):
+    import test_tsrn_gpu as T
+    T.test_tsrn_forward_backward_vs_golden(golden_dir)
+    T.test_tsrn_gradients_vs_oracle_nostn()
+    T.test_train_trajectory_nostn(golden_dir)
+    T.test_tsrn_tl_vs_golden(golden_dir)
+    T.test_tsrn_tl_gradients_vs_oracle_nostn()
+
+
+def test_crnn_golden_x3(golden_dir, x3):
+    import test_crnn_gpu as T
+    T.test_crnn_vs_golden(golden_dir)
+    T.test_crnn_gradients_vs_oracle()
+    T.test_train_c3_step_vs_golden(golden_dir)
+    T.test_cascade_two_stages_vs_oracle()
+
+
+def test_fullsize_x3(x3):
+    import test_fullsize_gpu as T
+    T.test_c2_bs48_step0_vs_oracle()
+    T.test_c3_bs48_step0_vs_oracle()
+    T.test_c5_shape_stu_iter3_sr_share_bs32_vs_oracle()
+
+
+@pytest.mark.parametrize("seed", [1234, 77, 4242])
+def test_c3_bs48_bf16_policy_north_star_gates(seed, bf16):
+    """BASELINE.json quotes C3 / C4 in bf16.  The bf16 policy (tpgsr_amd/kernels.py: bf16 operands in the SR network and all
+    backward GEMMs, the text-prior generator's forward fp32-equivalent) against the fp32 ORACLE on the gates `north_star`
+    states, at the full batch size, on three different batches: |dPSNR| < 1e-3 dB and IDENTICAL arg-max text priors."""
+    import test_fullsize_gpu as T
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    T._threads()
+    sr, stus, teacher, sd_sr, sd_s, sd_t = T._tpgsr(1)
+    lr, hr = O.synthetic_batch(48, seed)
+    ts = TPGSRTrainStep([sr], stus, teacher, stu_iter=1)
+    loss = ts.step(lr.to(DEV), hr.to(DEV))
+    torch.cuda.synchronize()
+    ps, pt, pu = O.as_params(sd_sr), O.as_params(sd_t, False), [O.as_params(x) for x in sd_s]
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
+    ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=1)
+    dpsnr = abs(T._psnr(ts.last_sr, hr) - T._psnr(ref["sr"], hr))
+    am = ts.last_p.cpu().permute(1, 0, 2).argmax(-1)
+    mism = int((am != ref["priors"][0].argmax(-1)).sum())
+    gn, gn_ref = ts.opt.grad_norm(sr).item(), float(ref["grad_norms"][0])
+    print(f"C3 bs48 bf16 policy (seed {seed}): loss {loss.item():.5f} vs {ref['loss'].item():.5f}; |dPSNR| {dpsnr:.3e} dB; "
+          f"arg-max mismatches {mism} / {am.numel()}; SR grad norm {gn:.3f} vs {gn_ref:.3f}")
+    assert dpsnr < 1e-3
+    assert mism == 0
+    assert abs(loss.item() - ref["loss"].item()) < 2e-3 * ref["loss"].item()
+    assert abs(gn - gn_ref) < 3e-2 * gn_ref
+
+
+def test_c5_shape_bf16_policy_gates(bf16):
+    """the multi-stage cascade (stu_iter 3, sr_share, bs 32) under the bf16 policy: stage 0 sees the same input as the oracle's
+    stage 0 -> identical arg-max prior; later stages read an SR image that differs at bf16 level, so their priors are compared
+    statistically; the final SR image must still hold the PSNR gate."""
+    import test_fullsize_gpu as T
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    T._threads()
+    sr, stus, teacher, sd_sr, sd_s, sd_t = T._tpgsr(3, seeds=(21, 22, 23))
+    lr, hr = O.synthetic_batch(32, 555)
+    ts = TPGSRTrainStep([sr], stus, teacher, stu_iter=3, sr_share=True, tpg_share=False)
+    loss = ts.step(lr.to(DEV), hr.to(DEV))
+    torch.cuda.synchronize()
+    ps, pt, pu = O.as_params(sd_sr), O.as_params(sd_t, False), [O.as_params(x) for x in sd_s]
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
+    ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=3, sr_share=True, tpg_share=False)
+    dpsnr = abs(T._psnr(ts.last_sr, hr) - T._psnr(ref["sr"], hr))
+    mism = [int((ts._static["p"][i].cpu().permute(1, 0, 2).argmax(-1) != ref["priors"][i].argmax(-1)).sum()) for i in range(3)]
+    print(f"C5-shape bf16 policy: loss {loss.item():.5f} vs {ref['loss'].item():.5f}; |dPSNR| {dpsnr:.3e} dB; arg-max mismatches per "
+          f"stage {mism} / {26 * 32}")
+    assert mism[0] == 0
+    assert max(mism) <= 26 * 32 // 50
+    assert dpsnr < 1e-3
+    assert abs(loss.item() - ref["loss"].item()) < 3e-3 * ref["loss"].item()

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import tpgsr_oracle as O  # noqa: E402
 
 DEV = "cuda"
+NOISE = 1.0     # see tests/test_tsrn_gpu.py
 
 
 def _build(seed=103):
@@ -227,12 +228,12 @@ def test_crnn_gradients_vs_oracle():
     for n, q in net.named_parameters():
         ref = p[n].grad
         rel = (q.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-3 * gmax)
-        if rel > 3e-3:
+        if rel > 3e-3 * NOISE:
             bad.append((n, rel))
     assert not bad, bad[:10]
     rel = (gd.grad.cpu() - gr.grad).norm().item() / gr.grad.norm().item()
     print("dgray rel err", rel)
-    assert rel < 3e-3
+    assert rel < 3e-3 * NOISE
 
 
 def _c3_models(seeds=(301, 302, 303), stn=True, n_sr=1, n_stu=1):

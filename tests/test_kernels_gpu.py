@@ -40,8 +40,21 @@ def pack_f(w):  # [Co][Ci][KH][KW] -> [K][Co] on device through the kernel under
     wd = torch.empty(KH * KW * Co, Ci, device=DEV)
     wdev = w.to(DEV).contiguous()
     k.pack_conv_weight(wdev, Co, Ci, KH, KW, wf, wd)
+    if k.CONV_TERMS:
+        k.make_bf_twin(wf)
+        k.make_bf_twin(wd)
     torch.cuda.synchronize()
     return wf, wd
+
+
+@pytest.fixture(params=["f32", "x3"])
+def prec(request):
+    """MFMA arithmetic of the conv / linear GEMMs: fp32 matrix cores, or the fp32-equivalent split-operand path on the
+    bf16 matrix cores (csrc/conv_xbf.hip) -- the SAME tolerances must hold for both."""
+    k = K()
+    k.set_conv_prec(request.param)
+    yield request.param
+    k.set_conv_prec("f32")
 
 
 def mish(x):
@@ -65,7 +78,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_plain(case):
+def test_conv_fwd_plain(case, prec):
     N, H, W, Ci, Co, KH, KW, ph, pw = case
     k = K()
     g = torch.Generator().manual_seed(sum(case))
@@ -94,7 +107,7 @@ def test_conv_fwd_plain(case):
 
 
 @pytest.mark.parametrize("Cout,ks,ps", [(192, 1, False), (256, 3, True), (192, 3, False)])
-def test_conv_fwd_wide_tiles(Cout, ks, ps):
+def test_conv_fwd_wide_tiles(Cout, ks, ps, prec):
     """Wide outputs (Cout = 192 / 256: several column tiles per pixel tile) on a grid of > 512 pixel tiles with a ragged
     last one: loader affine + residual, bias, optional pixel-shuffle store."""
     k = K()
@@ -123,7 +136,7 @@ def test_conv_fwd_wide_tiles(Cout, ks, ps):
     assert relerr(got, want) < 3e-6
 
 
-def test_conv_fwd_prologue_epilogue_bnstats():
+def test_conv_fwd_prologue_epilogue_bnstats(prec):
     """loader: mish(scale*x+shift) + in2 ; epilogue: bias, relu, per-block BN partial sums."""
     k = K()
     N, H, W, C = 2, 16, 64, 64
@@ -175,7 +188,7 @@ def test_conv_fwd_prologue_epilogue_bnstats():
     assert (y_got - y_ref).abs().max() < 2e-5
 
 
-def test_conv_pixel_shuffle_store_and_gather():
+def test_conv_pixel_shuffle_store_and_gather(prec):
     """out_ps writes nn.PixelShuffle(2) layout; in_ps / dy_ps read it back as the un-shuffled tensor."""
     k = K()
     N, H, W, C = 2, 8, 24, 64
@@ -218,7 +231,7 @@ def test_conv_pixel_shuffle_store_and_gather():
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[2], CONV_CASES[4], CONV_CASES[6], CONV_CASES[9]])
-def test_conv_wgrad(case):
+def test_conv_wgrad(case, prec):
     N, H, W, Ci, Co, KH, KW, ph, pw = case
     k = K()
     g = torch.Generator().manual_seed(sum(case) + 1)
@@ -241,7 +254,7 @@ def test_conv_wgrad(case):
     assert relerr(db.cpu() - 1, b.grad) < 1e-5
 
 
-def test_wgrad_with_loader_prologue():
+def test_wgrad_with_loader_prologue(prec):
     k = K()
     N, H, W, C = 2, 16, 64, 64
     g = torch.Generator().manual_seed(17)
@@ -264,7 +277,7 @@ def test_wgrad_with_loader_prologue():
     assert relerr(dw.cpu(), w.grad) < 1e-5
 
 
-def test_tail_fold_matches_conv9x9():
+def test_tail_fold_matches_conv9x9(prec):
     """9x9 C->4 conv + tanh == 9x1 conv with 36 folded columns + shift-sum; and its backward."""
     k = K()
     N, H, W, C, Co, KS = 2, 12, 40, 64, 4, 9
@@ -279,6 +292,9 @@ def test_tail_fold_matches_conv9x9():
     wf = torch.empty(KS * C, KS * Co, device=DEV); wd = torch.empty(KS * KS * Co, C, device=DEV)
     wdev = w.detach().float().to(DEV).contiguous()
     k.pack_tail_weight(wdev, Co, C, KS, wf, wd)
+    if k.CONV_TERMS:
+        k.make_bf_twin(wf)
+        k.make_bf_twin(wd)
     geom = k.ConvGeom(N, H, W, C, KS * Co, KS, 1, KS // 2, 0)
     P = torch.empty(geom.M, KS * Co, device=DEV)
     xd = to_nhwc(x)

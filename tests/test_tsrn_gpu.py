@@ -10,6 +10,11 @@ pytestmark = pytest.mark.gpu
 from oracle import tpgsr_oracle as O  # noqa: E402
 
 DEV = "cuda"
+# Multiplier on the tolerances of ILL-CONDITIONED gradient checks (through the TPS rectification / deep recurrences, where the
+# oracle's own fp32-vs-fp64 distance is at the tolerance's level).  1 for the fp32 matrix-core path they were calibrated on;
+# tests/test_conv_xbf_gpu.py re-runs them with 1.5 for the split-operand path: a different accumulation order draws a different
+# sample of the same rounding noise (its distance to the fp64 truth is measured there and is not larger).
+NOISE = 1.0
 
 
 def _psnr(a, b):
@@ -51,8 +56,8 @@ def test_tsrn_forward_backward_vs_golden(golden_dir):
         k = min(8, got.numel())
         eh = (got.reshape(-1)[:k] - torch.tensor(head[:k])).abs().max().item() / max(ref_norm / np.sqrt(got.numel()), 1e-3 * gmax / np.sqrt(got.numel()))
         worst = max(worst, e)
-        assert e < 2e-2, (n, e, ref_norm)
-        assert eh < 0.2 or "stn_head" in n, (n, eh)
+        assert e < 2e-2 * NOISE, (n, e, ref_norm)
+        assert eh < 0.2 * NOISE or "stn_head" in n, (n, eh)
     print("worst grad-norm rel err", worst)
     # BN running statistics after one training forward
     rn = [str(n) for n in g["running_names"]]

@@ -29,7 +29,8 @@ class ConvArgs(C.Structure):
                 ("in_ld", ci), ("in_coff", ci), ("in2_ld", ci), ("in_act", ci), ("in_ps", ci),
                 ("Cout", ci), ("KH", ci), ("KW", ci), ("pad_h", ci), ("pad_w", ci), ("OH", ci), ("OW", ci),
                 ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci),
-                ("in_b", vp), ("cin_a", ci), ("in_b_ld", ci), ("in_dil_w", ci), ("wt_ld", ci), ("wt_coff", ci), ("stride_w", ci)]
+                ("in_b", vp), ("cin_a", ci), ("in_b_ld", ci), ("in_dil_w", ci), ("wt_ld", ci), ("wt_coff", ci), ("stride_w", ci),
+                ("terms", ci), ("kp", ci), ("wt_bf", vp)]
 
 
 class WgradArgs(C.Structure):
@@ -51,6 +52,10 @@ class WgradReduceDesc(C.Structure):
     _fields_ = [("part", vp), ("dbpart", vp), ("dw", vp), ("db", vp), ("Z", ci), ("K", ci), ("Cin", ci), ("Cout", ci),
                 ("KH", ci), ("KW", ci), ("layout", ci), ("accumulate", ci), ("gscale", cf), ("blk0", ci), ("cin_ld", ci),
                 ("reserved", ci)]
+
+
+class SplitDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("K", ci), ("N", ci), ("ld", ci), ("kp", ci), ("blk0", ci), ("reserved", ci)]
 
 
 class PlanArg(C.Union):
@@ -135,6 +140,9 @@ _SIGS = {
     "tpgsr_pad_channels": (ci, [vp, ll, ci, ci, vp, vp]),
     "tpgsr_semantic_loss_fwd": (ci, [vp, vp, ll, vp, ci, vp]),
     "tpgsr_semantic_loss_bwd": (ci, [vp, vp, vp, ll, vp, vp]),
+    "tpgsr_split_bf_blocks": (ci, [ci, ci]),
+    "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
+    "tpgsr_tr_probe": (ci, [vp, vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["tpgsr_last_error"])
@@ -162,7 +170,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

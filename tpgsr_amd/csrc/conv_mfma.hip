@@ -315,6 +315,9 @@ __global__ __launch_bounds__(768) void conv3x3_wstat_kernel(tpgsr_conv_args a, c
   }
 }
 
+extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, int K, int ld, hipStream_t st);
+extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long M, int K, int Z, int MB, int ld, hipStream_t st);
+
 static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
   TPGSR_CHECK_ARG(a && a->in, "%s: null input", who);
   TPGSR_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0,
@@ -356,6 +359,12 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   int vecB = ((wld_ & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;   // rows padded to a multiple of 4 floats
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
+  // bf16 matrix cores with split operands (conv_xbf.hip): vector loader + pre-split weights required
+  if (a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0) {
+    TPGSR_CHECK_ARG(a->terms == 1 || a->terms == 3, "tpgsr_conv_fwd: terms must be 0, 1 or 3");
+    TPGSR_CHECK_ARG(a->kp >= K && (a->kp & 31) == 0 && ((uintptr_t)a->wt_bf & 15) == 0, "tpgsr_conv_fwd: bad split operand (kp %d, K %d)", a->kp, K);
+    return tpgsr_conv_fwd_xbf_launch(a, M, K, ld, st);
+  }
   // the 64-channel 3x3 trunk convs on 64-wide maps: weights-stationary kernel (TPGSR_CONV_WSTAT=0 falls back to the tile loop)
   static const bool wstat_on = [] { const char* e = getenv("TPGSR_CONV_WSTAT"); return !(e && e[0] == '0'); }();
   if (wstat_on && ld == 0 && a->KH == 3 && a->KW == 3 && a->pad_h == 1 && a->pad_w == 1 && a->Cin == 64 && a->Cout == 64 &&
@@ -615,6 +624,10 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
               ((uintptr_t)w->dy & 15) == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
+  if (a->terms > 0 && (a->Cin & 3) == 0 && (vecY || w->dy_ps)) {
+    TPGSR_CHECK_ARG(a->terms == 1 || a->terms == 3, "tpgsr_conv_wgrad: terms must be 0, 1 or 3");
+    return tpgsr_conv_wgrad_xbf_launch(w, M, K, Z, MB, ld, st);
+  }
 #define TPGSR_WG_CASE(B) case B: hipLaunchKernelGGL(conv_wgrad_kernel<B>, grid, dim3(256), 0, st, *w, (int)M, K, MB, vecY); break;
   if ((a->Cin & 3) != 0 || (!vecY && !w->dy_ps)) {
     hipLaunchKernelGGL(conv_wgrad_kernel<-1>, grid, dim3(256), 0, st, *w, (int)M, K, MB, vecY);

@@ -75,7 +75,7 @@ const std::unordered_map<std::string, Entry>& registry() {
       TPGSR_REG(tpgsr_image_loss_bwd), TPGSR_REG(tpgsr_sumsq_partial), TPGSR_REG(tpgsr_clip_coef),
       TPGSR_REG(tpgsr_adam_step), TPGSR_REG(tpgsr_step_inc), TPGSR_REG(tpgsr_scale_),
       TPGSR_REG(tpgsr_im2col3x3_c1), TPGSR_REG(tpgsr_col2im3x3_c1), TPGSR_REG(tpgsr_pad_channels),
-      TPGSR_REG(tpgsr_semantic_loss_fwd), TPGSR_REG(tpgsr_semantic_loss_bwd),
+      TPGSR_REG(tpgsr_semantic_loss_fwd), TPGSR_REG(tpgsr_semantic_loss_bwd), TPGSR_REG(tpgsr_split_bf_program),
   };
   return r;
 }

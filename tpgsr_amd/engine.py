@@ -184,6 +184,7 @@ class ConvLayer:
         else:
             eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=KH, KW=KW, kind=0,
                          f_ld=self.Cout, wscale=wscale)
+        eng.register_operand(self.wt_f, self.wt_d)
 
     def geom(self, N, H, W) -> ConvGeom:
         return ConvGeom(N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.pad_h, self.pad_w)
@@ -296,6 +297,7 @@ class GruLayer:
                          src3=P[gp + "bias_ih_l0" + suf], numel=96)
             eng.add_pack(P[gp + "weight_hh_l0" + suf], self.whh[d], None, kind=2)
             eng.add_pack(P[gp + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
+        eng.register_operand(self.wc_f, self.wc_d)
 
     def fwd(self, N, H, W, x, gi, h, gates=None, **loader):
         """gi = loader(x) Wc^T + bc; h = BiGRU(gi) (gates: saved for bwd in training plans)"""
@@ -348,6 +350,7 @@ class TConvStrip:
         self.wt_d = torch.zeros(3 * self.Cout, self.Cp, dtype=F32, device=dev)
         eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=3, KW=3, kind=4, f_ld=self.Cout,
                      d_ld=self.Cp, cin_ld=self.Cp)
+        eng.register_operand(self.wt_f, self.wt_d)
 
     def out_w(self, Win):
         return (Win - 1) * self.sw - 2 * self.pw + 3
@@ -390,6 +393,8 @@ class _EngineBase:
         self._plans: Dict[tuple, dict] = {}
         self._scratch: Dict[str, torch.Tensor] = {}
         self._pack: List[tuple] = []
+        self._operands: List[torch.Tensor] = []
+        self._split_n = 0
         self._bn_layers: List["BNLayer"] = []
         self._pending_batches = 0
         self._wg_idx, self._cur_ws = 0, None
@@ -472,6 +477,38 @@ class _EngineBase:
                  numel=None, d_ld=0, cin_ld=0):
         self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld))
 
+    def register_operand(self, *tensors):
+        """fp32 MFMA operands [K][ld] packed by the pack program: get a bf16 split twin when the bf16 matrix-core path is on"""
+        for t in tensors:
+            if t is not None:
+                assert t.dim() == 2 and t.is_contiguous()
+                self._operands.append(t)
+
+    def _finish_split_table(self):
+        from ._lib import SplitDesc, load
+        self._split_n = 0
+        ops, seen = [], set()
+        for t in self._operands:
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                ops.append(t)
+        if K.POLICY == "f32" or not ops:
+            return
+        lib = load()
+        arr = (SplitDesc * len(ops))()
+        blk = 0
+        self._split_keep = []
+        for d, t in zip(arr, ops):
+            Kd, N = t.shape
+            kp = (Kd + 31) // 32 * 32
+            twin = torch.zeros(3 * N * kp, dtype=torch.bfloat16, device=self.device)
+            K.register_bf_twin(t, twin, kp)
+            d.src, d.dst, d.K, d.N, d.ld, d.kp, d.blk0 = t.data_ptr(), twin.data_ptr(), Kd, N, N, kp, blk
+            blk += lib.tpgsr_split_bf_blocks(Kd, N)
+            self._split_keep += [t, twin]
+        self._split_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self._split_n, self._split_blocks = len(ops), blk
+
     def _finish_pack_table(self):
         n = len(self._pack)
         arr = (PackDesc * n)()
@@ -495,6 +532,8 @@ class _EngineBase:
 
     def pack_all(self):
         K.pack_program(self._pack_dev, self._pack_n, self._pack_blocks)
+        if self._split_n:
+            K.split_bf_program(self._split_dev, self._split_n, self._split_blocks)
 
     def bind(self, device):
         rebuilt = self.arena.ensure(device)
@@ -505,6 +544,7 @@ class _EngineBase:
         self._scratch.clear()
         self._live.clear()
         self._pack = []
+        self._operands = []
         self._bn_layers = []
         m = self.module
         self.P = dict(m.named_parameters())
@@ -518,6 +558,7 @@ class _EngineBase:
                 raise RuntimeError(f"buffer {name} is on {b.device}, parameters on {device}: call module.to(device) first")
         self._build_layers()
         self._finish_pack_table()
+        self._finish_split_table()
 
     def flush_counters(self):
         if self._pending_batches and self.device is not None:
@@ -611,10 +652,10 @@ class TSRNEngine(_EngineBase):
         self._cur_ws, self._wg_idx, self._compose = ws, 0, []
         for bn in self._bn_layers:
             bn.use(ws)
-        with recording(fwd):
+        with recording(fwd), K.conv_terms(K.terms_for("sr", "fwd")):
             self._record_fwd(N, H, W, training, ws)
         if training:
-            with recording(bwd):
+            with recording(bwd), K.conv_terms(K.terms_for("sr", "bwd")):
                 self._record_bwd(N, H, W, ws)
                 if self.defer_reduce:
                     K.flush_wgrad_reduces()
@@ -928,3 +969,4 @@ class _FC1AsConv(ConvLayer):
         self.wt_f = torch.empty(2 * Cin, Cout, dtype=F32, device=dev)
         self.wt_d = torch.empty(2 * Cout, Cin, dtype=F32, device=dev)
         eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=Cout, Cin=Cin, KH=1, KW=2, kind=0, f_ld=Cout)
+        eng.register_operand(self.wt_f, self.wt_d)

@@ -33,6 +33,7 @@ class Conv0Im2col:
         self.wt_f = torch.zeros(12, self.Cout, dtype=F32, device=dev)      # rows 9..11 stay zero
         self.wt_d = torch.zeros(self.Cout, 12, dtype=F32, device=dev)      # columns 9..11 stay zero
         eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=9, KH=1, KW=1, kind=0, f_ld=self.Cout, d_ld=12)
+        eng.register_operand(self.wt_f, self.wt_d)
 
     def fwd(self, N, H, W, gray, col, out, **kw):
         K.im2col3x3_c1(gray, N, H, W, col)
@@ -65,6 +66,7 @@ class PaddedLinear:
         self.wt_f = torch.zeros(self.Cin, self.Cp, dtype=F32, device=dev)
         self.wt_d = torch.zeros(self.Cp, self.Cin, dtype=F32, device=dev)
         eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, kind=0, f_ld=self.Cp)
+        eng.register_operand(self.wt_f, self.wt_d)
 
     def fwd(self, N, H, W, x, out, **kw):
         K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, self.Cin, self.Cout), x, self.wt_f, out, bias=self.b, wt_ld=self.Cp, **kw))
@@ -103,6 +105,7 @@ class LstmLayer:
             eng.add_pack(P[r + "bias_ih_l0" + suf], self.bih[d * G4:(d + 1) * G4], None, kind=2)
             eng.add_pack(P[r + "bias_hh_l0" + suf], self.bhh[d], None, kind=2)
             eng.add_pack(P[r + "weight_hh_l0" + suf], self.whh_f[d], None, Cout=G4, Cin=Hh, kind=0, f_ld=G4)
+        eng.register_operand(self.wih_f, self.wih_d)
         nout = P[prefix + ".embedding.weight"].shape[0]
         self.emb = (ConvLayer if nout % 4 == 0 else PaddedLinear)(eng, prefix + ".embedding.weight", prefix + ".embedding.bias")
 
@@ -199,15 +202,15 @@ class CRNNEngine(_EngineBase):
         self._cur_ws, self._wg_idx = ws, 0
         for bn in self._bn_layers:
             bn.use(ws)
-        with recording(fwd):
+        with recording(fwd), K.conv_terms(K.terms_for("tpg", "fwd")):
             self._record_fwd(N, training, ws)
         if training:
-            with recording(bwd):
+            with recording(bwd), K.conv_terms(K.terms_for("tpg", "bwd")):
                 self._record_bwd(N, ws)
                 if defer:
                     K.flush_wgrad_reduces()
                 bwd.join()
-            with recording(dgp):   # d gray: only later cascade stages ask for it (their input is the previous SR image)
+            with recording(dgp), K.conv_terms(K.terms_for("tpg", "bwd")):   # d gray: only later cascade stages ask for it
                 self._record_dgray(N, ws)
         return dict(fwd=fwd, bwd=bwd, dgray=dgp, ws=ws)
 

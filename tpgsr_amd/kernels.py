@@ -23,6 +23,56 @@ from ._lib import ConvArgs, WgradArgs, act_code, check
 DRYRUN = os.environ.get("TPGSR_PLAN_DRYRUN") == "1"
 
 
+# Arithmetic of the MFMA GEMMs (tpgsr_conv_args.terms): 0 = fp32 matrix cores; 3 = fp32-equivalent on the bf16 matrix cores
+# (every operand split exactly into three bf16 terms, csrc/conv_xbf.hip); 1 = plain bf16 operands, fp32 accumulate.
+# POLICY (TPGSR_CONV_PREC) names what the engines record:
+#   "f32"  : fp32 matrix cores everywhere
+#   "x3"   : split operands everywhere -- fp32-equivalent results, every parity test at its fp32 tolerance
+#   "bf16" : BASELINE.json's bf16 configurations: bf16 operands in the SR network and in every backward pass, while the
+#            FORWARD pass of the text-prior generator (CRNN) stays fp32-equivalent, so the arg-max text priors are identical
+#            to the fp32 oracle's by construction; fp32 accumulation, activations, statistics, losses and optimiser throughout
+# CONV_TERMS is the value make_conv_args stamps into launches while a plan is recorded / a kernel is called directly.
+_TERMS = {"f32": 0, "x3": 3, "bf16": 1}
+POLICY = os.environ.get("TPGSR_CONV_PREC", "f32")
+if POLICY not in _TERMS:
+    raise ValueError(f"TPGSR_CONV_PREC={POLICY!r}: expected one of {sorted(_TERMS)}")
+CONV_TERMS = _TERMS[POLICY]
+_BF_TWIN = {}     # data_ptr of a packed fp32 operand -> (bf16 planes tensor, kp)
+
+
+def set_conv_prec(name: str):
+    """'f32' | 'x3' | 'bf16' for plans recorded from now on (engines bound earlier keep their recorded plans)"""
+    global CONV_TERMS, POLICY
+    POLICY, CONV_TERMS = name, _TERMS[name]
+
+
+def terms_for(net_kind: str, phase: str) -> int:
+    """what an engine records under the current policy; net_kind 'sr' | 'tpg' (text-prior generator), phase 'fwd' | 'bwd'"""
+    if POLICY == "bf16":
+        return 3 if (net_kind == "tpg" and phase == "fwd") else 1
+    return _TERMS[POLICY]
+
+
+class conv_terms:
+    """``with conv_terms(t):`` stamps `t` into the launches recorded inside"""
+
+    def __init__(self, terms):
+        self.terms = terms
+
+    def __enter__(self):
+        global CONV_TERMS
+        self.prev, CONV_TERMS = CONV_TERMS, self.terms
+
+    def __exit__(self, *exc):
+        global CONV_TERMS
+        CONV_TERMS = self.prev
+        return False
+
+
+def register_bf_twin(wt: torch.Tensor, twin: torch.Tensor, kp: int):
+    _BF_TWIN[wt.data_ptr()] = (twin, kp)
+
+
 class _DummyStream:
     cuda_stream = None
     device = torch.device("cpu")
@@ -361,6 +411,16 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
     a.in_dil_w = in_dil_w
     a.wt_ld, a.wt_coff = wt_ld, wt_coff
     a.stride_w = stride_w
+    a.terms = 0
+    if CONV_TERMS and g.Cin % 4 == 0:
+        if wt is None or isinstance(wt, (int, DynPtr)):
+            a.terms = CONV_TERMS                       # weight-gradient use: no weight operand
+        else:
+            tw = _BF_TWIN.get(wt.data_ptr())
+            if tw is not None:
+                a.terms, a.kp, a.wt_bf = CONV_TERMS, tw[1], tw[0].data_ptr()
+                if _REC is not None:
+                    _REC.keep.append(tw[0])
     return a
 
 
@@ -675,3 +735,22 @@ def semantic_loss_fwd(p, q, n, partial, nblk):
 
 def semantic_loss_bwd(p, q, dloss, n, dp):
     _launch("tpgsr_semantic_loss_bwd", _p(p), _p(q), _p(dloss), n, _p(dp))
+
+
+def make_bf_twin(wt: torch.Tensor):
+    """split ONE packed fp32 operand [K][ld] into its bf16 planes now (single-op callers / tests; the engines batch all their
+    operands into one tpgsr_split_bf_program launch per step)"""
+    lib = _lib.load()
+    Kd, N = wt.shape
+    kp = (Kd + 31) // 32 * 32
+    twin = torch.zeros(3 * N * kp, dtype=torch.bfloat16, device=wt.device)
+    d = (_lib.SplitDesc * 1)()
+    d[0].src, d[0].dst, d[0].K, d[0].N, d[0].ld, d[0].kp, d[0].blk0 = wt.data_ptr(), twin.data_ptr(), Kd, N, N, kp, 0
+    table = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(wt.device)
+    split_bf_program(table, 1, lib.tpgsr_split_bf_blocks(Kd, N))
+    register_bf_twin(wt, twin, kp)
+    return twin, kp
+
+
+def split_bf_program(descs_dev, ndesc, total_blocks):
+    _launch("tpgsr_split_bf_program", _p(descs_dev), ndesc, total_blocks)
