@@ -201,6 +201,8 @@ int tpgsr_split_bf_program(const tpgsr_split_desc* descs_dev, int ndesc, int tot
 /* diagnostic: out[lane*4 + j] = what ds_read_b64_tr_b16 hands lane `lane` as element j from a [16 rows][16] image of
  * consecutive integers, addressed like the weight-gradient fragment fetch (64 lanes, 256 ints) */
 int tpgsr_tr_probe(int* out, void* stream);
+/* diagnostic: d = (a b + ...) applied `reps` times with ONE v_mfma_f32_32x32x16_bf16: a [32][16] / b [16][32] bf16 bit patterns, c / d [32][32] f32 */
+int tpgsr_mfma_bf16_probe(const void* a, const void* b, const float* c, float* d, int reps, void* stream);
 /* diagnostic: `blocks` workgroups x 4 waves x 2*iters register-only v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) */
 int tpgsr_mfma_probe(float* out, int blocks, int iters, void* stream);
 int tpgsr_copy(const float* src, float* dst, long long n, void* stream);   /* async D2D copy (graph memcpy node) */
@@ -347,6 +349,25 @@ int tpgsr_softmax_prior_bwd(const float* p, const float* q, const float* dprior_
  * partial [nblk][2] = (sum|q-p|, sum q'(log q' - log p')) -> tpgsr_semantic_loss_finalize; bwd: dp = dloss*(-sign(q-p) - q'/p')/n */
 int tpgsr_semantic_loss_fwd(const float* p, const float* q, long long n, float* partial, int nblk, void* stream);
 int tpgsr_semantic_loss_bwd(const float* p, const float* q, const float* dloss, long long n, float* dp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / resampling glue of the standalone operator API and the _TL baseline backbones (csrc/glue.hip), NHWC:
+ * torch.cat / channel slicing (model/srresnet.py:213, model/srcnn.py:98-104, model/rdn.py:147,197, model/vdsr.py:31),
+ * F.interpolate nearest (model/srcnn.py:91, model/vdsr.py:205) and bilinear align_corners=True (model/srresnet.py:153),
+ * zero-dilation / sub-sampling (ConvTranspose2d model/srresnet.py:174-183 and the strided conv4_1 of
+ * model/crnn/modules/feature_extraction.py:232 expressed through the stride-1 MFMA conv), mean over H
+ * (nn.AdaptiveAvgPool2d((None, 1)), model/crnn/model.py:46,71).  Backward kernels are gathers (deterministic).
+ * ---------------------------------------------------------------------------------------------- */
+int tpgsr_copy_strided(const float* src, int src_ld, int src_coff, float* dst, int dst_ld, int dst_coff, long long M, int C,
+                       int accumulate, void* stream);
+int tpgsr_resize_nearest_fwd(const float* in, int N, int H, int W, int C, int s, float* out, void* stream);
+int tpgsr_resize_nearest_bwd(const float* dout, int N, int H, int W, int C, int s, float* din, void* stream);
+int tpgsr_resize_bilinear_fwd(const float* in, int N, int H, int W, int C, int OH, int OW, float* out, void* stream);
+int tpgsr_resize_bilinear_bwd(const float* dout, int N, int H, int W, int C, int OH, int OW, float* din, void* stream);
+int tpgsr_dilate2d(const float* in, int N, int H, int W, int C, int sh, int sw, float* out, void* stream);
+int tpgsr_subsample2d(const float* in, int N, int H, int W, int C, int sh, int sw, float* out, void* stream);
+int tpgsr_hreduce(const float* in, int N, int H, int W, int C, float scale, float* out, void* stream);
+int tpgsr_hbroadcast(const float* dout, int N, int H, int W, int C, float scale, float* din, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tail: out = tanh(bias + sum_kw P[h][w+kw-4][kw][co])  (model/tsrn.py:159,213), NCHW output

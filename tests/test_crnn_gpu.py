@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import tpgsr_oracle as O  # noqa: E402
 
 DEV = "cuda"
-NOISE = 1.0     # see tests/test_tsrn_gpu.py
+NOISE = 1.5     # see tests/test_tsrn_gpu.py
 
 
 def _build(seed=103):

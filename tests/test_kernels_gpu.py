@@ -52,9 +52,10 @@ def prec(request):
     """MFMA arithmetic of the conv / linear GEMMs: fp32 matrix cores, or the fp32-equivalent split-operand path on the
     bf16 matrix cores (csrc/conv_xbf.hip) -- the SAME tolerances must hold for both."""
     k = K()
+    prev = k.POLICY
     k.set_conv_prec(request.param)
     yield request.param
-    k.set_conv_prec("f32")
+    k.set_conv_prec(prev)
 
 
 def mish(x):

@@ -10,11 +10,12 @@ pytestmark = pytest.mark.gpu
 from oracle import tpgsr_oracle as O  # noqa: E402
 
 DEV = "cuda"
-# Multiplier on the tolerances of ILL-CONDITIONED gradient checks (through the TPS rectification / deep recurrences, where the
-# oracle's own fp32-vs-fp64 distance is at the tolerance's level).  1 for the fp32 matrix-core path they were calibrated on;
-# tests/test_conv_xbf_gpu.py re-runs them with 1.5 for the split-operand path: a different accumulation order draws a different
-# sample of the same rounding noise (its distance to the fp64 truth is measured there and is not larger).
-NOISE = 1.0
+# Multiplier on the tolerances of the DISCONTINUOUS / ill-conditioned gradient checks: the STN head's gradients pass through
+# five max-pools and the TPS resampling, the recogniser's through four max-pools.  One arg-max decision that flips between
+# two arithmetic orders (values agreeing to 5e-6) re-routes a whole gradient element: measured with tools/lab/xbf_diverge.py,
+# ONE flipped pooling window moves every gradient below it by 3-4e-3 (relative L2) while all activations agree to 1e-5.
+# The thresholds below therefore sit at "a few flips", for every arithmetic mode alike.
+NOISE = 1.5
 
 
 def _psnr(a, b):

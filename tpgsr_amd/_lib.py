@@ -140,9 +140,19 @@ _SIGS = {
     "tpgsr_pad_channels": (ci, [vp, ll, ci, ci, vp, vp]),
     "tpgsr_semantic_loss_fwd": (ci, [vp, vp, ll, vp, ci, vp]),
     "tpgsr_semantic_loss_bwd": (ci, [vp, vp, vp, ll, vp, vp]),
+    "tpgsr_copy_strided": (ci, [vp, ci, ci, vp, ci, ci, ll, ci, ci, vp]),
+    "tpgsr_resize_nearest_fwd": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_resize_nearest_bwd": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_resize_bilinear_fwd": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_resize_bilinear_bwd": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_dilate2d": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_subsample2d": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_hreduce": (ci, [vp, ci, ci, ci, ci, cf, vp, vp]),
+    "tpgsr_hbroadcast": (ci, [vp, ci, ci, ci, ci, cf, vp, vp]),
     "tpgsr_split_bf_blocks": (ci, [ci, ci]),
     "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_tr_probe": (ci, [vp, vp]),
+    "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["tpgsr_last_error"])

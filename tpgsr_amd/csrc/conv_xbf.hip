@@ -487,3 +487,27 @@ extern "C" int tpgsr_tr_probe(int* out, void* stream) {
   hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
   TPGSR_LAUNCH_CHECK("tpgsr_tr_probe");
 }
+
+
+// diagnostic: ONE v_mfma_f32_32x32x16_bf16 on host-given operands: a [32][16] bf16 bits (row i, k), b [16][32] (k, col j), c / d [32][32] f32
+__global__ void mfma_bf16_probe_kernel(const unsigned short* a, const unsigned short* b, const float* c, float* d, int reps) {
+  const int l = threadIdx.x;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 av, bv;
+  for (int j = 0; j < 8; ++j) {
+    const int k = (l >> 5) * 8 + j;
+    av[j] = (short)a[(l & 31) * 16 + k];
+    bv[j] = (short)b[k * 32 + (l & 31)];
+  }
+  floatx16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = c[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)];
+  for (int it = 0; it < reps; ++it)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+}
+
+extern "C" int tpgsr_mfma_bf16_probe(const void* a, const void* b, const float* c, float* d, int reps, void* stream) {
+  TPGSR_CHECK_ARG(a && b && c && d && reps > 0, "tpgsr_mfma_bf16_probe: bad arguments");
+  hipLaunchKernelGGL(mfma_bf16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned short*)a, (const unsigned short*)b, c, d, reps);
+  TPGSR_LAUNCH_CHECK("tpgsr_mfma_bf16_probe");
+}

@@ -76,6 +76,8 @@ const std::unordered_map<std::string, Entry>& registry() {
       TPGSR_REG(tpgsr_adam_step), TPGSR_REG(tpgsr_step_inc), TPGSR_REG(tpgsr_scale_),
       TPGSR_REG(tpgsr_im2col3x3_c1), TPGSR_REG(tpgsr_col2im3x3_c1), TPGSR_REG(tpgsr_pad_channels),
       TPGSR_REG(tpgsr_semantic_loss_fwd), TPGSR_REG(tpgsr_semantic_loss_bwd), TPGSR_REG(tpgsr_split_bf_program),
+      TPGSR_REG(tpgsr_copy_strided), TPGSR_REG(tpgsr_resize_nearest_fwd), TPGSR_REG(tpgsr_resize_nearest_bwd), TPGSR_REG(tpgsr_resize_bilinear_fwd),
+      TPGSR_REG(tpgsr_resize_bilinear_bwd), TPGSR_REG(tpgsr_dilate2d), TPGSR_REG(tpgsr_subsample2d), TPGSR_REG(tpgsr_hreduce), TPGSR_REG(tpgsr_hbroadcast),
   };
   return r;
 }
