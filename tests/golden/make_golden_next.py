@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Fixtures for the SURVEY.md section 8(f) rows N3 / N4 -- the `--tpg OPT` text-prior generator and the `_TL` baseline
+backbones -- generated from the GENUINE reference imported from /root/reference (build container only; stubs for IPython,
+torchvision, cv2 which the reference imports but never uses on these paths).  Weights by recipe (`generic_recipe` below, also
+used by the tests: key order and shapes of the reference's state_dict == ours, which this script asserts), so only inputs and
+expected outputs are stored: forward in train and eval mode, input / prior gradients, per-parameter gradient norms + heads.
+
+    python tests/golden/make_golden_next.py          # rewrites tests/golden/next_*.npz + next_layouts.json"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+
+
+def generic_recipe(template_sd, seed):
+    """fill a state_dict (ordered like `template_sd`) from numpy's default_rng(seed): conv / linear weights N(0, 1/fan_in),
+    BN weight U(0.5, 1.5), biases / BN bias N(0, 0.1), running_mean N(0, 0.1), running_var U(0.5, 1.5), PReLU 0.25 +- 0.05"""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k, v in template_sd.items():
+        shape = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            t = np.zeros(shape, dtype=np.int64)
+        elif k.endswith("running_var"):
+            t = rng.uniform(0.5, 1.5, shape)
+        elif k.endswith("running_mean"):
+            t = rng.normal(0, 0.1, shape)
+        elif v.dim() >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            t = rng.normal(0, 1.0 / np.sqrt(fan_in), shape)
+        elif "bn" in k.lower() and k.endswith("weight") or (k.endswith("weight") and v.dim() == 1 and shape[0] > 1):
+            t = rng.uniform(0.5, 1.5, shape)
+        elif k.endswith("weight") and shape == (1,):
+            t = 0.25 + rng.normal(0, 0.05, shape)
+        else:
+            t = rng.normal(0, 0.1, shape)
+        out[k] = torch.tensor(np.asarray(t), dtype=v.dtype)
+    return out
+
+
+def grad_summary(mod):
+    names, norms, heads = [], [], []
+    for n, p in mod.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(n)
+        norms.append(float(g.double().norm()))
+        h = np.zeros(8, dtype=np.float32)
+        k = min(8, g.numel())
+        h[:k] = g.reshape(-1)[:k].numpy()
+        heads.append(h)
+    return np.array(names), np.array(norms), np.stack(heads)
+
+
+def main():
+    for name in ("IPython", "cv2"):
+        m = types.ModuleType(name)
+        m.embed = lambda *a, **k: None
+        sys.modules.setdefault(name, m)
+    tv = types.ModuleType("torchvision")
+    for sub in ("models", "transforms", "datasets"):
+        m = types.ModuleType("torchvision." + sub)
+        setattr(tv, sub, m)
+        sys.modules["torchvision." + sub] = m
+    sys.modules.setdefault("torchvision", tv)
+    sys.path.insert(0, "/root/reference")
+    import warnings
+    warnings.filterwarnings("ignore")
+    from model import rdn as r_rdn, srcnn as r_srcnn, srresnet as r_srresnet, vdsr as r_vdsr
+    from model.crnn import model as r_opt
+    from tpgsr_amd.model import rdn, srcnn, srresnet, vdsr
+    from tpgsr_amd.model.crnn import model as opt
+
+    class Opt(dict):
+        __getattr__ = dict.get
+
+    optcfg = Opt(Transformation="None", FeatureExtraction="ResNet", SequenceModeling="None", Prediction="CTC", num_fiducial=20,
+                 input_channel=1, output_channel=512, hidden_size=256, num_class=37)
+    torch.manual_seed(0)
+    cases = {
+        "srresnet_tl": (r_srresnet.SRResNet_TL(scale_factor=2, width=128, height=32, STN=False, mask=True),
+                        srresnet.SRResNet_TL(scale_factor=2, width=128, height=32, STN=False, mask=True)),
+        "srcnn_tl": (r_srcnn.SRCNN_TL(scale_factor=2, width=128, height=32, STN=False),
+                     srcnn.SRCNN_TL(scale_factor=2, width=128, height=32, STN=False)),
+        "vdsr_tl": (r_vdsr.VDSR_TL(scale_factor=2, width=128, height=32, STN=False),
+                    vdsr.VDSR_TL(scale_factor=2, width=128, height=32, STN=False)),
+        "rdn_tl": (r_rdn.RDN_TL(scale_factor=2), rdn.RDN_TL(scale_factor=2)),
+        "opt": (r_opt.Model(optcfg), opt.Model(optcfg)),
+    }
+    layouts = {}
+    g = torch.Generator().manual_seed(77)
+    lr = torch.rand(2, 4, 16, 64, generator=g)
+    prior = torch.softmax(torch.randn(2, 37, 1, 26, generator=g) * 2, 1)
+    gray = torch.rand(2, 1, 32, 100, generator=g)
+    for i, (name, (ref, ours)) in enumerate(cases.items()):
+        lay_ref = [(k, list(v.shape)) for k, v in ref.state_dict().items()]
+        lay_our = [(k, list(v.shape)) for k, v in ours.state_dict().items()]
+        assert lay_ref == lay_our, (name, [a for a, b in zip(lay_ref, lay_our) if a != b][:5], len(lay_ref), len(lay_our))
+        layouts[name] = lay_ref
+        sd = generic_recipe(ref.state_dict(), 100 + i)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        if name == "opt":
+            x = gray.clone().requires_grad_(True)
+            y = ref(x)
+            ins = {"x": gray.numpy()}
+        else:
+            x = lr.clone().requires_grad_(True)
+            t = prior.clone().requires_grad_(True)
+            y = ref(x, t)
+            ins = {"x": lr.numpy(), "prior": prior.numpy()}
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+        (y * gy).sum().backward()
+        names, norms, heads = grad_summary(ref)
+        out = dict(ins, y=y.detach().numpy(), gy=gy.numpy(), dx=x.grad.numpy(), grad_names=names, grad_norms=norms, grad_heads=heads)
+        if name != "opt":
+            out["dprior"] = t.grad.numpy()
+        running = torch.cat([v.reshape(-1).float() for k, v in ref.state_dict().items() if "running_" in k]) if any(
+            "running_" in k for k in ref.state_dict()) else torch.zeros(1)
+        out["running_cat"] = running.numpy()
+        ref.load_state_dict(sd, strict=True)
+        ref.eval()
+        with torch.no_grad():
+            ye = ref(gray) if name == "opt" else ref(lr, prior)
+        out["y_eval"] = ye.numpy()
+        np.savez_compressed(os.path.join(HERE, f"next_{name}.npz"), **out)
+        print(f"{name}: y {tuple(y.shape)}, {len(names)} parameters, |y| max {float(y.abs().max()):.3f}")
+    json.dump(layouts, open(os.path.join(HERE, "next_layouts.json"), "w"), indent=0)
+    print("fixtures written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""GPU: SURVEY.md section 8(f) rows N3 (`--tpg OPT`: None-ResNet-None-CTC text-prior generator) and N4 (the `_TL` baseline
+backbones SRResNet_TL / SRCNN_TL / VDSR_TL / RDN_TL), operator by operator on the HIP kernels, against fixtures generated from
+the imported reference (tests/golden/make_golden_next.py): train-mode forward, input and text-prior gradients, every parameter
+gradient (norm + leading entries), BatchNorm running statistics, eval-mode forward, state_dict layout."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_golden_next import generic_recipe  # noqa: E402  (the weight recipe only; the reference is not imported here)
+
+
+def _build(name):
+    from tpgsr_amd.model import rdn, srcnn, srresnet, vdsr
+    from tpgsr_amd.model.crnn import model as opt
+    if name == "srresnet_tl":
+        return srresnet.SRResNet_TL(scale_factor=2, width=128, height=32, STN=False, mask=True)
+    if name == "srcnn_tl":
+        return srcnn.SRCNN_TL(scale_factor=2, width=128, height=32, STN=False)
+    if name == "vdsr_tl":
+        return vdsr.VDSR_TL(scale_factor=2, width=128, height=32, STN=False)
+    if name == "rdn_tl":
+        return rdn.RDN_TL(scale_factor=2)
+    return opt.Model(dict(Transformation="None", FeatureExtraction="ResNet", SequenceModeling="None", Prediction="CTC", num_fiducial=20,
+                          input_channel=1, output_channel=512, hidden_size=256, num_class=37))
+
+
+@pytest.mark.parametrize("idx,name", list(enumerate(["srresnet_tl", "srcnn_tl", "vdsr_tl", "rdn_tl", "opt"])))
+def test_next_model_vs_reference_fixture(idx, name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"next_{name}.npz"))
+    lay = json.load(open(os.path.join(golden_dir, "next_layouts.json")))[name]
+    net = _build(name)
+    assert [(k, list(v.shape)) for k, v in net.state_dict().items()] == [(a, b) for a, b in lay]
+    sd = generic_recipe(net.state_dict(), 100 + idx)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    x = torch.tensor(g["x"]).to(DEV).requires_grad_(True)
+    if name == "opt":
+        y = net(x)
+    else:
+        t = torch.tensor(g["prior"]).to(DEV).requires_grad_(True)
+        y = net(x, t)
+    yref = torch.tensor(g["y"])
+    scale = max(1.0, float(yref.abs().max()))
+    err = (y.detach().cpu() - yref).abs().max().item()
+    (y * torch.tensor(g["gy"]).to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    print(f"{name}: train fwd max err {err:.2e} (|y| max {scale:.2f})")
+    assert y.shape == yref.shape and err < 1e-4 * scale
+    dx = torch.tensor(g["dx"])
+    e = (x.grad.cpu() - dx).norm().item() / max(dx.norm().item(), 1e-12)
+    print(f"   dx rel err {e:.2e}")
+    assert e < 5e-3
+    if name != "opt":
+        dp = torch.tensor(g["dprior"])
+        e = (t.grad.cpu() - dp).norm().item() / max(dp.norm().item(), 1e-12)
+        print(f"   dprior rel err {e:.2e}")
+        assert e < 5e-3
+    P = dict(net.named_parameters())
+    gmax = g["grad_norms"].max()
+    worst = 0.0
+    for n, ref_norm, head in zip([str(n) for n in g["grad_names"]], g["grad_norms"], g["grad_heads"]):
+        got = P[n].grad.detach().cpu()
+        en = abs(got.double().norm().item() - ref_norm) / max(ref_norm, 1e-3 * gmax)
+        k = min(8, got.numel())
+        sc = max(ref_norm / np.sqrt(got.numel()), 1e-3 * gmax / np.sqrt(got.numel()))
+        eh = (got.reshape(-1)[:k] - torch.tensor(head[:k])).abs().max().item() / sc
+        worst = max(worst, en)
+        assert en < 5e-3 and eh < 0.1, (name, n, en, eh)
+    print(f"   worst parameter-gradient norm rel err {worst:.2e}")
+    if len(g["running_cat"]) > 1:
+        cat = torch.cat([v.detach().cpu().reshape(-1).float() for k, v in net.state_dict().items() if "running_" in k])
+        assert (cat - torch.tensor(g["running_cat"])).abs().max() < 2e-4
+    net2 = _build(name)
+    net2.load_state_dict(sd, strict=True)
+    net2 = net2.to(DEV).eval()
+    with torch.no_grad():
+        ye = net2(torch.tensor(g["x"]).to(DEV)) if name == "opt" else net2(torch.tensor(g["x"]).to(DEV), torch.tensor(g["prior"]).to(DEV))
+    e = (ye.cpu() - torch.tensor(g["y_eval"])).abs().max().item()
+    print(f"   eval fwd max err {e:.2e}")
+    assert e < 1e-4 * max(1.0, float(np.abs(g["y_eval"]).max()))
+    if name == "opt":
+        assert (ye.cpu().argmax(-1) == torch.tensor(g["y_eval"]).argmax(-1)).all()      # identical arg-max text prior

@@ -89,3 +89,71 @@ def test_record_all_plans_without_gpu():
     assert res["c3"][2].get("tpgsr_pad_channels", 0) >= 2          # prior 37 -> 40, dlogits 37 -> 40
     assert res["pool"][0] >= res["pool"][1] and res["views"] and res["sr_first"]
     assert res["live_after_bwd"] == 0
+
+
+FSCRIPT = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+from tpgsr_amd import kernels as K
+assert K.DRYRUN
+from tpgsr_amd.model import tsrn
+from tpgsr_amd.model.stn_head import STNHead
+from tpgsr_amd.model.tps_spatial_transformer import TPSSpatialTransformer
+x = torch.randn(2, 64, 8, 24, requires_grad=True)
+t = torch.rand(2, 32, 8, 24, requires_grad=True)
+for m, inp in ((tsrn.GruBlock(64, 64), (x,)), (tsrn.RecurrentResidualBlock(64), (x,)), (tsrn.RecurrentResidualBlockTL(64, 32), (x, t)),
+               (tsrn.UpsampleBLock(64, 2), (x,)), (tsrn.InfoGen(37, 32), (torch.rand(2, 37, 1, 26, requires_grad=True),)), (tsrn.mish(), (x,))):
+    y = m.train()(*inp)
+    y.sum().backward()
+    print(type(m).__name__, tuple(y.shape))
+lr = torch.rand(3, 4, 16, 64, requires_grad=True)
+head, tps = STNHead(4, 20, "none", input_size=[16, 64]).train(), TPSSpatialTransformer((16, 64), 20, (0.05, 0.05))
+feat, ctrl = head(lr)
+y, src = tps(lr, ctrl)
+y.sum().backward()
+print("STN", tuple(feat.shape), tuple(ctrl.shape), tuple(y.shape), tuple(src.shape))
+print("RESULT ok")
+'''
+
+
+@pytest.mark.timeout(600)
+def test_standalone_blocks_record_without_gpu():
+    """every standalone block forward + backward issues well-formed C-ABI calls (argument lists checked, nothing computed)"""
+    env = dict(os.environ, TPGSR_PLAN_DRYRUN="1")
+    r = subprocess.run([sys.executable, "-c", FSCRIPT % dict(root=ROOT)], capture_output=True, text=True, env=env, timeout=550)
+    assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "UpsampleBLock (2, 64, 16, 48)" in r.stdout and "InfoGen (2, 32, 1, 203)" in r.stdout
+    assert "STN (3, 512) (3, 20, 2) (3, 4, 16, 64) (3, 1024, 2)" in r.stdout
+
+
+NSCRIPT = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from tpgsr_amd import kernels as K
+assert K.DRYRUN
+import test_next_models_gpu as T
+lr = torch.rand(2, 4, 16, 64, requires_grad=True)
+prior = torch.rand(2, 37, 1, 26, requires_grad=True)
+for name in ("srresnet_tl", "srcnn_tl", "vdsr_tl", "rdn_tl"):
+    net = T._build(name).train()
+    y = net(lr, prior)
+    y.sum().backward()
+    assert tuple(y.shape) == (2, 4, 32, 128), (name, y.shape)
+    net.eval()
+    with torch.no_grad():
+        assert tuple(net(lr, prior).shape) == (2, 4, 32, 128)
+net = T._build("opt").train()
+y = net(torch.rand(2, 1, 32, 100, requires_grad=True))
+y.sum().backward()
+assert tuple(y.shape) == (26, 2, 37), y.shape
+print("RESULT ok")
+'''
+
+
+@pytest.mark.timeout(600)
+def test_next_models_record_without_gpu():
+    """the N3 / N4 networks issue well-formed C-ABI calls end to end (forward + backward), shapes as the reference's"""
+    env = dict(os.environ, TPGSR_PLAN_DRYRUN="1")
+    r = subprocess.run([sys.executable, "-c", NSCRIPT % dict(root=ROOT)], capture_output=True, text=True, env=env, timeout=550)
+    assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

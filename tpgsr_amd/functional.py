@@ -195,11 +195,7 @@ class _Subsample(torch.autograd.Function):
         if d.shape[1] == H and d.shape[2] == W:
             return d, None, None
         full = torch.zeros(N, H, W, C, dtype=F32, device=g.device)      # rows / columns past the last sample get no gradient
-        for h in range(d.shape[1]):
-            K.copy_strided(d[:, h], d.shape[2] * C, 0, full[:, h], W * C, 0, N, d.shape[2] * C) if False else None
-        # general case through one strided copy per image row block: (N*dH) rows of dW*C floats into rows of W*C floats
-        K.copy_strided(d, d.shape[2] * C, 0, full.view(N, H, W * C)[:, :d.shape[1]].reshape(-1, W * C) if d.shape[1] == H else full, W * C, 0,
-                       N * d.shape[1], d.shape[2] * C) if d.shape[1] == H else _rows_copy(d, full)
+        _rows_copy(d, full)
         return full, None, None
 
 

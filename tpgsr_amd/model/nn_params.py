@@ -2,8 +2,10 @@
 
 The reference builds its networks from nn.Conv2d / nn.BatchNorm2d / nn.GRU / nn.Linear / nn.PReLU instances; their
 only durable contract is the state_dict (names, shapes) and the default initialisation.  These holders register the
-same tensors under the same names with the same init, but deliberately have no forward(): compute goes through the
-HIP kernels (tpgsr_amd/engine.py), and nothing can silently fall back to a stock PyTorch kernel."""
+same tensors under the same names with the same init.  Inside the fused networks (TSRN / TSRN_TL / CRNN) they are executed by
+the recorded plans of tpgsr_amd/engine*.py; called directly they run the same HIP kernels one operator at a time through
+tpgsr_amd/functional.py -- on NHWC activations (N, H, W, C): block / network modules convert at their NCHW boundary.
+Nothing can silently fall back to a stock PyTorch kernel."""
 import math
 
 import torch
@@ -37,6 +39,11 @@ class Conv2dParams(_NoForward):
         else:
             self.register_parameter("bias", None)
 
+    def forward(self, x, out_ps=False, wscale=1.0):
+        """x NHWC -> NHWC (out_ps: store nn.PixelShuffle(2)'s layout directly)"""
+        from .. import functional as Fh
+        return Fh.conv2d(x, self.weight, self.bias, self.padding, out_ps=out_ps, wscale=wscale)
+
 
 class ConvTranspose2dParams(_NoForward):
     """nn.ConvTranspose2d(in, out, k, stride, padding, bias=False) parameters ([in][out][kh][kw])."""
@@ -51,6 +58,10 @@ class ConvTranspose2dParams(_NoForward):
         self.weight = nn.Parameter(torch.empty(in_channels, out_channels, k, k))
         _uniform(self.weight, 1.0 / math.sqrt(out_channels * k * k))
 
+    def forward(self, x):
+        from .. import functional as Fh
+        return Fh.conv_transpose2d(x, self.weight, self.stride, self.padding)
+
 
 class LinearParams(_NoForward):
     def __init__(self, in_features, out_features):
@@ -59,6 +70,10 @@ class LinearParams(_NoForward):
         bound = 1.0 / math.sqrt(in_features)
         self.weight = nn.Parameter(_uniform(torch.empty(out_features, in_features), bound))
         self.bias = nn.Parameter(_uniform(torch.empty(out_features), bound))
+
+    def forward(self, x, wscale=1.0):
+        from .. import functional as Fh
+        return Fh.linear(x, self.weight, self.bias, wscale=wscale)
 
 
 class BatchNormParams(_NoForward):
@@ -73,11 +88,20 @@ class BatchNormParams(_NoForward):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
+    def forward(self, x, act=None):
+        """x (..., C) channels-last; act ('relu' | 'mish' | None) is fused into the normalisation pass"""
+        from .. import functional as Fh
+        return Fh.batch_norm(x, self, self.training, act)
+
 
 class PReLUParams(_NoForward):
     def __init__(self, init=0.25):
         super().__init__()
         self.weight = nn.Parameter(torch.full((1,), float(init)))
+
+    def forward(self, x):
+        from .. import functional as Fh
+        return Fh.prelu(x, self.weight)
 
 
 class _RNNParams(_NoForward):
@@ -101,6 +125,11 @@ class _RNNParams(_NoForward):
 
 class GRUParams(_RNNParams):
     GATES = 3
+
+    def forward(self, x, axis=0):
+        """bidirectional GRU along W (axis 0) or H (axis 1) of an NHWC map"""
+        from .. import functional as Fh
+        return Fh.bigru(x, self, axis)
 
 
 class LSTMParams(_RNNParams):

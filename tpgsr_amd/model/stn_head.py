@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import functional as Fh
 from .nn_params import BatchNormParams, Conv2dParams, LinearParams, _NoForward
 
 
@@ -61,5 +62,24 @@ class STNHead(nn.Module):
             fc2.weight.zero_()
             fc2.bias.copy_(torch.tensor(pts.astype(np.float32)).view(-1))
 
+    POOLS = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), None]     # MaxPool2d after stages 0-4 (reference :34-45)
+
     def forward(self, x):
-        raise RuntimeError("STNHead is executed inside the fused TSRN plan; it has no standalone forward in tpgsr_amd")
+        """(N, in_planes, 16, 64) -> (img_feat (N, 512), ctrl points (N, num_ctrlpoints, 2)) (reference :92-106).  Inside a
+        TSRN the same computation is part of the fused plan; this standalone form runs it operator by operator."""
+        h = Fh.to_nhwc(x)
+        for i, pool in enumerate(self.POOLS):
+            block = self.stn_convnet[2 * i]
+            h = block[1](block[0](h), act="relu")
+            if pool is not None:
+                h = Fh.max_pool2d(h, pool, pool)
+        N, fh, fw, C = h.shape
+        fc1, bn1 = self.stn_fc1[0], self.stn_fc1[1]
+        if fh * fw * C != fc1.in_features:
+            raise ValueError(f"STNHead: the conv stack left a {fh}x{fw}x{C} map, stn_fc1 expects {fc1.in_features} features")
+        # fc1 sees the NCHW flatten (c*fh*fw + y*fw + x) == a valid fh x fw conv over the NHWC map
+        f = Fh.conv2d(h, fc1.weight.view(fc1.out_features, C, fh, fw), fc1.bias, 0)
+        img_feat = bn1(f, act="relu")                                   # (N, 1, 1, 512)
+        ctrl = Fh.conv2d(img_feat, self.stn_fc2.weight.view(self.stn_fc2.out_features, -1, 1, 1), self.stn_fc2.bias, 0,
+                         wscale=0.1)                                     # fc2(0.1 * img_feat)
+        return img_feat.reshape(N, -1), ctrl.reshape(N, self.num_ctrlpoints, 2)

@@ -50,6 +50,15 @@ class TPSSpatialTransformer(nn.Module):
         self.register_buffer("target_coordinate_repr", rep.contiguous())
         self.register_buffer("target_control_points", tcp.contiguous())
 
-    def forward(self, input, source_control_points):
-        raise RuntimeError("TPSSpatialTransformer is executed inside the fused TSRN plan (tpgsr_tps_grid_fwd + "
-                           "tpgsr_grid_sample_fwd); it has no standalone forward in tpgsr_amd")
+    def forward(self, input, source_control_points, align_corners=False):
+        """(N, C, H, W), (N, num_control_points, 2) -> (rectified (N, C, th, tw), source coordinates (N, th*tw, 2))
+        (reference :97-112; F.grid_sample's align_corners default of torch >= 1.3).  Inside a TSRN this is part of the fused
+        plan; standalone it is the same two kernels (TPS grid with fp64 accumulation, bilinear sampler) with their adjoints."""
+        from .. import functional as Fh
+        if source_control_points.dim() != 3 or source_control_points.shape[1] != self.num_control_points or \
+                source_control_points.shape[2] != 2:
+            raise ValueError(f"expected control points (N, {self.num_control_points}, 2), got {tuple(source_control_points.shape)}")
+        th, tw = self.output_image_size
+        grid, src = Fh.tps_grid(source_control_points, self.inverse_kernel, self.target_coordinate_repr, th * tw)
+        out = Fh.grid_sample(Fh.to_nhwc(input), grid, (th, tw), align_corners)
+        return Fh.to_nchw(out), src

@@ -16,20 +16,26 @@ import math
 import torch
 from torch import nn
 
+from .. import functional as Fh
 from .nn_params import BatchNormParams, Conv2dParams, ConvTranspose2dParams, GRUParams, PReLUParams, _NoForward
 from .stn_head import STNHead
 from .tps_spatial_transformer import TPSSpatialTransformer
 
 
-class mish(_NoForward):
-    """x * tanh(softplus(x)) (reference :480-488); stateless, applied inside the consumer conv's tile loader."""
+# The block classes below are executed by the fused plan when they sit inside a TSRN / TSRN_TL; called on their own they run the
+# same HIP kernels operator by operator (tpgsr_amd/functional.py), NCHW in / NCHW out like the reference's modules.
+class mish(nn.Module):
+    """x * tanh(softplus(x)) (reference :480-488)"""
 
     def __init__(self):
         super().__init__()
         self.activated = True
 
+    def forward(self, x):
+        return Fh.mish(x)
 
-class GruBlock(_NoForward):
+
+class GruBlock(nn.Module):
     """1x1 conv + bidirectional GRU over the last spatial axis (reference :491-508)."""
 
     def __init__(self, in_channels, out_channels):
@@ -38,8 +44,15 @@ class GruBlock(_NoForward):
         self.conv1 = Conv2dParams(in_channels, out_channels, 1, padding=0)
         self.gru = GRUParams(out_channels, out_channels // 2, bidirectional=True)
 
+    def nhwc(self, x, axis=0):
+        """NHWC in / out; axis 1 = the reference's `.transpose(-1, -2)` around the block, without the copies"""
+        return self.gru(self.conv1(x), axis)
 
-class RecurrentResidualBlock(_NoForward):
+    def forward(self, x):
+        return Fh.to_nchw(self.nhwc(Fh.to_nhwc(x), 0))
+
+
+class RecurrentResidualBlock(nn.Module):
     """conv-bn-mish-conv-bn, vertical BiGRU, then horizontal BiGRU of (x + residual) (reference :373-394)."""
 
     def __init__(self, channels):
@@ -52,8 +65,15 @@ class RecurrentResidualBlock(_NoForward):
         self.bn2 = BatchNormParams(channels)
         self.gru2 = GruBlock(channels, channels)
 
+    def forward(self, x):
+        xh = Fh.to_nhwc(x)
+        r = self.bn1(self.conv1(xh), act="mish")
+        r = self.bn2(self.conv2(r))
+        r = self.gru1.nhwc(r, 1)
+        return Fh.to_nchw(self.gru2.nhwc(Fh.add(xh, r), 0))
 
-class RecurrentResidualBlockTL(_NoForward):
+
+class RecurrentResidualBlockTL(nn.Module):
     """as above with the text-prior strip concatenated in front of gru1 (reference :397-426)."""
 
     def __init__(self, channels, text_channels):
@@ -66,18 +86,30 @@ class RecurrentResidualBlockTL(_NoForward):
         self.bn2 = BatchNormParams(channels)
         self.gru2 = GruBlock(channels, channels)
 
+    def forward(self, x, text_emb):
+        xh = Fh.to_nhwc(x)
+        r = self.bn1(self.conv1(xh), act="mish")
+        r = self.bn2(self.conv2(r))
+        r = self.gru1.nhwc(Fh.cat([r, Fh.to_nhwc(text_emb)]), 1)
+        return Fh.to_nchw(self.gru2.nhwc(Fh.add(xh, r), 0))
 
-class UpsampleBLock(_NoForward):
+
+class UpsampleBLock(nn.Module):
     """conv3x3 C->4C, PixelShuffle(2), mish (reference :464-477)."""
 
     def __init__(self, in_channels, up_scale):
         super().__init__()
+        if up_scale != 2:
+            raise NotImplementedError("the pixel-shuffle store of the conv kernel is specialised for up_scale 2 (the reference's)")
         self.conv = Conv2dParams(in_channels, in_channels * up_scale ** 2, 3, padding=1)
-        self.pixel_shuffle = _NoForward()
+        self.pixel_shuffle = _NoForward()          # fused into the conv's store
         self.prelu = mish()
 
+    def forward(self, x):
+        return Fh.to_nchw(Fh.mish(self.conv(Fh.to_nhwc(x), out_ps=True)))
 
-class InfoGen(_NoForward):
+
+class InfoGen(nn.Module):
     """text prior (N,37,1,26) -> (N,32,1,203) by four ConvTranspose2d+BN+ReLU (reference :81-108)."""
 
     def __init__(self, t_emb, output_size):
@@ -90,6 +122,14 @@ class InfoGen(_NoForward):
         self.bn3 = BatchNormParams(64)
         self.tconv4 = ConvTranspose2dParams(64, output_size, 3, (2, 1), padding=(1, 0))
         self.bn4 = BatchNormParams(output_size)
+
+    def forward(self, t_embedding):
+        x = Fh.to_nhwc(t_embedding)
+        x = self.bn1(self.tconv1(x), act="relu")
+        x = self.bn2(self.tconv2(x), act="relu")
+        x = self.bn3(self.tconv3(x), act="relu")
+        x = self.bn4(self.tconv4(x), act="relu")
+        return Fh.to_nchw(x)
 
 
 class _TSRNFunction(torch.autograd.Function):
