@@ -391,6 +391,17 @@ int tpgsr_image_loss_bwd(const float* out, const float* tgt, const float* dloss,
                          int gradient, float w0, float w1, float* dout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Evaluation path (interfaces/super_resolution.py:540-900): CTC greedy decoding of the recogniser's logits
+ * (utils/metrics.py:71-88 get_string_crnn; logits batch-major [N][T][C], labels [N][T] collapsed + blank-free, -1 padded),
+ * PSNR and SSIM of NCHW images over their first 3 channels (utils/ssim_psnr.py:9-15, :18-78; window = the reference's
+ * 11x11 Gaussian, passed in).  partial: nblk doubles of scratch.
+ * ---------------------------------------------------------------------------------------------- */
+int tpgsr_ctc_greedy_decode(const float* logits, int N, int T, int C, int* labels, int* lengths, void* stream);
+int tpgsr_psnr(const float* a, const float* b, int N, int Ctot, int H, int W, double* partial, int nblk, float* out, void* stream);
+int tpgsr_ssim(const float* a, const float* b, const float* window, int KS, int N, int Ctot, int H, int W, double* partial, int nblk,
+               float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser -- clip_grad_norm_(0.25) + Adam(lr 1e-3, betas (0.5,0.999)) over flat arenas
  * (interfaces/super_resolution.py:419-424, interfaces/base.py:449-450)
  * ---------------------------------------------------------------------------------------------- */

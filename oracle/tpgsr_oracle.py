@@ -666,3 +666,64 @@ def srcnn_train_step(p, opt: AdamState, lr_img: Tensor, hr_img: Tensor):
     gnorm = clip_grad_norm_(grads, 0.25)
     opt.step(grads)
     return {"loss": loss.detach(), "grad_norm": gnorm, "sr": sr.detach()}
+
+
+# ---------------------------------------------------------------------------
+# evaluation path (interfaces/super_resolution.py:540-900)
+# ---------------------------------------------------------------------------
+ALPHABET = "-0123456789abcdefghijklmnopqrstuvwxyz"
+
+
+def get_string_crnn(outputs_: Tensor, alphabet: str = ALPHABET) -> List[str]:
+    """utils/metrics.py:71-88: per sample arg-max over classes (first maximum), collapse repeats, drop the blank (index 0);
+    a blank between two equal characters keeps both.  outputs_ is seq-first (T, N, C)."""
+    idx = outputs_.permute(1, 0, 2).argmax(-1)       # torch.max / argmax return the first maximal index on CPU
+    res = []
+    for row in idx.tolist():
+        s, last = "", -1
+        for i in row:
+            if i != last:
+                if i != 0:
+                    s += alphabet[i]
+                    last = i
+                else:
+                    last = -1
+        res.append(s)
+    return res
+
+
+def ssim(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
+    """utils/ssim_psnr.py:18-78 (SSIM(window_size=11, size_average=True)): Gaussian window sigma 1.5, zero padding, first 3 channels"""
+    a, b = img1[:, :3], img2[:, :3]
+    ch = a.shape[1]
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(ch, 1, window_size, window_size).contiguous()
+    p = window_size // 2
+    mu1, mu2 = F.conv2d(a, w, padding=p, groups=ch), F.conv2d(b, w, padding=p, groups=ch)
+    s11 = F.conv2d(a * a, w, padding=p, groups=ch) - mu1 * mu1
+    s22 = F.conv2d(b * b, w, padding=p, groups=ch) - mu2 * mu2
+    s12 = F.conv2d(a * b, w, padding=p, groups=ch) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))).mean()
+
+
+@torch.no_grad()
+def tpgsr_eval_step(sr_params: List[dict], tpg_params: List[dict], recognizer: dict, lr_img: Tensor, hr_img: Tensor, *, stu_iter=1,
+                    sr_share=True, tpg_share=False, srb_nums=5):
+    """the cascade branch of TextSR.eval (interfaces/super_resolution.py:727-746 + :770-830): eval-mode networks (no STN, running
+    BN statistics), per stage prior = softmax(TPG(parse_crnn_data(cascade))) -> SR; PSNR / SSIM of the last SR vs HR; strings
+    of SR / LR / HR from the evaluation recogniser"""
+    cascade = lr_img
+    srs, priors = [], []
+    for i in range(stu_iter):
+        tpg = tpg_params[0 if tpg_share else i]
+        pv = F.softmax(crnn_forward(tpg, parse_crnn_data(cascade[:, :3]), training=False), -1)
+        prior = pv.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+        cascade = tsrn_forward(sr_params[0 if sr_share else i], lr_img, prior, training=False, stn=True, srb_nums=srb_nums,
+                               text_prior=True)
+        srs.append(cascade)
+        priors.append(pv)
+    rec = lambda img: get_string_crnn(crnn_forward(recognizer, parse_crnn_data(img[:, :3]), training=False))
+    return {"sr": srs, "priors": priors, "psnr": calculate_psnr(cascade, hr_img), "ssim": ssim(cascade, hr_img),
+            "pred_sr": rec(cascade), "pred_lr": rec(lr_img), "pred_hr": rec(hr_img)}

@@ -132,6 +132,29 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"next_{name}.npz"), **out)
         print(f"{name}: y {tuple(y.shape)}, {len(names)} parameters, |y| max {float(y.abs().max()):.3f}")
     json.dump(layouts, open(os.path.join(HERE, "next_layouts.json"), "w"), indent=0)
+
+    # ---- N2: evaluation metrics of the reference (utils/metrics.py get_string_crnn, utils/ssim_psnr.py calculate_psnr / SSIM)
+    ed = types.ModuleType("editdistance")
+    ed.eval = lambda a, b: 0
+    sys.modules.setdefault("editdistance", ed)
+    from utils import metrics as r_metrics, ssim_psnr as r_sp, util as r_util
+    ge = torch.Generator().manual_seed(9)
+    logits = torch.randn(26, 24, 37, generator=ge) * 2
+    logits[:, :, 0] += 2.5                                   # plenty of blanks
+    logits[3:9, 0] = logits[3:4, 0]                          # a run of repeats
+    logits[:, 1, 0] += 100                                   # an all-blank row -> ""
+    logits[:, 2] = 0                                         # all-equal row: first maximum = blank -> ""
+    logits[5, 3, 7] = logits[5, 3].max() + 0.0               # an exact tie: torch.max keeps the first index
+    strings = r_metrics.get_string_crnn(logits)
+    a = torch.rand(5, 4, 32, 128, generator=ge)
+    b = (a + 0.1 * torch.randn(5, 4, 32, 128, generator=ge)).clamp(0, 1)
+    c3a, c3b = a[:, :3].contiguous(), b[:, :3].contiguous()
+    out = dict(logits=logits.numpy(), strings=np.array(strings), a=a.numpy(), b=b.numpy(), psnr=float(r_sp.calculate_psnr(a, b)),
+               ssim=float(r_sp.SSIM()(a, b)), psnr3=float(r_sp.calculate_psnr(c3a, c3b)), ssim_same=float(r_sp.SSIM()(a, a)),
+               filt_in=np.array(["Hello, World-42!", "ABC def", "x_y.z"]),
+               filt_lower=np.array([r_util.str_filt(t, "lower") for t in ["Hello, World-42!", "ABC def", "x_y.z"]]))
+    np.savez_compressed(os.path.join(HERE, "next_eval_metrics.npz"), **out)
+    print("eval metrics:", strings[:6], out["psnr"], out["ssim"])
     print("fixtures written")
 
 

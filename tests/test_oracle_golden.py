@@ -159,3 +159,13 @@ def test_explicit_rnn_equals_aten():
     sd = O.recipe_state_dict(O._lstm_spec("l", 24, 16), 8)
     x = torch.randn(7, 3, 24, generator=g)
     _close(O.lstm_bidir(x, sd, "l", True), O.lstm_bidir(x, sd, "l", False), 1e-6)
+
+
+def test_eval_metrics_oracle_vs_reference_fixture(golden_dir):
+    """oracle.get_string_crnn / ssim / calculate_psnr (restated from utils/metrics.py:71-88, utils/ssim_psnr.py) against the
+    reference's own outputs (tests/golden/make_golden_next.py)"""
+    g = np.load(os.path.join(golden_dir, "next_eval_metrics.npz"))
+    assert O.get_string_crnn(torch.tensor(g["logits"])) == [str(s) for s in g["strings"]]
+    a, b = torch.tensor(g["a"]), torch.tensor(g["b"])
+    assert abs(float(O.calculate_psnr(a, b)) - float(g["psnr"])) < 1e-5
+    assert abs(float(O.ssim(a, b)) - float(g["ssim"])) < 1e-6

@@ -149,6 +149,9 @@ _SIGS = {
     "tpgsr_subsample2d": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_hreduce": (ci, [vp, ci, ci, ci, ci, cf, vp, vp]),
     "tpgsr_hbroadcast": (ci, [vp, ci, ci, ci, ci, cf, vp, vp]),
+    "tpgsr_ctc_greedy_decode": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_psnr": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
+    "tpgsr_ssim": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp]),
     "tpgsr_split_bf_blocks": (ci, [ci, ci]),
     "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_tr_probe": (ci, [vp, vp]),

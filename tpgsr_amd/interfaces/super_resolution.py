@@ -330,3 +330,72 @@ class TPGSRTrainStep:
             self._exchange()
             self._graph_b.replay()
         return self._graph_loss
+
+
+class TextSREvaluator:
+    """The evaluation pass of interfaces/super_resolution.py:540-900 for the `tsrn_tl` / cascade architectures, on the HIP
+    kernels end to end: eval-mode networks (BatchNorm from running statistics, folded into the consumer convs' loaders; STN
+    skipped, model/tsrn.py:183), per stage: parse_crnn_data -> text-prior generator -> softmax -> (N, 37, 1, 26) prior ->
+    SR network; then PSNR / SSIM of the last SR image against HR (tpgsr_psnr / tpgsr_ssim) and recognition of LR / SR / HR by
+    an evaluation recogniser with on-device CTC greedy decoding + string comparison (utils/metrics.py, utils/util.py).
+    No dropout of the prior, no gradient state, no host round trip before the strings are built."""
+
+    def __init__(self, sr_models, tpg_models, recognizer=None, stu_iter=1, sr_share=True, tpg_share=False, voc_type="lower"):
+        self.sr = list(sr_models) if isinstance(sr_models, (list, tuple)) else [sr_models]
+        self.tpg = list(tpg_models) if isinstance(tpg_models, (list, tuple)) else [tpg_models]
+        self.recognizer = recognizer if recognizer is not None else self.tpg[0]
+        self.stu_iter, self.sr_share, self.tpg_share, self.voc_type = stu_iter, sr_share, tpg_share, voc_type
+        from ..utils.ssim_psnr import SSIM
+        self._ssim = SSIM()
+        self._buf = None
+
+    @torch.no_grad()
+    def super_resolve(self, images_lr):
+        """-> (list of the stu_iter SR images, list of their (N, 26, 37) text priors)"""
+        for m in self.sr + self.tpg:
+            if m.training:
+                raise RuntimeError("TextSREvaluator needs the networks in eval() mode")
+        lr = images_lr.contiguous().float()
+        N, C, H, W = lr.shape
+        dev = lr.device
+        cascade, ch, cw = lr, H, W
+        srs, priors = [], []
+        for i in range(self.stu_iter):
+            tpg = self.tpg[0 if self.tpg_share else i]
+            srm = self.sr[0 if self.sr_share else i]
+            gray = torch.empty(N, 1, 32, 100, device=dev)
+            K.bicubic_gray_fwd(cascade, N, cascade.shape[1], ch, cw, 32, 100, gray)
+            logits = tpg._engine().forward(gray, False)                       # [N][T][C]
+            p = torch.empty(N, 26, 37, device=dev)
+            prior = torch.empty(N, 37, 1, 26, device=dev)
+            K.softmax_prior_fwd(logits, None, N, 26, 37, 0, p, prior, None, _NBLK)
+            sr = srm._engine().forward(lr, False, prior)
+            srs.append(sr)
+            priors.append(p)
+            cascade, ch, cw = sr, 2 * H, 2 * W
+        return srs, priors
+
+    @torch.no_grad()
+    def recognize(self, images):
+        """evaluation recogniser + CTC greedy decoding -> list of strings"""
+        from ..utils.metrics import get_string_crnn
+        x = images.contiguous().float()
+        N, C, H, W = x.shape
+        gray = torch.empty(N, 1, 32, 100, device=x.device)
+        K.bicubic_gray_fwd(x, N, C, H, W, 32, 100, gray)
+        logits = self.recognizer._engine().forward(gray, False)
+        return get_string_crnn(logits.permute(1, 0, 2))
+
+    @torch.no_grad()
+    def eval_batch(self, images_lr, images_hr, label_strs=None):
+        from ..utils.metrics import str_filt
+        from ..utils.ssim_psnr import calculate_psnr
+        srs, priors = self.super_resolve(images_lr)
+        sr = srs[-1]
+        out = dict(images_sr=srs, priors=priors, psnr=calculate_psnr(sr, images_hr), ssim=self._ssim(sr, images_hr),
+                   pred_sr=self.recognize(sr), pred_lr=self.recognize(images_lr), pred_hr=self.recognize(images_hr))
+        if label_strs is not None:
+            tgt = [str_filt(s, self.voc_type) for s in label_strs]
+            for k in ("sr", "lr", "hr"):
+                out["n_correct_" + k] = sum(str_filt(a, self.voc_type) == b for a, b in zip(out["pred_" + k], tgt))
+        return out

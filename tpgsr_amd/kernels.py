@@ -347,7 +347,7 @@ def _launch(name, *args):
 def _p(t):
     if t is None or isinstance(t, (int, DynPtr)):
         return t
-    assert (t.is_cuda or DRYRUN) and t.dtype in (torch.float32, torch.int32, torch.uint8) and t.is_contiguous(), \
+    assert (t.is_cuda or DRYRUN) and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.float64) and t.is_contiguous(), \
         f"tpgsr kernels need contiguous fp32 CUDA tensors (got {t.dtype}, cuda={t.is_cuda}, contiguous={t.is_contiguous()})"
     if _REC is not None:
         _REC.keep.append(t)
@@ -792,3 +792,16 @@ def hreduce(inp, N, H, W, C_, scale, out):
 
 def hbroadcast(dout, N, H, W, C_, scale, din):
     _launch("tpgsr_hbroadcast", _p(dout), N, H, W, C_, scale, _p(din))
+
+
+# ---- evaluation path (csrc/metrics.hip) ---------------------------------------------------------------------------
+def ctc_greedy_decode(logits, N, T, C_, labels, lengths):
+    _launch("tpgsr_ctc_greedy_decode", _p(logits), N, T, C_, _p(labels), _p(lengths))
+
+
+def psnr(a, b, N, Ctot, H, W, partial, nblk, out):
+    _launch("tpgsr_psnr", _p(a), _p(b), N, Ctot, H, W, _p(partial), nblk, _p(out))
+
+
+def ssim(a, b, window, KS, N, Ctot, H, W, partial, nblk, out):
+    _launch("tpgsr_ssim", _p(a), _p(b), _p(window), KS, N, Ctot, H, W, _p(partial), nblk, _p(out))

@@ -1,0 +1,40 @@
+"""String metrics of the evaluation path (reference: utils/metrics.py:71-88 get_string_crnn, utils/util.py:12-24 str_filt).
+The arg-max + CTC collapse runs on the device (tpgsr_ctc_greedy_decode); only N short index lists cross PCIe to become
+Python strings."""
+import string
+
+import torch
+
+ALPHABET = "-0123456789abcdefghijklmnopqrstuvwxyz"
+
+
+def ctc_greedy(outputs_: torch.Tensor):
+    """outputs_ (T, N, C) logits or probabilities (the recogniser's seq-first output) -> (labels (N, T) int32 padded with -1,
+    lengths (N,) int32), both on the device"""
+    from .. import kernels as K
+    if not outputs_.is_cuda and not K.DRYRUN:
+        raise RuntimeError("tpgsr_amd.utils.metrics runs on the GPU only (no CPU fallback)")
+    T, N, C = outputs_.shape
+    x = outputs_.detach().permute(1, 0, 2)
+    x = x if x.is_contiguous() else x.contiguous()           # the drop-in CRNN returns a view of a batch-major buffer: no copy
+    labels = torch.empty(N, T, dtype=torch.int32, device=x.device)
+    lengths = torch.empty(N, dtype=torch.int32, device=x.device)
+    K.ctc_greedy_decode(x.float(), N, T, C, labels, lengths)
+    return labels, lengths
+
+
+def get_string_crnn(outputs_, alphabet=ALPHABET):
+    labels, lengths = ctc_greedy(outputs_)
+    lab, ln = labels.cpu().tolist(), lengths.cpu().tolist()
+    return ["".join(alphabet[i] for i in row[:n]) for row, n in zip(lab, ln)]
+
+
+def str_filt(str_, voc_type):
+    alpha_dict = {"digit": string.digits, "lower": string.digits + string.ascii_lowercase,
+                  "upper": string.digits + string.ascii_letters, "all": string.digits + string.ascii_letters + string.punctuation}
+    if voc_type == "lower":
+        str_ = str_.lower()
+    for char in str_:
+        if char not in alpha_dict[voc_type]:
+            str_ = str_.replace(char, "")
+    return str_
