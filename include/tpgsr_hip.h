@@ -32,7 +32,7 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
-/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc): a binding can verify its mirror */
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc, 6 image_desc): a binding can verify its mirror */
 int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -389,6 +389,25 @@ int tpgsr_image_loss_finalize(const float* partial, int nblk, long long n_mse, l
                               float* loss, void* stream);
 int tpgsr_image_loss_bwd(const float* out, const float* tgt, const float* dloss, int N, int C, int H, int W,
                          int gradient, float w0, float w1, float* dout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input pipeline (dataset/dataset.py:615-632 resizeNormalize, called by alignCollate_real* :1226-1323): Pillow's 8-bit
+ * bicubic `img.resize` + ToTensor + luminance-threshold mask for a batch of variable-size uint8 HWC images, bit-exact.
+ * tpgsr_resample_coeffs (HOST) fills Pillow's per-output-index bounds [out][2] and 22-bit fixed-point taps
+ * [out][tpgsr_resample_ksize]; the batch's tables are concatenated into one int32 device buffer, every image's descriptor
+ * holds the offsets (in ints).  pixels: the images' bytes back to back; tmp [N][maxH][OW][3], res8 [N][OH][OW][3] scratch;
+ * out [N][3 + mask][OH][OW] float.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tpgsr_image_desc {
+  long long offset;       /* byte offset of the image's [H][W][3] pixels */
+  int H, W;
+  int xb_off, xk_off, kx; /* horizontal pass: bounds table, tap table, taps per output column */
+  int yb_off, yk_off, ky; /* vertical pass */
+} tpgsr_image_desc;
+int tpgsr_resample_ksize(int in_size, int out_size);
+int tpgsr_resample_coeffs(int in_size, int out_size, int* bounds, int* kk);
+int tpgsr_resize_normalize(const unsigned char* pixels, const tpgsr_image_desc* descs_dev, const int* tables_dev, int N, int OH, int OW,
+                           int maxH, int mask, unsigned char* tmp, unsigned char* res8, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Evaluation path (interfaces/super_resolution.py:540-900): CTC greedy decoding of the recogniser's logits

@@ -155,6 +155,25 @@ def main():
                filt_lower=np.array([r_util.str_filt(t, "lower") for t in ["Hello, World-42!", "ABC def", "x_y.z"]]))
     np.savez_compressed(os.path.join(HERE, "next_eval_metrics.npz"), **out)
     print("eval metrics:", strings[:6], out["psnr"], out["ssim"])
+    # ---- N1: Pillow's own output for resizeNormalize (dataset/dataset.py:615-632) on a few random images ------------------------
+    from PIL import Image
+    import PIL
+    rng = np.random.default_rng(5)
+    imgs, outs = {}, {}
+    for j, (h, w) in enumerate([(16, 64), (32, 128), (37, 211), (9, 40), (13, 17), (60, 180)]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if j == 5:     # a smooth image (natural-like): gradients + noise
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.stack([(xx * 255 / w), (yy * 255 / h), ((xx + yy) * 255 / (w + h))], -1).astype(np.uint8) ^ (img & 7)
+        imgs[f"img{j}"] = img
+        for tag, size in (("hr", (128, 32)), ("lr", (64, 16))):
+            pil = Image.fromarray(img).resize(size, Image.BICUBIC)
+            L = np.array(pil.convert("L"))
+            mask = np.array(pil.convert("L").point(lambda x, t=L.mean(): 0 if x > t else 255))
+            outs[f"{tag}{j}"] = np.array(pil)
+            outs[f"{tag}{j}_mask"] = mask
+    np.savez_compressed(os.path.join(HERE, "next_resize.npz"), pillow=np.array(PIL.__version__), **imgs, **outs)
+    print("resize fixtures from Pillow", PIL.__version__)
     print("fixtures written")
 
 

@@ -58,6 +58,10 @@ class SplitDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("K", ci), ("N", ci), ("ld", ci), ("kp", ci), ("blk0", ci), ("reserved", ci)]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [("offset", ll), ("H", ci), ("W", ci), ("xb_off", ci), ("xk_off", ci), ("kx", ci), ("yb_off", ci), ("yk_off", ci), ("ky", ci)]
+
+
 class PlanArg(C.Union):
     """tpgsr_plan_arg: one launch argument of a native plan (pointer / integer / float)"""
     _fields_ = [("p", vp), ("i", ll), ("f", C.c_double)]
@@ -149,6 +153,9 @@ _SIGS = {
     "tpgsr_subsample2d": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_hreduce": (ci, [vp, ci, ci, ci, ci, cf, vp, vp]),
     "tpgsr_hbroadcast": (ci, [vp, ci, ci, ci, ci, cf, vp, vp]),
+    "tpgsr_resample_ksize": (ci, [ci, ci]),
+    "tpgsr_resample_coeffs": (ci, [ci, ci, vp, vp]),
+    "tpgsr_resize_normalize": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "tpgsr_ctc_greedy_decode": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "tpgsr_psnr": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
     "tpgsr_ssim": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp]),
@@ -183,7 +190,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

@@ -478,9 +478,9 @@ extern "C" int tpgsr_prelu_fwd(const float* x, const float* alpha, long long n, 
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                         const float* __restrict__ dy, const float* __restrict__ dy2,
                                                         long long n4, float* __restrict__ dx, float* __restrict__ dap) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   float a = alpha[0];
-  float acc = 0.f;
+  double acc = 0.0;      // d alpha = sum over the negative side of dy * x: a heavily cancelling sum, accumulated in fp64
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 v = ld4(x + i * 4);
     float4 g = ld4(dy + i * 4);
@@ -493,14 +493,14 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
     o.y = v.y > 0.f ? g.y : a * g.y;
     o.z = v.z > 0.f ? g.z : a * g.z;
     o.w = v.w > 0.f ? g.w : a * g.w;
-    acc += (v.x > 0.f ? 0.f : g.x * v.x) + (v.y > 0.f ? 0.f : g.y * v.y) + (v.z > 0.f ? 0.f : g.z * v.z) +
-           (v.w > 0.f ? 0.f : g.w * v.w);
+    acc += (double)((v.x > 0.f ? 0.f : g.x * v.x) + (v.y > 0.f ? 0.f : g.y * v.y)) +
+           (double)((v.z > 0.f ? 0.f : g.z * v.z) + (v.w > 0.f ? 0.f : g.w * v.w));
     *reinterpret_cast<float4*>(dx + i * 4) = o;
   }
-  acc = wave_sum(acc);
+  acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) dap[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) dap[blockIdx.x] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 extern "C" int tpgsr_prelu_bwd(const float* x, const float* alpha, const float* dy, const float* dy2, long long n, float* dx,

@@ -24,6 +24,7 @@ extern "C" int tpgsr_sizeof(int which) {
     case 3: return (int)sizeof(tpgsr_wgrad_reduce_desc);
     case 4: return (int)sizeof(tpgsr_compose_bwd_desc);
     case 5: return (int)sizeof(tpgsr_split_desc);
+    case 6: return (int)sizeof(tpgsr_image_desc);
     default: return -1;
   }
 }

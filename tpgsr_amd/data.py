@@ -1,0 +1,129 @@
+"""Input pipeline contract of the reference on the device.
+
+reference: dataset/dataset.py:615-632 `resizeNormalize(size, mask, interpolation=Image.BICUBIC)` -- Pillow bicubic
+`img.resize`, `ToTensor`, luminance-threshold mask channel -- applied per image by `alignCollate_real*`
+(dataset/dataset.py:1226-1323: HR -> (128, 32), LR -> (64, 16)) on ONE DataLoader worker; LMDB record keys
+dataset/dataset.py:104-149.  Here a whole batch of variable-size uint8 HWC images is resized + normalised + masked by three
+kernel launches (csrc/preprocess.hip), bit-exact against Pillow's 8-bit resampling; the host only concatenates the decoded
+pixels and Pillow's per-size coefficient tables (cached per (in, out) size pair).  JPEG/PNG decoding and LMDB I/O stay host
+work exactly as in the reference (`buf2PIL`)."""
+import ctypes as C
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, kernels as K
+
+NUM_SAMPLES_KEY = b"num-samples"
+
+
+def lmdb_keys(index: int) -> Dict[str, bytes]:
+    """record keys of sample `index` (0-based) in the reference's LMDB layout (1-based, 9 digits)"""
+    i = index + 1
+    return dict(label=b"label-%09d" % i, image_hr=b"image_hr-%09d" % i, image_lr=b"image_lr-%09d" % i)
+
+
+class ResizeNormalize:
+    """`resizeNormalize((w, h), mask)` for a batch: list of uint8 [H][W][3] arrays -> float tensor (N, 3 + mask, h, w) on `device`."""
+
+    def __init__(self, size: Tuple[int, int], mask: bool = False, device="cuda"):
+        self.size, self.mask, self.device = (int(size[0]), int(size[1])), bool(mask), torch.device(device)
+        self._tables: Dict[Tuple[int, int], Tuple[np.ndarray, np.ndarray, int]] = {}
+
+    def _coeffs(self, in_size, out_size):
+        key = (in_size, out_size)
+        t = self._tables.get(key)
+        if t is None:
+            lib = _lib.load()
+            ks = lib.tpgsr_resample_ksize(in_size, out_size)
+            b = np.zeros((out_size, 2), np.int32)
+            k = np.zeros((out_size, ks), np.int32)
+            _lib.check(lib.tpgsr_resample_coeffs(in_size, out_size, b.ctypes.data, k.ctypes.data), "tpgsr_resample_coeffs")
+            t = self._tables[key] = (b, k, ks)
+        return t
+
+    def __call__(self, images: Sequence[np.ndarray]) -> torch.Tensor:
+        if not K.DRYRUN and self.device.type != "cuda":
+            raise RuntimeError("tpgsr_amd.data.ResizeNormalize runs on the GPU only (the reference's PIL path is the CPU form)")
+        ow, oh = self.size
+        N = len(images)
+        descs = (_lib.ImageDesc * N)()
+        tabs: List[np.ndarray] = []
+        toff, poff, maxH = 0, 0, 1
+        tab_index: Dict[Tuple[int, int], Tuple[int, int, int]] = {}
+
+        def table(in_size, out_size):
+            nonlocal toff
+            key = (in_size, out_size)
+            if key not in tab_index:
+                b, k, ks = self._coeffs(in_size, out_size)
+                tab_index[key] = (toff, toff + b.size, ks)
+                tabs.extend([b.reshape(-1), k.reshape(-1)])
+                toff += b.size + k.size
+            return tab_index[key]
+
+        flat = []
+        for d, img in zip(descs, images):
+            a = np.ascontiguousarray(img)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError(f"expected uint8 [H][W][3] images, got {a.dtype} {a.shape}")
+            H, W = a.shape[:2]
+            d.offset, d.H, d.W = poff, H, W
+            d.xb_off, d.xk_off, d.kx = table(W, ow)
+            d.yb_off, d.yk_off, d.ky = table(H, oh)
+            flat.append(a.reshape(-1))
+            poff += a.size
+            maxH = max(maxH, H)
+        dev = self.device
+        pix = torch.from_numpy(np.concatenate(flat)).to(dev)
+        tab = torch.from_numpy(np.concatenate(tabs)).to(dev)
+        dsc = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        Cc = 4 if self.mask else 3
+        tmp = torch.empty(N * maxH * ow * 3, dtype=torch.uint8, device=dev)
+        res8 = torch.empty(N * oh * ow * 3, dtype=torch.uint8, device=dev)
+        out = torch.empty(N, Cc, oh, ow, dtype=torch.float32, device=dev)
+        K._launch("tpgsr_resize_normalize", K._p(pix), K._p(dsc), K._p(tab), N, oh, ow, maxH, int(self.mask), K._p(tmp), K._p(res8), K._p(out))
+        return out
+
+
+class AlignCollate:
+    """`alignCollate_real*` (dataset/dataset.py:1226-1323) reduced to what the training loop consumes: a list of
+    (HR image, LR image, label string) -> (images_HR (N, C, imgH, imgW), images_lr (N, C, imgH/ds, imgW/ds), label_strs)."""
+
+    def __init__(self, imgH=32, imgW=128, down_sample_scale=2, mask=True, device="cuda"):
+        self.hr = ResizeNormalize((imgW, imgH), mask, device)
+        self.lr = ResizeNormalize((imgW // down_sample_scale, imgH // down_sample_scale), mask, device)
+
+    def __call__(self, batch):
+        images_hr, images_lr, label_strs = zip(*batch)
+        return self.hr(images_hr), self.lr(images_lr), list(label_strs)
+
+
+class LmdbDatasetReal:
+    """`lmdbDataset_real` (dataset/dataset.py:104-149): (HR, LR, label) triples from the reference's LMDB layout, decoded to
+    uint8 arrays for AlignCollate.  Needs the `lmdb` and `PIL` packages like the reference; raises a clear error without them."""
+
+    def __init__(self, root, voc_type="upper", max_len=100):
+        try:
+            import lmdb
+        except ImportError as e:
+            raise ImportError("LmdbDatasetReal needs the `lmdb` package (as the reference's dataset/dataset.py does)") from e
+        self.env = lmdb.open(root, max_readers=1, readonly=True, lock=False, readahead=False, meminit=False)
+        with self.env.begin(write=False) as txn:
+            self.nSamples = int(txn.get(NUM_SAMPLES_KEY))
+        self.voc_type, self.max_len = voc_type, max_len
+
+    def __len__(self):
+        return self.nSamples
+
+    def __getitem__(self, index):
+        import io
+        from PIL import Image
+        from .utils.metrics import str_filt
+        keys = lmdb_keys(index)
+        with self.env.begin(write=False) as txn:
+            word = txn.get(keys["label"]).decode()
+            hr = np.asarray(Image.open(io.BytesIO(txn.get(keys["image_hr"]))).convert("RGB"))
+            lr = np.asarray(Image.open(io.BytesIO(txn.get(keys["image_lr"]))).convert("RGB"))
+        return hr, lr, str_filt(word, self.voc_type)

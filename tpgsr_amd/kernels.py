@@ -38,7 +38,8 @@ POLICY = os.environ.get("TPGSR_CONV_PREC", "x3")
 if POLICY not in _TERMS:
     raise ValueError(f"TPGSR_CONV_PREC={POLICY!r}: expected one of {sorted(_TERMS)}")
 CONV_TERMS = _TERMS[POLICY]
-_BF_TWIN = {}     # data_ptr of a packed fp32 operand -> (bf16 planes tensor, kp)
+# a packed fp32 operand tensor carries its bf16 planes as the attribute `_tpgsr_twin` = (planes tensor, kp): the twin lives and
+# dies with the operand (a registry keyed by address would hand a stale twin to the next tensor allocated there)
 
 
 def set_conv_prec(name: str):
@@ -71,7 +72,7 @@ class conv_terms:
 
 
 def register_bf_twin(wt: torch.Tensor, twin: torch.Tensor, kp: int):
-    _BF_TWIN[wt.data_ptr()] = (twin, kp)
+    wt._tpgsr_twin = (twin, kp)
 
 
 class _DummyStream:
@@ -417,7 +418,7 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
         if wt is None or isinstance(wt, (int, DynPtr)):
             a.terms = CONV_TERMS                       # weight-gradient use: no weight operand
         else:
-            tw = _BF_TWIN.get(wt.data_ptr())
+            tw = getattr(wt, "_tpgsr_twin", None)
             if tw is not None:
                 a.terms, a.kp, a.wt_bf = CONV_TERMS, tw[1], tw[0].data_ptr()
                 if _REC is not None:
