@@ -79,8 +79,8 @@ typedef struct {
                              1: plain bf16 operands, fp32 accumulate.  Needs the vector loader (Cin % 4 == 0) and, for
                              tpgsr_conv_fwd, wt_bf; otherwise the call silently stays on the fp32 kernel. */
   int kp;                 /* K rounded up to a multiple of 32 = row length of wt_bf */
-  const void* wt_bf;      /* `wt` pre-split by tpgsr_split_bf_program: bf16 planes [3][rows][kp], rows = wt_ld (or Cout),
-                             row r = column r of `wt`, k contiguous, zero padded */
+  const void* wt_bf;      /* `wt` pre-split by tpgsr_split_bf_program: bf16 planes in MFMA fragment order
+                             [3][ceil(rows / 32)][kp / 16][64 lanes][8], rows = wt_ld (or Cout), zero padded */
 } tpgsr_conv_args;
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);
@@ -189,8 +189,9 @@ int tpgsr_compose_bwd_blocks(int Cin, int U, int G);
 int tpgsr_compose_bwd_program(const tpgsr_compose_bwd_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 /* Split every packed fp32 MFMA operand of a network into bf16 planes for the bf16 matrix-core path, in ONE launch right
- * after tpgsr_pack_program: src fp32 [K][ld] (k-major, N <= ld columns used) -> dst bf16 [3][N][kp], kp = 32*ceil(K/32),
- * x = dst[0] + dst[1] + dst[2] exactly, zero padded in k.  blk0 = prefix sum of tpgsr_split_bf_blocks(K, N). */
+ * after tpgsr_pack_program: src fp32 [K][ld] (k-major, N <= ld columns used) -> dst bf16 planes
+ * [3][ceil(N/32)][kp/16][64][8] (element (k, n) of term t at lane ((k>>3)&1)*32 + (n&31), slot k&7 of block (n/32, k/16)),
+ * kp = 32*ceil(K/32), x = term0 + term1 + term2 exactly, zero padded.  blk0 = prefix sum of tpgsr_split_bf_blocks(K, N). */
 typedef struct tpgsr_split_desc {
   const float* src;
   void* dst;

@@ -65,10 +65,12 @@ def test_split_program_exact():
         twin, kp = k.make_bf_twin(w)
         torch.cuda.synchronize()
         assert kp == (Kd + 31) // 32 * 32
-        planes = twin.view(3, N, kp).float().cpu()
+        NB, KB = (N + 31) // 32, kp // 16
+        # fragment order [3][NB][KB][half = (k >> 3) & 1][n & 31][k & 7]  ->  planes [3][n][k]
+        planes = twin.view(3, NB, KB, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(3, NB * 32, kp).float().cpu()
         rec = (planes[0].double() + planes[1].double() + planes[2].double())
-        assert torch.equal(rec[:, :Kd].t().contiguous().float(), w.cpu()), (Kd, N)      # exact three-term split
-        assert (planes[:, :, Kd:] == 0).all()
+        assert torch.equal(rec[:N, :Kd].t().contiguous().float(), w.cpu()), (Kd, N)      # exact three-term split
+        assert (planes[:, :, Kd:] == 0).all() and (planes[:, N:] == 0).all()
         assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-45).all()
 
 

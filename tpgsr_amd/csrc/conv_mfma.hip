@@ -360,7 +360,7 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
   // bf16 matrix cores with split operands (conv_xbf.hip): vector loader + pre-split weights required
-  if (a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0) {
+  if (a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) {
     TPGSR_CHECK_ARG(a->terms == 1 || a->terms == 3, "tpgsr_conv_fwd: terms must be 0, 1 or 3");
     TPGSR_CHECK_ARG(a->kp >= K && (a->kp & 31) == 0 && ((uintptr_t)a->wt_bf & 15) == 0, "tpgsr_conv_fwd: bad split operand (kp %d, K %d)", a->kp, K);
     return tpgsr_conv_fwd_xbf_launch(a, M, K, ld, st);

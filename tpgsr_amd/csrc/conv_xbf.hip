@@ -20,14 +20,14 @@
 //   rows padded to 192 B; the contraction runs over pixels, so fragments are fetched with the transposing
 //   ds_read_b64_tr_b16 (4 consecutive pixels of one channel per lane and instruction).
 #include "conv_loader.h"
+#include <stdlib.h>
+#include <mutex>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-#define XA_ROW 80                 // bytes per LDS row of the fwd images (32 bf16 + 16 B pad)
-#define XA_PLANE (64 * XA_ROW)
 #define XW_ROW 192                // bytes per LDS row of the wgrad images (64 bf16 + 64 B pad): 4 consecutive rows -> disjoint 64-B bank windows
 #define XW_PLANE (32 * XW_ROW)
 
@@ -70,45 +70,63 @@ __device__ __forceinline__ floatx16 mfma_terms(const bf16x8 (&a)[T], const bf16x
 }
 
 // ------------------------------------------------------------------------------------------------------
-// forward / data-gradient
+// forward / data-gradient.  BMT pixels x 64 channels per workgroup, BMT / 16 waves each owning a 32 x 32 block (two
+// accumulators: the leading term a1 b1, and the five correction terms -- independent MFMA chains, and the corrections are summed
+// among themselves before they meet the large sum), K chunks of 32.
+//   A (activations, split at run time): through a DOUBLE-buffered LDS image with ONE barrier per chunk -- while the matrix pipe
+//     works on chunk c out of buffer c & 1, the same wave splits chunk c + 1 (in registers: its global loads were issued one
+//     iteration earlier) into the other buffer and issues the loads of chunk c + 2.  Image per term: [BMT rows][32 k] bf16 =
+//     64-byte rows, 16-byte slot s of row r stored at slot s ^ ((r >> 2) & 3): conflict-free ds_read_b128 fragments with no
+//     padding (2 x 3 x 8 KB for BMT = 128: two or three workgroups per CU).
+//   W (weights, split once per step by tpgsr_split_bf_program): NEVER touches LDS.  The planes are stored in MFMA fragment
+//     order [term][n / 32][k / 16][lane][8], so a wave's B operand of one k-block is ONE fully coalesced 1 KB load straight into
+//     the registers the MFMA reads.  (Measured on the previous form, which staged W through LDS as well: the LDS pipe was busy
+//     46 % of the kernel, the matrix pipe 31 %, next to each other rather than on top of each other; W was half of the LDS
+//     traffic and a third of the staging instructions.)
 // ------------------------------------------------------------------------------------------------------
-template <int LD, int T>
-__global__ __launch_bounds__(256) void conv_fwd_xbf_kernel(tpgsr_conv_args a, int M, int K) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[T * XA_PLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[T * XA_PLANE];
+__device__ __forceinline__ int xa_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int LD, int T, int BMT>
+__global__ __launch_bounds__(BMT * 4) void conv_fwd_xbf_kernel(tpgsr_conv_args a, int M, int K) {
+  constexpr int A_PLANE = BMT * 64;               // bytes per term
+  constexpr int BUF = T * A_PLANE;
+  constexpr int WROWS = BMT / 32;                 // wave rows (wave columns: 2)
+  __shared__ __attribute__((aligned(16))) unsigned char xsm[2 * BUF];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WROWS, wn = wave / WROWS;
   const int nbn = (a.Cout + BN - 1) / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mblk = tile / nbn;
-  const int m0 = mblk * BM, n0 = (tile - mblk * nbn) * BN;
+  const int m0 = mblk * BMT, n0 = (tile - mblk * nbn) * BN;
   const int nchunks = a.kp / KC;
 
-  // A staging: thread -> quad (tid&7) of the chunk, pixels (tid>>3) and (tid>>3)+32  (as conv_fwd_kernel)
+  // A staging: quad (tid & 7) = 16 of a row's 64 bytes -> half of slot (tid & 7) >> 1; pixels (tid >> 3) and (tid >> 3) + BMT / 2
   const int aq = tid & 7;
   const int am0 = tid >> 3;
   const PixelPos px0 = decode_pixel(a, m0 + am0, M);
-  const PixelPos px1 = decode_pixel(a, m0 + am0 + 32, M);
-  // B staging: weight row (output channel) tid>>2, 16-byte part tid&3 of its 64-byte k slice
-  const int bn_ = tid >> 2, bpart = tid & 3;
+  const PixelPos px1 = decode_pixel(a, m0 + am0 + BMT / 2, M);
+  const int wofs0 = xa_off(am0, aq >> 1) + (aq & 1) * 8;
+  const int wofs1 = xa_off(am0 + BMT / 2, aq >> 1) + (aq & 1) * 8;
 
   const int Wr_ = real_w(a);
   const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * Wr_ * a.in_ld;
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, in_floats);
   const __amdgpu_buffer_rsrc_t rs_in2 = (LD & 16) ? make_rsrc(a.in_b, (size_t)a.N * Wr_ * a.in_b_ld)
                                                   : make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * Wr_ * a.in2_ld);
-  const int wrows = a.wt_ld > 0 ? a.wt_ld : a.Cout;            // rows per plane of the split operand
-  const size_t plane_b = (size_t)wrows * a.kp * 2;               // bytes per plane
-  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const float*>(a.wt_bf), (plane_b * T + 3) / 4);
-  const bool brow_ok = n0 + bn_ < a.Cout;
-  const unsigned boff0 = (unsigned)(((size_t)(a.wt_coff + n0 + bn_) * a.kp) * 2 + bpart * 16);
+  // W fragments: plane t, 32-column block nb, k-block kb16 at ((t * NB32 + nb) * KB16 + kb16) * 1024 bytes (+ lane * 16)
+  const int wrows = a.wt_ld > 0 ? a.wt_ld : a.Cout;
+  const int NB32 = (wrows + 31) >> 5, KB16 = a.kp >> 4;
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const float*>(a.wt_bf), (size_t)T * NB32 * 32 * a.kp / 2);
+  const int nb = (a.wt_coff + n0 + wn * 32) >> 5;
+  const bool bok = n0 + wn * 32 < a.Cout;           // a column block entirely past Cout (Cout <= 32 in a 64-wide tile): zeros
+  const unsigned plane_w = (unsigned)NB32 * KB16 * 1024u;
+  const unsigned woff0 = ((unsigned)nb * KB16) * 1024u + lane * 16u;
 
   ARaw qa0, qa1;
   float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
-  u32x4 rb[T];
   KPos kp_ = kpos_init(a, aq);
-  auto load_chunk = [&](int ch) {
+  auto load_chunk = [&]() {
     qa0 = load_a_raw<LD>(a, rs_in, rs_in2, px0, kp_);
     qa1 = load_a_raw<LD>(a, rs_in, rs_in2, px1, kp_);
     if (LD & 1) {
@@ -116,11 +134,8 @@ __global__ __launch_bounds__(256) void conv_fwd_xbf_kernel(tpgsr_conv_args a, in
       qt = *reinterpret_cast<const float4*>(a.in_shift + (kp_.kh < a.KH ? kp_.c : 0));
     }
     kpos_advance(a, kp_, KC);
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      rb[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, brow_ok ? (int)(boff0 + (unsigned)(t * plane_b) + (unsigned)ch * (KC * 2)) : (int)OOB_OFF, 0, 0);
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](unsigned char* buf) {
     const float4 v0 = finish_a<LD>(a, qa0, qs, qt);
     const float4 v1 = finish_a<LD>(a, qa1, qs, qt);
     uint2 h0[T], h1[T];
@@ -128,42 +143,60 @@ __global__ __launch_bounds__(256) void conv_fwd_xbf_kernel(tpgsr_conv_args a, in
     split4<T>(v1, h1);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      *reinterpret_cast<uint2*>(As + t * XA_PLANE + am0 * XA_ROW + aq * 8) = h0[t];
-      *reinterpret_cast<uint2*>(As + t * XA_PLANE + (am0 + 32) * XA_ROW + aq * 8) = h1[t];
-      *reinterpret_cast<u32x4*>(Bs + t * XA_PLANE + bn_ * XA_ROW + bpart * 16) = rb[t];
+      *reinterpret_cast<uint2*>(buf + t * A_PLANE + wofs0) = h0[t];
+      *reinterpret_cast<uint2*>(buf + t * A_PLANE + wofs1) = h1[t];
     }
   };
 
-  floatx16 acc;
+  floatx16 acc, accl;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) acc[i] = accl[i] = 0.f;
 
-  load_chunk(0);
-  store_chunk();
+  load_chunk();
+  store_chunk(xsm);
+  if (nchunks > 1) load_chunk();
   __syncthreads();
   const int g = lane >> 5;
-  const int acol = wm * 32 + (lane & 31);     // A row (pixel) of this lane's fragments
-  const int bcol = wn * 32 + (lane & 31);     // B row (output channel)
-  const unsigned char* ap = As + acol * XA_ROW + g * 16;
-  const unsigned char* bp = Bs + bcol * XA_ROW + g * 16;
+  const int acol = wm * 32 + (lane & 31);
+  const int bcol = wn * 32 + (lane & 31);
+  const int aoff0 = xa_off(acol, g), aoff1 = xa_off(acol, 2 + g);   // the two k-blocks of a chunk
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    const unsigned char* cur = xsm + (ch & 1) * BUF;
+    unsigned char* nxt = xsm + ((ch + 1) & 1) * BUF;
+    u32x4 bw[2][T];
 #pragma unroll
-    for (int kb = 0; kb < KC / 16; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        bw[kb][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bok ? (int)(woff0 + t * plane_w + (unsigned)(ch * 2 + kb) * 1024u) : (int)OOB_OFF, 0, 0);
+    if (ch + 1 < nchunks) {
+      store_chunk(nxt);                        // chunk ch + 1: in registers since the previous iteration
+      if (ch + 2 < nchunks) load_chunk();
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
       bf16x8 av[T], bv[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        av[t] = *reinterpret_cast<const bf16x8*>(ap + t * XA_PLANE + kb * 32);
-        bv[t] = *reinterpret_cast<const bf16x8*>(bp + t * XA_PLANE + kb * 32);
+        av[t] = *reinterpret_cast<const bf16x8*>(cur + t * A_PLANE + (kb ? aoff1 : aoff0));
+        bv[t] = __builtin_bit_cast(bf16x8, bw[kb][t]);
       }
-      acc = mfma_terms<T>(av, bv, acc);
+      if (T == 3) {
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], accl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], accl, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], accl, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], accl, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], accl, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc, 0, 0, 0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the split arithmetic / LDS stores of the next tile behind the MFMAs
     __syncthreads();
-    if (ch + 1 < nchunks) {
-      store_chunk();
-      __syncthreads();
-    }
+  }
+  if (T == 3) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += accl[i];
   }
 
   // ---- epilogue (as conv_fwd_kernel): bias, activation, (pixel-shuffled) store, BN partial statistics ----
@@ -192,19 +225,24 @@ __global__ __launch_bounds__(256) void conv_fwd_xbf_kernel(tpgsr_conv_args a, in
       }
     }
   }
-  if (a.bn_partial) {
+  if (a.bn_partial) {   // statistics per 64-pixel row block (the layout bn_finalize expects): wave rows 2j, 2j+1 form block j
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
-    float* red = reinterpret_cast<float*>(Bs);  // all MFMA reads finished behind the loop's final barrier
+    float* red = reinterpret_cast<float*>(xsm);     // [WROWS][2][64]; all LDS reads are behind the loop's last barrier
     if (lane < 32) {
       red[(wm * 2 + 0) * BN + bcol] = s;
       red[(wm * 2 + 1) * BN + bcol] = ss;
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < a.Cout) {
-      float* dst = a.bn_partial + (size_t)mblk * 2 * a.Cout;
-      dst[n0 + tid] = red[0 * BN + tid] + red[2 * BN + tid];
-      dst[a.Cout + n0 + tid] = red[1 * BN + tid] + red[3 * BN + tid];
+    constexpr int NBLK = BMT / 64;
+    if (tid < BN * NBLK) {
+      const int blk = tid / BN, c = tid - blk * BN;
+      const long long rb64 = (long long)mblk * NBLK + blk;
+      if (n0 + c < a.Cout && rb64 * 64 < M) {
+        float* dst = a.bn_partial + (size_t)rb64 * 2 * a.Cout;
+        dst[n0 + c] = red[((2 * blk) * 2 + 0) * BN + c] + red[((2 * blk + 1) * 2 + 0) * BN + c];
+        dst[a.Cout + n0 + c] = red[((2 * blk) * 2 + 1) * BN + c] + red[((2 * blk + 1) * 2 + 1) * BN + c];
+      }
     }
   }
 }
@@ -213,12 +251,22 @@ __global__ __launch_bounds__(256) void conv_fwd_xbf_kernel(tpgsr_conv_args a, in
 #define XBF_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7) X(8) X(17)
 
 extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, int K, int ld, hipStream_t st) {
-  dim3 grid(cdiv(M, BM) * cdiv(a->Cout, BN));
   const int T = a->terms;
-#define XBF_FWD_CASE(B)                                                                                 \
-  case B:                                                                                               \
-    if (T == 1) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 1>), grid, dim3(256), 0, st, *a, (int)M, K); \
-    else hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 3>), grid, dim3(256), 0, st, *a, (int)M, K);        \
+  // tile height: 64 pixels.  The 128-pixel variant (TPGSR_XBF_TILE=128) measured equal or slower on every layer shape of
+  // the TSRN / CRNN step at batch 48 (profiles/r02_conv_prec_tiles.md): fewer, fatter workgroups lose more to the tail than
+  // the halved W traffic wins; it is kept for larger problems.
+  static const int force = [] { const char* e = getenv("TPGSR_XBF_TILE"); return e ? atoi(e) : 0; }();
+  const bool big = force == 128;
+  dim3 grid(cdiv(M, big ? 128 : 64) * cdiv(a->Cout, BN));
+#define XBF_FWD_CASE(B)                                                                                          \
+  case B:                                                                                                        \
+    if (T == 1) {                                                                                                \
+      if (big) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 1, 128>), grid, dim3(512), 0, st, *a, (int)M, K);      \
+      else hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 1, 64>), grid, dim3(256), 0, st, *a, (int)M, K);           \
+    } else {                                                                                                     \
+      if (big) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 3, 128>), grid, dim3(512), 0, st, *a, (int)M, K);      \
+      else hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 3, 64>), grid, dim3(256), 0, st, *a, (int)M, K);           \
+    }                                                                                                            \
     break;
   switch (ld) {
     XBF_LD_CASES(XBF_FWD_CASE)
@@ -407,9 +455,10 @@ extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// operand splitting: fp32 [K][ld] (k-major, as packed for the fp32 kernels) -> bf16 planes [3][N][Kp] (k contiguous,
-// Kp = K rounded up to 32, zero padded).  One launch for all operands of a network (descriptor table, 64x64 tiles
-// transposed through LDS so both sides stay coalesced).
+// operand splitting: fp32 [K][ld] (k-major, as packed for the fp32 kernels) -> bf16 planes in MFMA FRAGMENT ORDER
+//   dst[((t * NB32 + n / 32) * KB16 + k / 16) * 64 + ((k >> 3) & 1) * 32 + (n & 31)][k & 7],  NB32 = ceil(N / 32), KB16 = Kp / 16,
+// Kp = K rounded up to 32, zero padded in k and n: the B operand of one (32-column, 16-k) block is 1 KB contiguous, lane-major.
+// One launch for all operands of a network (descriptor table, 64x64 tiles transposed through LDS so both sides stay coalesced).
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_bf_program_kernel(const tpgsr_split_desc* __restrict__ descs, int ndesc) {
   __shared__ float tile[64][65];
@@ -426,8 +475,8 @@ __global__ __launch_bounds__(256) void split_bf_program_kernel(const tpgsr_split
   const tpgsr_split_desc d = descs[s_d];
   const int b = (int)blockIdx.x - d.blk0;
   const int nkb = d.kp / 64 + ((d.kp & 63) ? 1 : 0);
-  const int kb = b % nkb, nb = b / nkb;
-  const int k0 = kb * 64, n0 = nb * 64;
+  const int kb = b % nkb, nbk = b / nkb;
+  const int k0 = kb * 64, n0 = nbk * 64;
   {  // load: coalesced along n
     const int n = threadIdx.x & 63, kr = threadIdx.x >> 6;
 #pragma unroll
@@ -437,22 +486,24 @@ __global__ __launch_bounds__(256) void split_bf_program_kernel(const tpgsr_split
     }
   }
   __syncthreads();
-  const int n = threadIdx.x >> 2, kq = (threadIdx.x & 3) * 16;
-  if (n0 + n >= d.N) return;
+  const int NB32 = (d.N + 31) >> 5, KB16 = d.kp >> 4;
   unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
-  const size_t plane = (size_t)d.N * d.kp;
-  for (int half = 0; half < 2; ++half) {
-    const int kk = k0 + kq + half * 8;
-    if (kk >= d.kp) break;                 // kp is a multiple of 32: 8-element groups are all-in or all-out
+  const size_t plane = (size_t)NB32 * KB16 * 512;            // bf16 elements per term
+  for (int i = 0; i < 2; ++i) {
+    const int p = threadIdx.x + 256 * i;                      // 64 columns x 8 groups of 8 k
+    const int n = p & 63, kg = p >> 6;
+    const int k = k0 + kg * 8, nn = n0 + n;
+    if (k >= d.kp || nn >= NB32 * 32) continue;
     __bf16 h[8][3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split_bf<3>(tile[kq + half * 8 + j][n], h[j]);
+    for (int j = 0; j < 8; ++j) split_bf<3>(tile[kg * 8 + j][n], h[j]);
+    const size_t off = ((((size_t)(nn >> 5) * KB16 + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (nn & 31)) * 8;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       bf16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = h[j][t];
-      *reinterpret_cast<bf16x8*>(dst + t * plane + (size_t)(n0 + n) * d.kp + kk) = v;
+      *reinterpret_cast<bf16x8*>(dst + t * plane + off) = v;
     }
   }
 }

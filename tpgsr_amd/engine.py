@@ -501,7 +501,7 @@ class _EngineBase:
         for d, t in zip(arr, ops):
             Kd, N = t.shape
             kp = (Kd + 31) // 32 * 32
-            twin = torch.zeros(3 * N * kp, dtype=torch.bfloat16, device=self.device)
+            twin = torch.zeros(3 * ((N + 31) // 32 * 32) * kp, dtype=torch.bfloat16, device=self.device)
             K.register_bf_twin(t, twin, kp)
             d.src, d.dst, d.K, d.N, d.ld, d.kp, d.blk0 = t.data_ptr(), twin.data_ptr(), Kd, N, N, kp, blk
             blk += lib.tpgsr_split_bf_blocks(Kd, N)

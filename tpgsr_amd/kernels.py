@@ -745,7 +745,7 @@ def make_bf_twin(wt: torch.Tensor):
     lib = _lib.load()
     Kd, N = wt.shape
     kp = (Kd + 31) // 32 * 32
-    twin = torch.zeros(3 * N * kp, dtype=torch.bfloat16, device=wt.device)
+    twin = torch.zeros(3 * ((N + 31) // 32 * 32) * kp, dtype=torch.bfloat16, device=wt.device)
     d = (_lib.SplitDesc * 1)()
     d[0].src, d[0].dst, d[0].K, d[0].N, d[0].ld, d[0].kp, d[0].blk0 = wt.data_ptr(), twin.data_ptr(), Kd, N, N, kp, 0
     table = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(wt.device)
