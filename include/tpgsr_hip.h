@@ -81,6 +81,10 @@ typedef struct {
   int kp;                 /* K rounded up to a multiple of 32 = row length of wt_bf */
   const void* wt_bf;      /* `wt` pre-split by tpgsr_split_bf_program: bf16 planes in MFMA fragment order
                              [3][ceil(rows / 32)][kp / 16][64 lanes][8], rows = wt_ld (or Cout), zero padded */
+  int wt_bf_cin;          /* 0: wt_bf rows in the natural k = (tap, ci) order.  Cin (a multiple of 32): in channel-block order
+                             k' = ((ci / 32) * KH*KW + tap) * 32 + ci % 32  (tpgsr_split_desc.cin), which is what lets KH x KW
+                             convolutions run on the halo kernel */
+  int reserved0;
 } tpgsr_conv_args;
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);
@@ -195,10 +199,14 @@ int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_bl
 typedef struct tpgsr_split_desc {
   const float* src;
   void* dst;
-  int K, N, ld, kp, blk0, reserved;
+  int K, N, ld, kp, blk0;
+  int cin;                /* > 0 (a multiple of 32 dividing K): write the rows in channel-block order, see tpgsr_conv_args.wt_bf_cin */
 } tpgsr_split_desc;
 int tpgsr_split_bf_blocks(int K, int N);
 int tpgsr_split_bf_program(const tpgsr_split_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+/* diagnostic: time line of the halo convolution kernel.  buf = 8 * 8 * 256 uint64 of device memory ([workgroup][wave][slot],
+ * 100 MHz wall-clock stamps, see csrc/conv_xbf.hip) or NULL to switch it off.  Not thread safe; off by default. */
+int tpgsr_halo_trace(unsigned long long* buf);
 /* diagnostic: out[lane*4 + j] = what ds_read_b64_tr_b16 hands lane `lane` as element j from a [16 rows][16] image of
  * consecutive integers, addressed like the weight-gradient fragment fetch (64 lanes, 256 ints) */
 int tpgsr_tr_probe(int* out, void* stream);

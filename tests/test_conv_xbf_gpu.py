@@ -90,7 +90,7 @@ def test_bf16_operands_kernel_level(case, bf16):
     Cp = (Co + 3) // 4 * 4
     wf = torch.zeros(KH * KW * Ci, Cp, device=DEV)
     wf[:, :Co] = w.permute(2, 3, 1, 0).reshape(-1, Co).to(DEV)
-    k.make_bf_twin(wf)
+    k.make_bf_twin(wf, Ci)
     out = torch.full((geom.M, Co), float("nan"), device=DEV)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     k.conv_fwd(k.make_conv_args(geom, xd, wf, out, wt_ld=Cp))
@@ -245,3 +245,125 @@ def test_c5_shape_bf16_policy_gates(bf16):
     assert max(mism) <= 26 * 32 // 8          # measured 64 / 832: the later stages read a bf16-level different SR image
     assert dpsnr < 5e-3                        # measured 2.1e-3 dB
     assert abs(loss.item() - ref["loss"].item()) < 3e-3 * ref["loss"].item()
+
+
+
+def test_split_program_channel_block_order():
+    """cin > 0: rows of the planes in k' = ((ci / 32) * taps + tap) * 32 + ci % 32 order (what the halo kernel consumes)"""
+    k = K()
+    g = torch.Generator().manual_seed(3)
+    for (taps, Cin, N) in [(9, 64, 64), (4, 96, 40), (9, 32, 192)]:
+        Kd = taps * Cin
+        w = torch.randn(Kd, N, generator=g).to(DEV).contiguous()
+        twin, kp = k.make_bf_twin(w, Cin)
+        assert w._tpgsr_twin[2] == Cin
+        torch.cuda.synchronize()
+        NB, KB = (N + 31) // 32, kp // 16
+        planes = twin.view(3, NB, KB, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(3, NB * 32, kp).float()
+        rec = (planes[0] + planes[1] + planes[2])[:N, :Kd].t()                      # [k'][n]
+        kk = torch.arange(Kd)
+        cc, rem = kk // (taps * 32), kk % (taps * 32)
+        src = (rem // 32) * Cin + cc * 32 + rem % 32                                # natural k of every k'
+        assert torch.equal(rec.cpu(), w.cpu()[src]), (taps, Cin, N)
+    # single-tap or non-multiple-of-32 operands stay in natural order
+    assert k.block_order_cin(64, 64) == 0 and k.block_order_cin(9 * 40, 40) == 0 and k.block_order_cin(9 * 64, 64) == 64
+
+
+def _halo_case(N, H, W, Ci, Co, KH, KW, ph, pw, *, affine, act, resid, bn, bias, seed, terms=None):
+    """conv forward through the halo kernel vs the fp64 restatement; returns (max rel err of the output, of the BN sums)"""
+    k = K()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    x2 = torch.randn(N, Ci, H, W, generator=g) if resid else None
+    sc = torch.rand(Ci, generator=g) + 0.5 if affine else None
+    sh = torch.randn(Ci, generator=g) * 0.3 if affine else None
+    w = torch.randn(Co, Ci, KH, KW, generator=g) / math.sqrt(Ci * KH * KW)
+    b = torch.randn(Co, generator=g) if bias else None
+    a = x.double()
+    if affine:
+        a = a * sc.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double()
+    if act:
+        a = a * torch.tanh(F.softplus(a))
+    if resid:
+        a = a + x2.double()
+    raw = F.conv2d(a, w.double(), None, padding=(ph, pw))
+    ref = raw + (b.double().view(1, -1, 1, 1) if bias else 0.0)
+    geom = k.ConvGeom(N, H, W, Ci, Co, KH, KW, ph, pw)
+    wf = w.permute(2, 3, 1, 0).reshape(KH * KW * Ci, Co).contiguous().to(DEV)
+    k.make_bf_twin(wf, Ci)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().to(DEV)
+    out = torch.full((geom.M, Co), float("nan"), device=DEV)
+    part = torch.zeros((geom.M + 63) // 64, 2, Co, device=DEV) if bn else None
+    keep = [nhwc(x), nhwc(x2) if resid else None, sc.to(DEV) if affine else None, sh.to(DEV) if affine else None,
+            b.to(DEV) if bias else None]
+    k.conv_fwd(k.make_conv_args(geom, keep[0], wf, out, bias=keep[4], in2=keep[1], in_scale=keep[2], in_shift=keep[3],
+                                in_act="mish" if act else None, bn_partial=part))
+    torch.cuda.synchronize()
+    OH, OW = geom.OH, geom.OW
+    got = out.cpu().double().reshape(N, OH, OW, Co).permute(0, 3, 1, 2)
+    e_out = ((got - ref).abs().max() / ref.abs().max()).item()
+    e_bn = 0.0
+    if bn:
+        s, ss = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
+        e_bn = max(((s - raw.sum((0, 2, 3))).abs().max() / raw.sum((0, 2, 3)).abs().max()).item(),
+                   ((ss - (raw ** 2).sum((0, 2, 3))).abs().max() / (raw ** 2).sum((0, 2, 3)).abs().max()).item())
+        # every 64-pixel block's row, not just the totals (the persistent kernel flushes each tile's statistics one barrier late)
+        rb = raw.permute(0, 2, 3, 1).reshape(-1, Co)
+        pad = (-rb.shape[0]) % 64
+        rb = torch.cat([rb, rb.new_zeros(pad, Co)]).reshape(-1, 64, Co)
+        e_bn = max(e_bn, ((part[:, 0].double().cpu() - rb.sum(1)).abs().max() / rb.sum(1).abs().max()).item())
+    return e_out, e_bn
+
+
+HALO_SHAPES = [
+    # N, H, W, Ci, Co, KH, KW, ph, pw
+    (48, 16, 64, 64, 64, 3, 3, 1, 1),      # the trunk: 768 tiles on a 512-workgroup persistent grid (1 or 2 tiles each)
+    (48, 16, 64, 64, 256, 3, 3, 1, 1),     # upsample conv: 3072 tiles, 6 per workgroup
+    (5, 8, 25, 128, 96, 3, 3, 1, 1),       # recognizer conv2 shape: tiles span rows AND images (8 * 25 = 200 pixels per image)
+    (7, 4, 26, 64, 40, 3, 3, 1, 1),        # 104 pixels per image, ragged Cout (40 < 64), ragged last tile
+    (3, 2, 27, 96, 64, 2, 2, 0, 0),        # 2x2, no padding (recognizer conv6): OH = 1
+    (2, 16, 50, 64, 128, 3, 3, 1, 1),      # recognizer conv1 shape: the 9-entries-per-thread variant (halo of 278 entries)
+    (2, 12, 20, 32, 64, 5, 3, 2, 1),       # odd taps, KH != KW, one channel block
+    (2, 6, 10, 64, 4, 3, 3, 1, 1),         # narrow map (padded width 12: a 32-entry step of the halo walk wraps three rows), Cout 4
+    (3, 5, 9, 32, 8, 5, 5, 2, 2),          # 5x5 on a 9-wide map
+    (2, 9, 6, 32, 64, 3, 3, 1, 1),         # padded width 8: the narrowest the halo kernel takes
+]
+
+
+@pytest.mark.parametrize("shape", HALO_SHAPES)
+def test_halo_kernel_shapes(shape):
+    """plain loader, bias + BN partials, against fp64 (x3 arithmetic: fp32-level agreement)"""
+    e_out, e_bn = _halo_case(*shape, affine=False, act=False, resid=False, bn=True, bias=True, seed=11)
+    print(f"halo {shape}: out {e_out:.2e}  bn {e_bn:.2e}")
+    assert e_out < 3e-6 and e_bn < 2e-5
+
+
+@pytest.mark.parametrize("affine,act,resid", [(True, False, False), (False, True, False), (True, True, False), (False, False, True),
+                                               (True, False, True), (True, True, True)])
+def test_halo_kernel_prologues(affine, act, resid):
+    """every fused-prologue variant the halo kernel is instantiated for (LD 1, 2, 3, 4, 5, 7), on a multi-tile-per-workgroup shape"""
+    e_out, e_bn = _halo_case(40, 16, 64, 64, 64, 3, 3, 1, 1, affine=affine, act=act, resid=resid, bn=True, bias=False, seed=5)
+    print(f"halo prologue affine={affine} act={act} resid={resid}: out {e_out:.2e}  bn {e_bn:.2e}")
+    assert e_out < 3e-6 and e_bn < 2e-5
+
+
+def test_halo_kernel_matches_tile_loop():
+    """the same convolution through the halo kernel (weights split in channel-block order) and through the tile loop (weights
+    split in natural order, which the halo kernel does not take): identical up to accumulation order"""
+    k = K()
+    g = torch.Generator().manual_seed(2)
+    N, H, W, C = 6, 16, 64, 64
+    x = torch.randn(N * H * W, C, generator=g).to(DEV)
+    w = (torch.randn(9 * C, C, generator=g) * 0.05).to(DEV)
+    geom = k.ConvGeom(N, H, W, C, C, 3, 3, 1, 1)
+    outs = []
+    for cin in (C, 0):          # channel-block order -> halo kernel; natural order -> tile loop
+        wf = w.clone()
+        k.make_bf_twin(wf, cin)
+        out = torch.empty(geom.M, C, device=DEV)
+        k.conv_fwd(k.make_conv_args(geom, x, wf, out))
+        torch.cuda.synchronize()
+        outs.append(out.double().cpu())
+    err = ((outs[0] - outs[1]).abs().max() / outs[1].abs().max()).item()
+    print(f"halo vs tile loop: {err:.2e}")
+    assert err < 2e-6

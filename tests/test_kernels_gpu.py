@@ -41,8 +41,8 @@ def pack_f(w):  # [Co][Ci][KH][KW] -> [K][Co] on device through the kernel under
     wdev = w.to(DEV).contiguous()
     k.pack_conv_weight(wdev, Co, Ci, KH, KW, wf, wd)
     if k.CONV_TERMS:
-        k.make_bf_twin(wf)
-        k.make_bf_twin(wd)
+        k.make_bf_twin(wf, Ci)
+        k.make_bf_twin(wd, Co)
     torch.cuda.synchronize()
     return wf, wd
 
@@ -294,7 +294,7 @@ def test_tail_fold_matches_conv9x9(prec):
     wdev = w.detach().float().to(DEV).contiguous()
     k.pack_tail_weight(wdev, Co, C, KS, wf, wd)
     if k.CONV_TERMS:
-        k.make_bf_twin(wf)
+        k.make_bf_twin(wf, C)
         k.make_bf_twin(wd)
     geom = k.ConvGeom(N, H, W, C, KS * Co, KS, 1, KS // 2, 0)
     P = torch.empty(geom.M, KS * Co, device=DEV)

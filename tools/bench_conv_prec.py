@@ -40,7 +40,7 @@ def case(name, N, Hh, Ww, Ci, Co, KH, KW, ph, pw):
     dy = torch.randn(g.M, Co, device=DEV)
     Z = K.wgrad_splits(g.M, g.K, Co)
     part = torch.empty(Z, g.K, Co, device=DEV)
-    K.make_bf_twin(wf)
+    K.make_bf_twin(wf, Ci)
     fa, wa = [], []
     for prec in ("f32", "x3", "bf16"):
         K.set_conv_prec(prec)

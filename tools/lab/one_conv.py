@@ -17,7 +17,7 @@ x = torch.randn(g.N * H * W, Ci, device="cuda")
 wf = torch.randn(g.K, Co, device="cuda") * 0.05
 out = torch.empty(g.M, Co, device="cuda")
 dy = torch.randn(g.M, Co, device="cuda")
-K.make_bf_twin(wf)
+K.make_bf_twin(wf, Ci)
 K.set_conv_prec(mode)
 if wgrad:
     Z = K.wgrad_splits(g.M, g.K, Co)

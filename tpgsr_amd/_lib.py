@@ -30,7 +30,7 @@ class ConvArgs(C.Structure):
                 ("Cout", ci), ("KH", ci), ("KW", ci), ("pad_h", ci), ("pad_w", ci), ("OH", ci), ("OW", ci),
                 ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci),
                 ("in_b", vp), ("cin_a", ci), ("in_b_ld", ci), ("in_dil_w", ci), ("wt_ld", ci), ("wt_coff", ci), ("stride_w", ci),
-                ("terms", ci), ("kp", ci), ("wt_bf", vp)]
+                ("terms", ci), ("kp", ci), ("wt_bf", vp), ("wt_bf_cin", ci), ("reserved0", ci)]
 
 
 class WgradArgs(C.Structure):
@@ -55,7 +55,7 @@ class WgradReduceDesc(C.Structure):
 
 
 class SplitDesc(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("K", ci), ("N", ci), ("ld", ci), ("kp", ci), ("blk0", ci), ("reserved", ci)]
+    _fields_ = [("src", vp), ("dst", vp), ("K", ci), ("N", ci), ("ld", ci), ("kp", ci), ("blk0", ci), ("cin", ci)]
 
 
 class ImageDesc(C.Structure):
@@ -162,6 +162,7 @@ _SIGS = {
     "tpgsr_split_bf_blocks": (ci, [ci, ci]),
     "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_tr_probe": (ci, [vp, vp]),
+    "tpgsr_halo_trace": (ci, [vp]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 

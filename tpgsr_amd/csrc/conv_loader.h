@@ -142,13 +142,36 @@ __device__ __forceinline__ void kpos_advance(const tpgsr_conv_args& a, KPos& k, 
   }
 }
 
+// branch-free form of kpos_advance for a fixed step (all quantities wave-uniform): the bf16 kernels keep loads in flight
+// across iterations, and control flow inside the loop makes the compiler's s_waitcnt placement conservative
+struct KStep {
+  int dr, dqw, dqh;   // dk = (dqh * KW + dqw) * Cin + dr
+};
+__device__ __forceinline__ KStep kstep_init(const tpgsr_conv_args& a, int dk) {
+  KStep s;
+  const int dq = dk / a.Cin;
+  s.dr = dk - dq * a.Cin;
+  s.dqh = dq / a.KW;
+  s.dqw = dq - s.dqh * a.KW;
+  return s;
+}
+__device__ __forceinline__ void kpos_advance(const tpgsr_conv_args& a, KPos& k, const KStep& s) {
+  k.c += s.dr;
+  const bool cc = k.c >= a.Cin;
+  k.c -= cc ? a.Cin : 0;
+  k.kw += s.dqw + (cc ? 1 : 0);          // < 2 KW
+  const bool cw = k.kw >= a.KW;
+  k.kw -= cw ? a.KW : 0;
+  k.kh += s.dqh + (cw ? 1 : 0);
+}
+
 template <int LD>
 __device__ __forceinline__ ARaw load_a_raw(const tpgsr_conv_args& a, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rin2,
                                            const PixelPos& p, const KPos& kp) {
   ARaw r;
   const int kh = kp.kh, kw = kp.kw, c = kp.c;
   int ih = p.oh + kh - a.pad_h, iw = p.ow * stride_w(a) + kw - a.pad_w;
-  r.ok = p.valid && kh < a.KH && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+  r.ok = p.valid && kh < a.KH && c < a.Cin && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
   int Wr = a.W;
   if (a.in_dil_w > 1) {
     r.ok = r.ok && (iw % a.in_dil_w) == 0;

@@ -21,6 +21,10 @@
 //   ds_read_b64_tr_b16 (4 consecutive pixels of one channel per lane and instruction).
 #include "conv_loader.h"
 #include <stdlib.h>
+#include <stdio.h>
+#include <type_traits>
+#include <utility>
+#include <vector>
 #include <mutex>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -69,45 +73,131 @@ __device__ __forceinline__ floatx16 mfma_terms(const bf16x8 (&a)[T], const bf16x
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
+// ---- epilogue shared by the forward kernels (as conv_fwd_kernel): bias, activation, (pixel-shuffled) store, BN partial
+// statistics.  The calling threads are the 256 of the four MFMA waves (tid 0..255); `red` = 4 * 64 WNB floats of LDS nobody
+// reads any more; contains one __syncthreads() when a.bn_partial is set. ----
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int wm,
+                                               int wn, int lane, float* red) {
+  constexpr int BNT = 64 * WNB;
+  const int ohw = a.OH * a.OW;
+#pragma unroll
+  for (int j = 0; j < WNB; ++j) {
+    const int cloc = wn * 32 * WNB + 32 * j + (lane & 31);
+    const int n = n0 + cloc;
+    const bool nvalid = n < a.Cout;
+    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int m = m0 + wm * 32 * WMB + 32 * i + row;
+        if (m < M && nvalid) {
+          float raw = acc[i][j][r];
+          s += raw;
+          ss += raw * raw;
+          float v = apply_act(raw + bias, a.out_act);
+          if (!a.out_ps) {
+            a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+          } else {
+            int nn = m / ohw;
+            int rem = m - nn * ohw;
+            int oh = rem / a.OW, ow = rem - oh * a.OW;
+            int cs = n >> 2, pi = (n >> 1) & 1, pj = n & 1;
+            a.out[((size_t)(nn * 2 * a.OH + 2 * oh + pi) * (2 * a.OW) + 2 * ow + pj) * (a.Cout >> 2) + cs] = v;
+          }
+        }
+      }
+    if (a.bn_partial) {
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * BNT + cloc] = s;
+        red[(wm * 2 + 1) * BNT + cloc] = ss;
+      }
+    }
+  }
+}
+// after a barrier: statistics per 64-pixel row block (the layout bn_finalize expects) out of the wave rows' partials
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, int n0, int mblk, int tid, const float* red) {
+  constexpr int BNT = 64 * WNB;
+  // WMB = 1: the two wave rows together are the one 64-pixel block; WMB = 2: each wave row is a block of its own
+  for (int e = tid; e < BNT * WMB; e += 256) {
+    const int blk = e / BNT, c = e - blk * BNT;
+    const long long rb64 = (long long)mblk * WMB + blk;
+    if (n0 + c < a.Cout && rb64 * 64 < M) {
+      float* dst = a.bn_partial + (size_t)rb64 * 2 * a.Cout;
+      if (WMB == 1) {
+        dst[n0 + c] = red[0 * BNT + c] + red[2 * BNT + c];
+        dst[a.Cout + n0 + c] = red[1 * BNT + c] + red[3 * BNT + c];
+      } else {
+        dst[n0 + c] = red[(blk * 2 + 0) * BNT + c];
+        dst[a.Cout + n0 + c] = red[(blk * 2 + 1) * BNT + c];
+      }
+    }
+  }
+}
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_epilogue(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int mblk,
+                                             int wm, int wn, int lane, int tid, float* red) {
+  xbf_store_tile<WMB, WNB>(a, acc, M, m0, n0, wm, wn, lane, red);
+  if (a.bn_partial) {
+    __syncthreads();
+    xbf_bn_flush<WMB, WNB>(a, M, n0, mblk, tid, red);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
-// forward / data-gradient.  BMT pixels x 64 channels per workgroup, BMT / 16 waves each owning a 32 x 32 block (two
-// accumulators: the leading term a1 b1, and the five correction terms -- independent MFMA chains, and the corrections are summed
-// among themselves before they meet the large sum), K chunks of 32.
+// forward / data-gradient.  Workgroup = 4 waves in a 2 x 2 arrangement; every wave owns WMB x WNB accumulator blocks of
+// 32 x 32, so the workgroup tile is (64 WMB) pixels x (64 WNB) channels.  K chunks of 32 (two MFMA k-blocks of 16).
 //   A (activations, split at run time): through a DOUBLE-buffered LDS image with ONE barrier per chunk -- while the matrix pipe
 //     works on chunk c out of buffer c & 1, the same wave splits chunk c + 1 (in registers: its global loads were issued one
-//     iteration earlier) into the other buffer and issues the loads of chunk c + 2.  Image per term: [BMT rows][32 k] bf16 =
+//     iteration earlier) into the other buffer and issues the loads of chunk c + 2.  Image per term: [rows][32 k] bf16 =
 //     64-byte rows, 16-byte slot s of row r stored at slot s ^ ((r >> 2) & 3): conflict-free ds_read_b128 fragments with no
-//     padding (2 x 3 x 8 KB for BMT = 128: two or three workgroups per CU).
+//     padding.
 //   W (weights, split once per step by tpgsr_split_bf_program): NEVER touches LDS.  The planes are stored in MFMA fragment
 //     order [term][n / 32][k / 16][lane][8], so a wave's B operand of one k-block is ONE fully coalesced 1 KB load straight into
-//     the registers the MFMA reads.  (Measured on the previous form, which staged W through LDS as well: the LDS pipe was busy
-//     46 % of the kernel, the matrix pipe 31 %, next to each other rather than on top of each other; W was half of the LDS
-//     traffic and a third of the staging instructions.)
+//     the registers the MFMA reads.
+//   Why the blocks per wave matter (x3 mode, per 32x32x16 MFMA = 32 cycles of one SIMD, i.e. one MFMA per 8 clk per CU at
+//     peak): a 1 x 1 wave tile needs 3 A + 3 W fragments (6 KB) per 6 MFMAs = 512 B of LDS reads AND 512 B of L1 reads per
+//     MFMA -- 50 % of the LDS pipe (128 B/clk) and 100 % of the vector L1 (64 B/clk) at matrix peak, which is where the
+//     1 x 1 kernel sat (31 % matrix-pipe busy, LDS 46 %: rocprofv3 PMC, profiles/r02_pmc_conv_v3.md).  2 x 1 halves the W
+//     bytes per MFMA, 2 x 2 halves both.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int xa_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <int LD, int T, int BMT>
-__global__ __launch_bounds__(BMT * 4) void conv_fwd_xbf_kernel(tpgsr_conv_args a, int M, int K) {
+// register budget: 1 x 1 wave tiles must keep three workgroups per CU resident (the trunk convolutions launch exactly
+// three per CU), i.e. <= 168 VGPRs + AGPRs
+template <int LD, int T, int WMB, int WNB>
+__global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1)) void conv_fwd_xbf_kernel(tpgsr_conv_args a, int M, int K) {
+  constexpr int BMT = 64 * WMB, BNT = 64 * WNB;
   constexpr int A_PLANE = BMT * 64;               // bytes per term
   constexpr int BUF = T * A_PLANE;
-  constexpr int WROWS = BMT / 32;                 // wave rows (wave columns: 2)
+  constexpr int NQ = BMT / 32;                    // A quads (4 consecutive k of one pixel) per thread and chunk
+  constexpr bool TWO = (T == 3) && (WMB * WNB <= 2);   // separate accumulator for the correction terms (registers permitting)
   __shared__ __attribute__((aligned(16))) unsigned char xsm[2 * BUF];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave % WROWS, wn = wave / WROWS;
-  const int nbn = (a.Cout + BN - 1) / BN;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int nbn = (a.Cout + BNT - 1) / BNT;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mblk = tile / nbn;
-  const int m0 = mblk * BMT, n0 = (tile - mblk * nbn) * BN;
+  const int m0 = mblk * BMT, n0 = (tile - mblk * nbn) * BNT;
   const int nchunks = a.kp / KC;
 
-  // A staging: quad (tid & 7) = 16 of a row's 64 bytes -> half of slot (tid & 7) >> 1; pixels (tid >> 3) and (tid >> 3) + BMT / 2
+  // A staging: quad (tid & 7) = 16 of a row's 64 bytes -> half of slot (tid & 7) >> 1; pixels (tid >> 3) + 32 i
   const int aq = tid & 7;
   const int am0 = tid >> 3;
-  const PixelPos px0 = decode_pixel(a, m0 + am0, M);
-  const PixelPos px1 = decode_pixel(a, m0 + am0 + BMT / 2, M);
-  const int wofs0 = xa_off(am0, aq >> 1) + (aq & 1) * 8;
-  const int wofs1 = xa_off(am0 + BMT / 2, aq >> 1) + (aq & 1) * 8;
+  PixelPos px[NQ];
+  int wofs[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    px[i] = decode_pixel(a, m0 + am0 + 32 * i, M);
+    wofs[i] = xa_off(am0 + 32 * i, aq >> 1) + (aq & 1) * 8;
+  }
 
   const int Wr_ = real_w(a);
   const size_t in_floats = a.in_ps ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * Wr_ * a.in_ld;
@@ -118,155 +208,585 @@ __global__ __launch_bounds__(BMT * 4) void conv_fwd_xbf_kernel(tpgsr_conv_args a
   const int wrows = a.wt_ld > 0 ? a.wt_ld : a.Cout;
   const int NB32 = (wrows + 31) >> 5, KB16 = a.kp >> 4;
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const float*>(a.wt_bf), (size_t)T * NB32 * 32 * a.kp / 2);
-  const int nb = (a.wt_coff + n0 + wn * 32) >> 5;
-  const bool bok = n0 + wn * 32 < a.Cout;           // a column block entirely past Cout (Cout <= 32 in a 64-wide tile): zeros
+  const int ncol0 = n0 + wn * 32 * WNB;             // first column of this wave
   const unsigned plane_w = (unsigned)NB32 * KB16 * 1024u;
-  const unsigned woff0 = ((unsigned)nb * KB16) * 1024u + lane * 16u;
+  unsigned woff[WNB];
+#pragma unroll
+  for (int j = 0; j < WNB; ++j)   // a column block entirely past Cout: zeros (hardware zero fill of the out-of-range offset)
+    woff[j] = ncol0 + 32 * j < a.Cout ? ((unsigned)((a.wt_coff + ncol0 + 32 * j) >> 5) * KB16) * 1024u + lane * 16u : OOB_OFF;
 
-  ARaw qa0, qa1;
+  ARaw qa[NQ];
   float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
-  KPos kp_ = kpos_init(a, aq);
-  auto load_chunk = [&]() {
-    qa0 = load_a_raw<LD>(a, rs_in, rs_in2, px0, kp_);
-    qa1 = load_a_raw<LD>(a, rs_in, rs_in2, px1, kp_);
+  // K order of the pre-split weights: natural (tap, ci), or -- a.wt_bf_cin > 0 -- channel blocks of 32 outermost:
+  // k' = ((ci / 32) * KH KW + tap) * 32 + ci % 32 (the order the halo kernel below consumes; chunk = one tap of one block)
+  const bool kperm = a.wt_bf_cin > 0;
+  KPos kp_ = kperm ? KPos{0, 0, aq * 4} : kpos_init(a, aq);
+  const KStep kstep = kstep_init(a, KC);
+  auto load_chunk = [&]() {          // past the last chunk: kh >= KH, every load is the hardware-zero-filled out-of-range one
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) qa[i] = load_a_raw<LD>(a, rs_in, rs_in2, px[i], kp_);
     if (LD & 1) {
-      qs = *reinterpret_cast<const float4*>(a.in_scale + (kp_.kh < a.KH ? kp_.c : 0));
-      qt = *reinterpret_cast<const float4*>(a.in_shift + (kp_.kh < a.KH ? kp_.c : 0));
+      qs = *reinterpret_cast<const float4*>(a.in_scale + ((kp_.kh < a.KH && kp_.c < a.Cin) ? kp_.c : 0));
+      qt = *reinterpret_cast<const float4*>(a.in_shift + ((kp_.kh < a.KH && kp_.c < a.Cin) ? kp_.c : 0));
     }
-    kpos_advance(a, kp_, KC);
+    if (kperm) {
+      const bool cw = ++kp_.kw >= a.KW;
+      kp_.kw = cw ? 0 : kp_.kw;
+      kp_.kh += cw ? 1 : 0;
+      const bool chh = kp_.kh >= a.KH;
+      kp_.kh = chh ? 0 : kp_.kh;
+      kp_.c += chh ? 32 : 0;
+    } else {
+      kpos_advance(a, kp_, kstep);
+    }
   };
   auto store_chunk = [&](unsigned char* buf) {
-    const float4 v0 = finish_a<LD>(a, qa0, qs, qt);
-    const float4 v1 = finish_a<LD>(a, qa1, qs, qt);
-    uint2 h0[T], h1[T];
-    split4<T>(v0, h0);
-    split4<T>(v1, h1);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      *reinterpret_cast<uint2*>(buf + t * A_PLANE + wofs0) = h0[t];
-      *reinterpret_cast<uint2*>(buf + t * A_PLANE + wofs1) = h1[t];
+    for (int i = 0; i < NQ; ++i) {
+      const float4 v = finish_a<LD>(a, qa[i], qs, qt);
+      uint2 h[T];
+      split4<T>(v, h);
+#pragma unroll
+      for (int t = 0; t < T; ++t) *reinterpret_cast<uint2*>(buf + t * A_PLANE + wofs[i]) = h[t];
     }
   };
 
-  floatx16 acc, accl;
+  floatx16 acc[WMB][WNB], accl[TWO ? WMB : 1][TWO ? WNB : 1];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = accl[i] = 0.f;
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < WNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if (TWO) accl[i][j][r] = 0.f;
+      }
 
-  load_chunk();
-  store_chunk(xsm);
-  if (nchunks > 1) load_chunk();
-  __syncthreads();
   const int g = lane >> 5;
-  const int acol = wm * 32 + (lane & 31);
-  const int bcol = wn * 32 + (lane & 31);
-  const int aoff0 = xa_off(acol, g), aoff1 = xa_off(acol, 2 + g);   // the two k-blocks of a chunk
-  for (int ch = 0; ch < nchunks; ++ch) {
+  int aoff[WMB][2];                                  // the two k-blocks of a chunk
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+    const int arow = wm * 32 * WMB + 32 * i + (lane & 31);
+    aoff[i][0] = xa_off(arow, g);
+    aoff[i][1] = xa_off(arow, 2 + g);
+  }
+  // Software pipeline, one chunk deep in REGISTERS on top of the one-chunk-deep LDS image: iteration c issues the fragment
+  // loads of chunk c (W from global, A from LDS buffer c & 1) into register set c & 1 and runs the MFMAs of chunk c - 1 out
+  // of the other set, so neither the L2 latency of W nor the LDS latency of A sits between a barrier and the matrix pipe.
+  // The loop body is straight-line code (loads past the end are harmless: zero-filled / unused), which is what lets the
+  // compiler count outstanding loads exactly instead of draining them at every join.
+  bf16x8 av[2][2][WMB][T];   // [set][k-block][m-block][term]
+  u32x4 bw[2][2][WNB][T];    // [set][k-block][n-block][term]
+  auto fetch = [&](const int ch, auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
     const unsigned char* cur = xsm + (ch & 1) * BUF;
-    unsigned char* nxt = xsm + ((ch + 1) & 1) * BUF;
-    u32x4 bw[2][T];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int t = 0; t < T; ++t)
-        bw[kb][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bok ? (int)(woff0 + t * plane_w + (unsigned)(ch * 2 + kb) * 1024u) : (int)OOB_OFF, 0, 0);
-    if (ch + 1 < nchunks) {
-      store_chunk(nxt);                        // chunk ch + 1: in registers since the previous iteration
-      if (ch + 2 < nchunks) load_chunk();
-    }
+      for (int j = 0; j < WNB; ++j)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 av[T], bv[T];
+        for (int t = 0; t < T; ++t)
+          bw[S][kb][j][t] = __builtin_amdgcn_raw_buffer_load_b128(
+              rs_w, woff[j] == OOB_OFF ? (int)OOB_OFF : (int)(woff[j] + t * plane_w + (unsigned)(ch * 2 + kb) * 1024u), 0, 0);
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        av[t] = *reinterpret_cast<const bf16x8*>(cur + t * A_PLANE + (kb ? aoff1 : aoff0));
-        bv[t] = __builtin_bit_cast(bf16x8, bw[kb][t]);
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < WMB; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) av[S][kb][i][t] = *reinterpret_cast<const bf16x8*>(cur + t * A_PLANE + aoff[i][kb]);
+  };
+  auto multiply = [&](auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < WNB; ++j) {
+        bf16x8 bv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bv[t] = __builtin_bit_cast(bf16x8, bw[S][kb][j][t]);
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) {
+          const bf16x8(&a_)[T] = av[S][kb][i];
+          if (T == 3) {
+            floatx16& lo = TWO ? accl[TWO ? i : 0][TWO ? j : 0] : acc[i][j];
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], bv[2], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], bv[0], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], bv[1], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], bv[1], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], bv[0], lo, 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], bv[0], acc[i][j], 0, 0, 0);
+        }
       }
-      if (T == 3) {
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], accl, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc, 0, 0, 0);
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], accl, 0, 0, 0);
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], accl, 0, 0, 0);
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], accl, 0, 0, 0);
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], accl, 0, 0, 0);
-      } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc, 0, 0, 0);
-      }
-    }
-    __syncthreads();
+  };
+  // iteration c: fetch(c) -> set c & 1; MFMAs of chunk c - 1; split chunk c + 1 into the other LDS buffer; issue the loads of c + 2
+  auto iteration = [&](const int ch, auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
+    fetch(ch, set_tag);
+    multiply(std::integral_constant<int, S ^ 1>{});
+    store_chunk(xsm + ((ch + 1) & 1) * BUF);
+    load_chunk();
+    __syncthreads();                                 // (waits for this wave's LDS reads and writes first)
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  load_chunk();
+  store_chunk(xsm);
+  load_chunk();
+  __syncthreads();
+  fetch(0, Set0{});                                  // iteration 0 has no MFMAs
+  store_chunk(xsm + BUF);
+  load_chunk();
+  __syncthreads();
+  int ch = 1;
+  for (; ch + 1 < nchunks; ch += 2) {
+    iteration(ch, Set1{});
+    iteration(ch + 1, Set0{});
   }
-  if (T == 3) {
+  if (ch < nchunks) {
+    iteration(ch, Set1{});
+    multiply(Set1{});
+  } else {
+    multiply(Set0{});
+  }
+  if (TWO) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += accl[i];
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int j = 0; j < WNB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[TWO ? i : 0][TWO ? j : 0][r];
   }
 
-  // ---- epilogue (as conv_fwd_kernel): bias, activation, (pixel-shuffled) store, BN partial statistics ----
-  const int n = n0 + bcol;
-  const bool nvalid = n < a.Cout;
-  const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
-  float s = 0.f, ss = 0.f;
-  const int ohw = a.OH * a.OW;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    int m = m0 + wm * 32 + row;
-    if (m < M && nvalid) {
-      float raw = acc[r];
-      s += raw;
-      ss += raw * raw;
-      float v = apply_act(raw + bias, a.out_act);
-      if (!a.out_ps) {
-        a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
-      } else {
-        int nn = m / ohw;
-        int rem = m - nn * ohw;
-        int oh = rem / a.OW, ow = rem - oh * a.OW;
-        int cs = n >> 2, i = (n >> 1) & 1, j = n & 1;
-        a.out[((size_t)(nn * 2 * a.OH + 2 * oh + i) * (2 * a.OW) + 2 * ow + j) * (a.Cout >> 2) + cs] = v;
-      }
-    }
-  }
-  if (a.bn_partial) {   // statistics per 64-pixel row block (the layout bn_finalize expects): wave rows 2j, 2j+1 form block j
-    s += __shfl_xor(s, 32);
-    ss += __shfl_xor(ss, 32);
-    float* red = reinterpret_cast<float*>(xsm);     // [WROWS][2][64]; all LDS reads are behind the loop's last barrier
-    if (lane < 32) {
-      red[(wm * 2 + 0) * BN + bcol] = s;
-      red[(wm * 2 + 1) * BN + bcol] = ss;
-    }
-    __syncthreads();
-    constexpr int NBLK = BMT / 64;
-    if (tid < BN * NBLK) {
-      const int blk = tid / BN, c = tid - blk * BN;
-      const long long rb64 = (long long)mblk * NBLK + blk;
-      if (n0 + c < a.Cout && rb64 * 64 < M) {
-        float* dst = a.bn_partial + (size_t)rb64 * 2 * a.Cout;
-        dst[n0 + c] = red[((2 * blk) * 2 + 0) * BN + c] + red[((2 * blk + 1) * 2 + 0) * BN + c];
-        dst[a.Cout + n0 + c] = red[((2 * blk) * 2 + 1) * BN + c] + red[((2 * blk + 1) * 2 + 1) * BN + c];
-      }
-    }
-  }
+  xbf_epilogue<WMB, WNB>(a, acc, M, m0, n0, mblk, wm, wn, lane, tid, reinterpret_cast<float*>(xsm));
 }
 
 // loader variants instantiated for the bf16 path (the same set as the fp32 kernel)
 #define XBF_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7) X(8) X(17)
 
+// ------------------------------------------------------------------------------------------------------
+// forward / data-gradient of KH x KW > 1 x 1 convolutions: HALO kernel.
+//
+// What bounds the tile loop above on the trunk / recognizer shapes is not a pipe but memory latency and the A side's
+// instruction count: every tap re-loads the same input pixels from L2 / HBM (9x for a 3x3) and re-splits them into bf16 terms,
+// two loads per thread in flight for ~1 us each (measured: 1.0 us per K chunk at 3 workgroups / CU, plain-bf16 and x3 alike).
+// Here the K loop runs channel block (32) outermost, taps innermost, and the workgroup keeps the HALO of its 64 output pixels
+// -- every input pixel any tap touches, one 32-channel block at a time -- in LDS, split once:
+//   virtual padded index   q(n, r, s) = (n Hp + r) Wp + s,  Hp = OH + KH - 1, Wp = OW + KW - 1  (stride 1, zero padding virtual)
+//   output pixel m = (n, oh, ow) reads, for tap (kh, kw), entry  q(n, oh, ow) + kh Wp + kw      -- a constant offset per tap,
+//   so a tile of 64 consecutive m needs the contiguous range [q(m0), q(m_last) + (KH - 1) Wp + KW - 1]: L entries of
+//   32 channels x T bf16 terms (198 for a 3x3 on a 64-wide map; tiles may span rows and images, the padding rows between
+//   images are part of the index space).
+// Roles (8 waves): waves 4..7 PRODUCE -- load halo block c + 1 (one 16-byte load per entry quad, fused prologue, split, store
+// to LDS buffer (c + 1) & 1) -- while waves 0..3 run the KH KW x 2 MFMA steps of block c out of buffer c & 1, one barrier per
+// channel block.  Separate waves because the vector-memory counter is in-order per wave: a wave that streams W fragments
+// every step cannot also keep a 1-us halo load in flight.  Per 3x3 block: 7 loads + 7 splits per producer thread against 108
+// MFMAs per consumer wave (the tile loop: 18 + 18 against 108), and the input is read from L2 / HBM about 3x instead of 9x.
+// W as above: fragment-ordered planes in k' order straight into registers, one step ahead; A fragments: ds_read_b128 at
+// entry (q(m) - q(m0)) + tap offset, 64-byte entries with the 16-byte slot XOR-swizzled by (entry >> 2) & 3.
+// ------------------------------------------------------------------------------------------------------
+// diagnostic time line (tpgsr_halo_trace): wall-clock stamps (100 MHz) of the first 8 workgroups, [workgroup][8 wave rows][256 slots];
+// slot 4 j + k of item j -- producers: k = 0 loads issued, 1 split + stored, 2 past the barrier; consumers: k = 0 at the
+// barrier, 1 past it, 2 MFMAs issued, 3 tile stored (last item of a tile)
+__device__ unsigned long long* g_halo_trace = nullptr;
+#define HALO_STAMP(slot)                                                                                     \
+  do {                                                                                                       \
+    if (trace && lane == 0 && (slot) < 256)                                                                  \
+      __builtin_nontemporal_store((unsigned long long)wall_clock64(), trace + (blockIdx.x * 8 + wave) * 256 + (slot));                \
+  } while (0)
+
+template <int LD, int T, int NE>   // NE: halo entries per producer thread (capacity 32 NE entries)
+__global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a, int M, int Lcap) {
+  // PERSISTENT: the grid is what the chip holds at once (two workgroups per CU for the 3x3 x3 shapes); workgroup b runs
+  // tiles b, b + grid, ... and the producer / consumer pipeline below simply continues across tiles -- while the consumers
+  // finish tile i (last channel block, epilogue stores) the producers are already loading and splitting tile i + 1.
+  // 8 waves at <= 128 registers: two workgroups per CU.  (Tried and measured slower: 4 consumers + 2 producers at 168 registers
+  // with two accumulators per wave -- the second 6-wave workgroup no longer fits next to the first on a CU, 42.8 vs 30.6 us
+  // on the trunk convolution.)
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];   // [2 buffers][T][Lcap entries][64 B], then 2 x 1 KB `red`
+  const int PLANE = Lcap * 64, BUF = T * PLANE;
+  float* red_base = reinterpret_cast<float*>(hsm + 2 * BUF);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  typedef __attribute__((address_space(1))) unsigned long long* gptr_t;     // (a global, not a flat, store: a pending FLAT
+  const gptr_t trace = blockIdx.x < 8 ? (gptr_t)g_halo_trace : (gptr_t) nullptr;   //  access makes every later s_waitcnt a full drain)
+  const int nbn = (a.Cout + 63) >> 6;
+  const int ntiles = ((M + 63) >> 6) * nbn;
+  const int taps = a.KH * a.KW, NC = a.Cin >> 5;
+  const int Hp = a.OH + a.KH - 1, Wp = a.OW + a.KW - 1, ohw = a.OH * a.OW;
+  auto qbase = [&](int m) __attribute__((always_inline)) {
+    const int n = m / ohw, r = m - n * ohw, oh = r / a.OW;
+    return (n * Hp + oh) * Wp + (r - oh * a.OW);
+  };
+
+  if (wave >= 4) {
+    // ------------------------------- producers -------------------------------
+    const int pt = tid - 256, aq = pt & 7, er = pt >> 3;      // quad aq of entries er, er + 32, ...
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (size_t)a.N * a.H * a.W * a.in_ld);
+    const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
+    int hpix[NE];          // of the tile being LOADED; input pixel of entry 32 i + er: >= 0, -1 = padding (stored as zeros), -2 = not part of the halo
+    auto decode_tile = [&](const int t) __attribute__((always_inline)) {
+      const int mblk = xcd_remap(t, ntiles) / nbn;
+      const int m0 = mblk * 64;
+      const int q0 = qbase(m0);
+      const int L = qbase(min(m0 + 63, M - 1)) - q0 + (a.KH - 1) * Wp + a.KW;     // <= Lcap (host bound)
+      // entry 32 i + er <-> virtual padded position q0 + er + 32 i: decode the first, then walk in steps of 32 (Wp >= 8, checked
+      // by the launcher: at most four row wraps per step)
+      const int q = q0 + er;
+      int n = q / (Hp * Wp);
+      const int rem = q - n * (Hp * Wp);
+      int r = rem / Wp, sx = rem - r * Wp;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int ih = r - a.pad_h, iw = sx - a.pad_w;
+        const bool in = n < a.N && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        hpix[i] = 32 * i + er < L ? (in ? (n * a.H + ih) * a.W + iw : -1) : -2;
+        sx += 32;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const bool c1 = sx >= Wp;
+          sx -= c1 ? Wp : 0;
+          r += c1 ? 1 : 0;
+          const bool c2 = r >= Hp;
+          r -= c2 ? Hp : 0;
+          n += c2 ? 1 : 0;
+        }
+      }
+    };
+    // the loads of item j + 1 (next channel block, or block 0 of the next tile) are issued BEFORE item j is split and stored,
+    // so they are in flight while this wave sits in barrier j waiting for the consumers
+    constexpr bool DB = !(LD & 4);       // (the residual-add loader carries two quads per entry: one register set only)
+    ARaw hr[DB ? 2 : 1][NE];             // .raw carries "this entry is part of the halo" (store mask)
+    float4 qs[2], qt[2];
+    qs[0] = qs[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+    qt[0] = qt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_item = [&](auto set_tag, const int cc) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+      const int c = cc * 32 + aq * 4;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const bool ok = hpix[i] >= 0;
+        hr[S][i].ok = ok;
+        hr[S][i].raw = hpix[i] > -2;
+        hr[S][i].v = buf_load4(rs_in, ok ? ((unsigned)hpix[i] * (unsigned)a.in_ld + (unsigned)(a.in_coff + c)) * 4u : OOB_OFF);
+        if (LD & 4) hr[S][i].v2 = buf_load4(rs_in2, ok ? ((unsigned)hpix[i] * (unsigned)a.in2_ld + (unsigned)c) * 4u : OOB_OFF);
+      }
+      if (LD & 1) {
+        qs[S] = *reinterpret_cast<const float4*>(a.in_scale + c);
+        qt[S] = *reinterpret_cast<const float4*>(a.in_shift + c);
+      }
+    };
+    auto store_item = [&](auto set_tag, const int j) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+      unsigned char* buf = hsm + (j & 1) * BUF;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const bool part = hr[S][i].raw;
+        hr[S][i].raw = false;
+        const float4 v = finish_a<LD>(a, hr[S][i], qs[S], qt[S]);
+        uint2 h[T];
+        split4<T>(v, h);
+        const int e = 32 * i + er;
+        const int off = e * 64 + (((aq >> 1) ^ ((e >> 2) & 3)) << 4) + (aq & 1) * 8;
+        if (part) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) *reinterpret_cast<uint2*>(buf + t * PLANE + off) = h[t];
+        }
+      }
+    };
+    int t = blockIdx.x, cc = 0, j = 0;
+    using P0 = std::integral_constant<int, 0>;
+    using PN = std::integral_constant<int, DB ? 1 : 0>;
+    decode_tile(t);
+    if (DB) load_item(P0{}, 0);
+    // one item: (if double-buffered) issue the next item's loads, split + store this one, barrier; returns false after the last
+    auto item = [&](auto cur_tag, auto nxt_tag) __attribute__((always_inline)) -> bool {
+      int ncc = cc + 1, nt = t;
+      if (ncc == NC) {
+        ncc = 0;
+        nt = t + gridDim.x;
+      }
+      const bool more = nt < ntiles;
+      if (!DB) load_item(cur_tag, cc);
+      if (more && ncc == 0) decode_tile(nt);       // (this item's entries are already captured in its register set)
+      if (DB && more) load_item(nxt_tag, ncc);
+      HALO_STAMP(4 * j);
+      store_item(cur_tag, j);
+      HALO_STAMP(4 * j + 1);
+      __syncthreads();      // barrier j: item j is in LDS, and the consumers are done with item j - 1
+      HALO_STAMP(4 * j + 2);
+      ++j;
+      t = nt;
+      cc = ncc;
+      return more;
+    };
+    while (true) {
+      if (!item(P0{}, PN{})) break;
+      if (!item(PN{}, P0{})) break;
+    }
+    __syncthreads();        // the final barrier (the consumers' last statistics flush)
+    return;
+  }
+
+  // ------------------------------- consumers -------------------------------
+  const int wm = wave & 1, wn = wave >> 1;
+  const int wrows = a.wt_ld > 0 ? a.wt_ld : a.Cout;
+  const int NB32 = (wrows + 31) >> 5, KB16 = a.kp >> 4;
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const float*>(a.wt_bf), (size_t)T * NB32 * 32 * a.kp / 2);
+  const unsigned plane_w = (unsigned)NB32 * KB16 * 1024u;
+  const int g = lane >> 5;
+  unsigned woff = 0;
+  int ebase = 0;
+
+  floatx16 acc[1][1];       // ONE accumulator (correction terms first, then a1 b1, every step): the register budget is 128
+  // W fragments run one TAP (two 16-k steps = 12 MFMAs = 384 cycles) ahead of the matrix pipe, in two register sets indexed
+  // by tap parity; A fragments are fetched as soon as the MFMAs reading their registers have been issued (one step ahead).
+  bf16x8 av[2][T];          // [k-block][term]
+  u32x4 bw[2][2][T];        // [set][k-block][term]
+  int gtap = 0;             // tap counter of the tile = (channel block, tap) in k' order; its W k-blocks are 2 gtap, 2 gtap + 1
+  auto fetch_w = [&](auto set_tag, auto kb_tag, const int tapidx) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value, KB = decltype(kb_tag)::value;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      bw[S][KB][t] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_w, woff == OOB_OFF ? (int)OOB_OFF : (int)(woff + t * plane_w + (unsigned)(2 * tapidx + KB) * 1024u), 0, 0);
+  };
+  auto fetch_a = [&](auto kb_tag, const unsigned char* buf, const int tapoff) __attribute__((always_inline)) {
+    constexpr int KB = decltype(kb_tag)::value;
+    const int e = ebase + tapoff;
+    const int off = e * 64 + (((KB * 2 + g) ^ ((e >> 2) & 3)) << 4);
+#pragma unroll
+    for (int t = 0; t < T; ++t) av[KB][t] = *reinterpret_cast<const bf16x8*>(buf + t * PLANE + off);
+  };
+  auto multiply = [&](auto set_tag, auto kb_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value, KB = decltype(kb_tag)::value;
+    bf16x8 bv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) bv[t] = __builtin_bit_cast(bf16x8, bw[S][KB][t]);
+    acc[0][0] = mfma_terms<T>(av[KB], bv, acc[0][0]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  int kw = 0, tapoff = 0;
+  auto next_tap = [&]() __attribute__((always_inline)) {
+    const bool cw = ++kw == a.KW;
+    tapoff += cw ? Wp - a.KW + 1 : 1;
+    kw = cw ? 0 : kw;
+  };
+  // one tap out of W set S; NEXT: another tap of this channel block follows (prefetch its A fragments).
+  // The sched_barriers pin the software pipeline: without them the machine scheduler sinks the prefetches down to their first
+  // use (measured: s_waitcnt vmcnt(0) at the loop head, 115 cycles per MFMA and wave instead of 32 -- every tap waited out L2).
+  auto tap = [&](auto set_tag, auto next_tag, const unsigned char* buf) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value;
+    constexpr bool NEXT = decltype(next_tag)::value != 0;
+    fetch_w(std::integral_constant<int, S ^ 1>{}, I0{}, gtap + 1);
+    fetch_w(std::integral_constant<int, S ^ 1>{}, I1{}, gtap + 1);
+    if (NEXT) next_tap();
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(set_tag, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (NEXT) fetch_a(I0{}, buf, tapoff);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(set_tag, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (NEXT) fetch_a(I1{}, buf, tapoff);
+    __builtin_amdgcn_sched_barrier(0);
+    ++gtap;
+  };
+  // last tap of a block with an ODD tap count: the next block starts on set 0 again, which this tap is still reading --
+  // its W prefetch goes into each half of set 0 as soon as the MFMAs reading that half have been issued
+  auto tap_last_odd = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_w(I0{}, I0{}, gtap + 1);
+    multiply(I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_w(I0{}, I1{}, gtap + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    ++gtap;
+  };
+  int j = 0, pend_mblk = -1, pend_n0 = 0, ntile_done = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tile = xcd_remap(t, ntiles);
+    const int mblk = tile / nbn;
+    const int m0 = mblk * 64, n0 = (tile - mblk * nbn) * 64;
+    const int q0 = qbase(m0);
+    const int ncol0 = n0 + wn * 32;
+    woff = ncol0 < a.Cout ? ((unsigned)((a.wt_coff + ncol0) >> 5) * KB16) * 1024u + lane * 16u : OOB_OFF;
+    ebase = qbase(min(m0 + wm * 32 + (lane & 31), M - 1)) - q0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    gtap = 0;
+    fetch_w(I0{}, I0{}, 0);
+    fetch_w(I0{}, I1{}, 0);
+    for (int cc = 0; cc < NC; ++cc, ++j) {
+      HALO_STAMP(4 * j);
+      __syncthreads();        // barrier j
+      HALO_STAMP(4 * j + 1);
+      if (pend_mblk >= 0) {   // the previous tile's BN statistics: its wave rows' partials are behind a barrier now
+        xbf_bn_flush<1, 1>(a, M, pend_n0, pend_mblk, tid, red_base + ((ntile_done - 1) & 1) * 256);
+        pend_mblk = -1;
+      }
+      const unsigned char* buf = hsm + (j & 1) * BUF;
+      kw = 0;
+      tapoff = 0;
+      fetch_a(I0{}, buf, 0);
+      fetch_a(I1{}, buf, 0);
+      int tp = 0;
+      for (; tp + 2 < taps; tp += 2) {     // straight-line body: the compiler counts the outstanding W loads exactly
+        tap(I0{}, I1{}, buf);
+        tap(I1{}, I1{}, buf);
+      }
+      if (taps - tp == 2) {
+        tap(I0{}, I1{}, buf);
+        tap(I1{}, I0{}, buf);
+      } else {
+        tap_last_odd();
+      }
+      HALO_STAMP(4 * j + 2);
+    }
+    xbf_store_tile<1, 1>(a, acc, M, m0, n0, wm, wn, lane, red_base + (ntile_done & 1) * 256);
+    HALO_STAMP(4 * (j - 1) + 3);
+    if (a.bn_partial) {
+      pend_mblk = mblk;
+      pend_n0 = n0;
+    }
+    ++ntile_done;
+  }
+  __syncthreads();            // the final barrier
+  if (pend_mblk >= 0) xbf_bn_flush<1, 1>(a, M, pend_n0, pend_mblk, tid, red_base + ((ntile_done - 1) & 1) * 256);
+}
+
+extern "C" int tpgsr_halo_trace(unsigned long long* buf) {   // buf: 8 * 8 * 256 uint64 of device memory, or nullptr to switch off
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_halo_trace), &buf, sizeof(buf)) != hipSuccess) {
+    tpgsr_set_error("tpgsr_halo_trace: hipMemcpyToSymbol failed");
+    return TPGSR_ERR_LAUNCH;
+  }
+  return 0;
+}
+
+// upper bound of the halo length of any 64-pixel tile (see the kernel's header)
+static int halo_capacity(const tpgsr_conv_args* a) {
+  const int Wp = a->OW + a->KW - 1, ohw = a->OH * a->OW;
+  const int row_wraps = (a->OW % 64 == 0) ? 0 : 63 / a->OW + 1;
+  const int img_wraps = (ohw % 64 == 0) ? 0 : 63 / ohw + 1;
+  return 63 + row_wraps * (a->KW - 1) + img_wraps * (a->KH - 1) * Wp + (a->KH - 1) * Wp + a->KW;
+}
+
+#define XBF_HALO_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
+
+// returns 1 when launched, 0 when the shape is not one of the halo kernel's, < 0 on error
+static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("TPGSR_XBF_HALO"); return !(e && e[0] == '0'); }();
+  const int T = a->terms;
+  if (!on || a->KH * a->KW < 2 || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_ps ||
+      a->in_b || (ld & ~7) || ld == 6 || a->OW + a->KW - 1 < 8)
+    return 0;
+  const int Lcap = halo_capacity(a);
+  const size_t lds = (size_t)2 * T * Lcap * 64 + 2048;      // two halo buffers + two 1 KB statistics scratch areas
+  // two workgroups per CU or not at all: with one, nothing covers a workgroup's barriers and epilogues (the 16x50 recognizer
+  // conv, 278 halo entries = 107 KB in x3 mode, measured 54 us here against 47 us on the tile loop)
+  if (Lcap > 32 * 9 || lds > 80 * 1024) return 0;
+  const bool small = Lcap <= 32 * 7;
+  const void* fn = nullptr;
+#define XBF_HALO_CASE(B)                                                                                                      \
+  case B:                                                                                                                     \
+    fn = T == 1 ? (small ? (const void*)conv_halo_xbf_kernel<B, 1, 7> : (const void*)conv_halo_xbf_kernel<B, 1, 9>)           \
+                : (small ? (const void*)conv_halo_xbf_kernel<B, 3, 7> : (const void*)conv_halo_xbf_kernel<B, 3, 9>);          \
+    break;
+  switch (ld) {
+    XBF_HALO_LD_CASES(XBF_HALO_CASE)
+    default: return 0;
+  }
+#undef XBF_HALO_CASE
+  if (lds > 64 * 1024) {   // opt-in to > 64 KB of dynamic LDS, per (kernel, device): raised to the largest size seen so far
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void*, int>, size_t>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+      tpgsr_set_error("tpgsr_conv_fwd: hipGetDevice failed");
+      return TPGSR_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    size_t* cur = nullptr;
+    for (auto& d : done)
+      if (d.first.first == fn && d.first.second == dev) cur = &d.second;
+    if (!cur || *cur < lds) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        tpgsr_set_error("tpgsr_conv_fwd: LDS opt-in (%zu bytes) for the halo kernel failed", lds);
+        return TPGSR_ERR_LAUNCH;
+      }
+      if (cur) *cur = lds; else done.push_back({{fn, dev}, lds});
+    }
+  }
+  // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs), cached per (kernel, LDS size, device)
+  struct Occ { const void* fn; size_t lds; int dev, wgs; };
+  static std::mutex omu;
+  static std::vector<Occ> occ;
+  int resident = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+      tpgsr_set_error("tpgsr_conv_fwd: hipGetDevice failed");
+      return TPGSR_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(omu);
+    for (auto& o : occ)
+      if (o.fn == fn && o.lds == lds && o.dev == dev) resident = o.wgs;
+    if (!resident) {
+      int per_cu = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds) != hipSuccess || per_cu < 1 ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        tpgsr_set_error("tpgsr_conv_fwd: occupancy query for the halo kernel failed (LDS %zu bytes)", lds);
+        return TPGSR_ERR_LAUNCH;
+      }
+      resident = per_cu * cus;
+      occ.push_back({fn, lds, dev, resident});
+      static const bool dbg = [] { const char* e = getenv("TPGSR_XBF_DEBUG"); return e && e[0] == '1'; }();
+      if (dbg)
+        fprintf(stderr, "[tpgsr] halo conv: Cin %d Cout %d %dx%d ld %d T %d Lcap %d lds %zu -> %d workgroups/CU x %d CUs\n", a->Cin, a->Cout,
+                a->KH, a->KW, ld, T, Lcap, lds, per_cu, cus);
+    }
+  }
+  const long long ntiles = (long long)cdiv(M, 64) * cdiv(a->Cout, 64);
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+  int Mi = (int)M, Lc = Lcap;
+  tpgsr_conv_args args = *a;
+  void* params[] = {&args, &Mi, &Lc};
+  if (hipLaunchKernel(fn, grid, dim3(512), params, lds, st) != hipSuccess) {
+    tpgsr_set_error("tpgsr_conv_fwd(halo): launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return TPGSR_ERR_LAUNCH;
+  }
+  return 1;
+}
+
+// wave-tile choice of the tile loop (WMB x 1 blocks of 32 x 32 per wave; workgroup tile 64 WMB x 64).  TPGSR_XBF_TILE=11|21 forces one.
+static int xbf_fwd_tile(long long M, int Cout) {
+  static const int force = [] { const char* e = getenv("TPGSR_XBF_TILE"); return e ? atoi(e) : 0; }();
+  if (force == 11 || force == 21) return force;
+  return 11;
+}
+
 extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, int K, int ld, hipStream_t st) {
   const int T = a->terms;
-  // tile height: 64 pixels.  The 128-pixel variant (TPGSR_XBF_TILE=128) measured equal or slower on every layer shape of
-  // the TSRN / CRNN step at batch 48 (profiles/r02_conv_prec_tiles.md): fewer, fatter workgroups lose more to the tail than
-  // the halved W traffic wins; it is kept for larger problems.
-  static const int force = [] { const char* e = getenv("TPGSR_XBF_TILE"); return e ? atoi(e) : 0; }();
-  const bool big = force == 128;
-  dim3 grid(cdiv(M, big ? 128 : 64) * cdiv(a->Cout, BN));
-#define XBF_FWD_CASE(B)                                                                                          \
-  case B:                                                                                                        \
-    if (T == 1) {                                                                                                \
-      if (big) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 1, 128>), grid, dim3(512), 0, st, *a, (int)M, K);      \
-      else hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 1, 64>), grid, dim3(256), 0, st, *a, (int)M, K);           \
-    } else {                                                                                                     \
-      if (big) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 3, 128>), grid, dim3(512), 0, st, *a, (int)M, K);      \
-      else hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 3, 64>), grid, dim3(256), 0, st, *a, (int)M, K);           \
-    }                                                                                                            \
+  TPGSR_CHECK_ARG(a->wt_bf_cin == 0 || (a->wt_bf_cin == a->Cin && (a->Cin & 31) == 0),
+                  "tpgsr_conv_fwd: weights were split in channel-block order for Cin %d, the convolution has Cin %d", a->wt_bf_cin, a->Cin);
+  const int h = conv_halo_xbf_launch(a, M, ld, st);
+  if (h < 0) return h;
+  if (h > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA, halo)");
+  const int cfg = xbf_fwd_tile(M, a->Cout);
+  const int wmb = cfg / 10;
+  dim3 grid(cdiv(M, 64 * wmb) * cdiv(a->Cout, 64));
+#define XBF_FWD_T(B, TT)                                                                                                    \
+  switch (cfg) {                                                                                                            \
+    case 21: hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, TT, 2, 1>), grid, dim3(256), 0, st, *a, (int)M, K); break;          \
+    default: hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, TT, 1, 1>), grid, dim3(256), 0, st, *a, (int)M, K); break;          \
+  }
+#define XBF_FWD_CASE(B)                  \
+  case B:                                \
+    if (T == 1) { XBF_FWD_T(B, 1) }      \
+    else { XBF_FWD_T(B, 3) }             \
     break;
   switch (ld) {
     XBF_LD_CASES(XBF_FWD_CASE)
@@ -275,6 +795,7 @@ extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, 
       return TPGSR_ERR_ARG;
   }
 #undef XBF_FWD_CASE
+#undef XBF_FWD_T
   TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA)");
 }
 
@@ -481,7 +1002,11 @@ __global__ __launch_bounds__(256) void split_bf_program_kernel(const tpgsr_split
     const int n = threadIdx.x & 63, kr = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int k = k0 + kr * 16 + i;
+      int k = k0 + kr * 16 + i;                      // destination k (k' order when d.cin > 0)
+      if (d.cin > 0 && k < d.K) {
+        const int taps = d.K / d.cin, cc = k / (taps * 32), rem = k - cc * taps * 32;
+        k = (rem >> 5) * d.cin + cc * 32 + (rem & 31);
+      }
       tile[kr * 16 + i][n] = (k < d.K && n0 + n < d.N) ? d.src[(size_t)k * d.ld + n0 + n] : 0.f;
     }
   }

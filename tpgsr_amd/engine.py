@@ -184,7 +184,7 @@ class ConvLayer:
         else:
             eng.add_pack(self.w, self.wt_f, self.wt_d, Cout=self.Cout, Cin=self.Cin, KH=KH, KW=KW, kind=0,
                          f_ld=self.Cout, wscale=wscale)
-        eng.register_operand(self.wt_f, self.wt_d)
+        eng.register_operand(self.wt_f, self.wt_d, cins=(self.Cin, self.Cout))
 
     def geom(self, N, H, W) -> ConvGeom:
         return ConvGeom(N, H, W, self.Cin, self.Cout, self.KH, self.KW, self.pad_h, self.pad_w)
@@ -477,12 +477,15 @@ class _EngineBase:
                  numel=None, d_ld=0, cin_ld=0):
         self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld))
 
-    def register_operand(self, *tensors):
-        """fp32 MFMA operands [K][ld] packed by the pack program: get a bf16 split twin when the bf16 matrix-core path is on"""
-        for t in tensors:
+    def register_operand(self, *tensors, cins=None):
+        """fp32 MFMA operands [K][ld] packed by the pack program: get a bf16 split twin when the bf16 matrix-core path is on.
+        cins: per tensor, the input-channel count of the convolution consuming it (multi-tap operands over a multiple of 32
+        channels are split in channel-block order, which is what the halo kernel reads)"""
+        for i, t in enumerate(tensors):
             if t is not None:
                 assert t.dim() == 2 and t.is_contiguous()
                 self._operands.append(t)
+                t._tpgsr_cin = K.block_order_cin(t.shape[0], cins[i] if cins else 0)
 
     def _finish_split_table(self):
         from ._lib import SplitDesc, load
@@ -502,8 +505,9 @@ class _EngineBase:
             Kd, N = t.shape
             kp = (Kd + 31) // 32 * 32
             twin = torch.zeros(3 * ((N + 31) // 32 * 32) * kp, dtype=torch.bfloat16, device=self.device)
-            K.register_bf_twin(t, twin, kp)
-            d.src, d.dst, d.K, d.N, d.ld, d.kp, d.blk0 = t.data_ptr(), twin.data_ptr(), Kd, N, N, kp, blk
+            cin = getattr(t, "_tpgsr_cin", 0)
+            K.register_bf_twin(t, twin, kp, cin)
+            d.src, d.dst, d.K, d.N, d.ld, d.kp, d.blk0, d.cin = t.data_ptr(), twin.data_ptr(), Kd, N, N, kp, blk, cin
             blk += lib.tpgsr_split_bf_blocks(Kd, N)
             self._split_keep += [t, twin]
         self._split_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)

@@ -95,8 +95,8 @@ def _pack(w, transposed, wscale):
     wt_d = torch.empty(KH * KW * Cout, Cin, dtype=F32, device=w.device)
     K.pack_conv_weight(_c(w), Cout, Cin, KH, KW, wt_f, wt_d, transposed=transposed, wscale=wscale)
     if K.CONV_TERMS:
-        K.make_bf_twin(wt_f)
-        K.make_bf_twin(wt_d)
+        K.make_bf_twin(wt_f, Cin)
+        K.make_bf_twin(wt_d, Cout)
     return wt_f, wt_d, Cout, Cin, KH, KW
 
 

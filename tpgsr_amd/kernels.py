@@ -71,8 +71,14 @@ class conv_terms:
         return False
 
 
-def register_bf_twin(wt: torch.Tensor, twin: torch.Tensor, kp: int):
-    wt._tpgsr_twin = (twin, kp)
+def register_bf_twin(wt: torch.Tensor, twin: torch.Tensor, kp: int, cin: int = 0):
+    wt._tpgsr_twin = (twin, kp, cin)
+
+
+def block_order_cin(Kd: int, cin: int) -> int:
+    """the `cin` a packed [K = taps * cin][N] operand is split with: cin (rows in channel-block order, the halo kernel's) when
+    it is a multi-tap operand over a multiple of 32 channels, else 0 (natural order)"""
+    return cin if (cin and cin % 32 == 0 and Kd % cin == 0 and Kd // cin > 1) else 0
 
 
 class _DummyStream:
@@ -420,7 +426,8 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
         else:
             tw = getattr(wt, "_tpgsr_twin", None)
             if tw is not None:
-                a.terms, a.kp, a.wt_bf = CONV_TERMS, tw[1], tw[0].data_ptr()
+                a.terms, a.kp, a.wt_bf, a.wt_bf_cin = CONV_TERMS, tw[1], tw[0].data_ptr(), tw[2]
+                assert tw[2] in (0, g.Cin), f"operand split for Cin {tw[2]}, used by a convolution over {g.Cin} channels"
                 if _REC is not None:
                     _REC.keep.append(tw[0])
     return a
@@ -739,18 +746,20 @@ def semantic_loss_bwd(p, q, dloss, n, dp):
     _launch("tpgsr_semantic_loss_bwd", _p(p), _p(q), _p(dloss), n, _p(dp))
 
 
-def make_bf_twin(wt: torch.Tensor):
+def make_bf_twin(wt: torch.Tensor, cin: int = 0):
     """split ONE packed fp32 operand [K][ld] into its bf16 planes now (single-op callers / tests; the engines batch all their
-    operands into one tpgsr_split_bf_program launch per step)"""
+    operands into one tpgsr_split_bf_program launch per step).  cin: input channels of the convolution that will consume it
+    (rows go in channel-block order when block_order_cin says so)"""
     lib = _lib.load()
     Kd, N = wt.shape
+    cin = block_order_cin(Kd, cin)
     kp = (Kd + 31) // 32 * 32
     twin = torch.zeros(3 * ((N + 31) // 32 * 32) * kp, dtype=torch.bfloat16, device=wt.device)
     d = (_lib.SplitDesc * 1)()
-    d[0].src, d[0].dst, d[0].K, d[0].N, d[0].ld, d[0].kp, d[0].blk0 = wt.data_ptr(), twin.data_ptr(), Kd, N, N, kp, 0
+    d[0].src, d[0].dst, d[0].K, d[0].N, d[0].ld, d[0].kp, d[0].blk0, d[0].cin = wt.data_ptr(), twin.data_ptr(), Kd, N, N, kp, 0, cin
     table = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(wt.device)
     split_bf_program(table, 1, lib.tpgsr_split_bf_blocks(Kd, N))
-    register_bf_twin(wt, twin, kp)
+    register_bf_twin(wt, twin, kp, cin)
     return twin, kp
 
 
