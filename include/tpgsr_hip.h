@@ -100,9 +100,19 @@ typedef struct {
   int dy_ps;              /* 1: dy stored pixel-shuffled [N][2OH][2OW][Cout/4] */
   float* part;            /* [Z][K][Cout] */
   float* dbpart;          /* optional [Z][Cout] */
+  int zsplits;            /* 0: Z = tpgsr_wgrad_splits(M, K, Cout).  > 0: the caller sized part / dbpart for exactly this many pixel
+                             splits (every kernel honours it); tpgsr_wgrad_halo_plan proposes the count the halo kernel wants */
+  int reserved1;
+  void* dy_bf;            /* optional scratch of tpgsr_wgrad_halo_plan's dy_bf_bytes: dy pre-split into bf16 fragment planes
+                             [3][ceil(M/16)][ceil(Cout/32)][64 lanes][8].  With zsplits > 0, terms > 0 and a KH x KW > 1 x 1
+                             stride-1 convolution over a multiple of 32 channels, the weight gradient runs on the halo kernel
+                             (csrc/conv_xbf.hip); anything else stays on the tile loop. */
 } tpgsr_wgrad_args;
 
 int tpgsr_wgrad_splits(int M, int K, int Cout);
+/* 1 + (*zsplits, *dy_bf_bytes) when the geometry (and a->terms > 0) suits the halo weight-gradient kernel, else 0.
+ * Only N, H, W, Cin, Cout, KH, KW, pads, OH, OW, terms and the loader-shape fields of `a` are read. */
+int tpgsr_wgrad_halo_plan(const tpgsr_conv_args* a, int* zsplits, long long* dy_bf_bytes);
 int tpgsr_conv_wgrad(const tpgsr_wgrad_args* a, void* stream);
 
 /* Deterministic second stage: dw (+)= sum_z part[z], written in the PyTorch parameter layout

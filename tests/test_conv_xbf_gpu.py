@@ -16,6 +16,10 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+# the halo weight-gradient kernel is switched on from 128 input channels up (a performance heuristic, read once per process);
+# this module drives it at 32 and 64 channels as well
+os.environ.setdefault("TPGSR_XBF_WGRAD_HALO_MINC", "32")
+
 from oracle import tpgsr_oracle as O  # noqa: E402
 
 DEV = "cuda"
@@ -367,3 +371,103 @@ def test_halo_kernel_matches_tile_loop():
     err = ((outs[0] - outs[1]).abs().max() / outs[1].abs().max()).item()
     print(f"halo vs tile loop: {err:.2e}")
     assert err < 2e-6
+
+
+
+def _halo_wgrad_case(N, H, W, Ci, Co, KH, KW, ph, pw, *, affine=False, act=False, resid=False, dy_ps=False, seed=0):
+    """weight / bias gradient through the halo weight-gradient kernel (split count from the geometry-aware plan) vs fp64 autograd"""
+    k = K()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    x2 = torch.randn(N, Ci, H, W, generator=g) if resid else None
+    sc = torch.rand(Ci, generator=g) + 0.5 if affine else None
+    sh = torch.randn(Ci, generator=g) * 0.3 if affine else None
+    w = (torch.randn(Co, Ci, KH, KW, generator=g) / math.sqrt(Ci * KH * KW)).double().requires_grad_(True)
+    b = torch.randn(Co, generator=g).double().requires_grad_(True)
+    a = x.double()
+    if affine:
+        a = a * sc.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double()
+    if act:
+        a = a * torch.tanh(F.softplus(a))
+    if resid:
+        a = a + x2.double()
+    y = F.conv2d(a, w, b, padding=(ph, pw))
+    if dy_ps:
+        y = F.pixel_shuffle(y, 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    geom = k.ConvGeom(N, H, W, Ci, Co, KH, KW, ph, pw)
+    assert k.wgrad_halo_plan(geom) is not None, "shape not taken by the halo weight-gradient kernel"
+    Z = k.wgrad_splits(geom.M, geom.K, Co, geom=geom)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().to(DEV)
+    part = torch.full((Z, geom.K, Co), float("nan"), device=DEV)
+    dbp = torch.full((Z, Co), float("nan"), device=DEV)
+    keep = [nhwc(x), nhwc(x2) if resid else None, sc.to(DEV) if affine else None, sh.to(DEV) if affine else None, nhwc(dy)]
+    ca = k.make_conv_args(geom, keep[0], in2=keep[1], in_scale=keep[2], in_shift=keep[3], in_act="mish" if act else None)
+    wa = k.make_wgrad_args(ca, keep[4], part, dbp, dy_ps=dy_ps, zsplits=Z)
+    assert wa.dy_bf, "no scratch attached: the launch would stay on the tile loop"
+    k.conv_wgrad(wa)
+    dw = torch.zeros(Co, Ci, KH, KW, device=DEV)
+    db = torch.zeros(Co, device=DEV)
+    k.wgrad_reduce(part, dbp, Z, geom, dw, db, accumulate=False)
+    torch.cuda.synchronize()
+    e_w = ((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()).item()
+    e_b = ((db.cpu().double() - b.grad).abs().max() / b.grad.abs().max()).item()
+    return e_w, e_b, Z
+
+
+HALO_WGRAD_SHAPES = [
+    (48, 16, 64, 64, 64, 3, 3, 1, 1),      # trunk: 128 splits x 2 channel blocks, 6 tiles per workgroup
+    (48, 16, 64, 64, 256, 3, 3, 1, 1),     # upsample conv: 4 column tiles
+    (5, 8, 25, 128, 96, 3, 3, 1, 1),       # tiles span rows and images; Cout not a multiple of 64
+    (7, 4, 26, 64, 40, 3, 3, 1, 1),        # Cout 40: a half-empty 32-column block; ragged last tile
+    (3, 2, 27, 96, 64, 2, 2, 0, 0),        # 2x2 valid conv: one tap per tap group
+    (2, 16, 50, 64, 128, 3, 3, 1, 1),      # 278-entry halo (9 entries per producer thread)
+    (2, 6, 10, 32, 8, 3, 3, 1, 1),         # narrow map, one channel block, Cout 8
+    (2, 12, 20, 32, 64, 3, 4, 1, 2),       # 12 taps: three per tap group, even kernel width
+]
+
+
+@pytest.mark.parametrize("shape", HALO_WGRAD_SHAPES)
+def test_halo_wgrad_shapes(shape):
+    e_w, e_b, Z = _halo_wgrad_case(*shape, seed=21)
+    print(f"halo wgrad {shape}: Z {Z}  dW {e_w:.2e}  db {e_b:.2e}")
+    assert e_w < 5e-6 and e_b < 5e-6
+
+
+@pytest.mark.parametrize("affine,act,resid", [(True, False, False), (False, True, False), (True, True, False), (False, False, True),
+                                               (True, True, True)])
+def test_halo_wgrad_prologues(affine, act, resid):
+    e_w, e_b, Z = _halo_wgrad_case(12, 16, 64, 64, 64, 3, 3, 1, 1, affine=affine, act=act, resid=resid, seed=8)
+    print(f"halo wgrad prologue affine={affine} act={act} resid={resid}: dW {e_w:.2e}  db {e_b:.2e}")
+    assert e_w < 5e-6 and e_b < 5e-6
+
+
+def test_halo_wgrad_pixel_shuffled_dy():
+    """dy handed over in the pixel-shuffled layout of the upsample block (the pre-split gathers it)"""
+    e_w, e_b, Z = _halo_wgrad_case(6, 16, 64, 64, 256, 3, 3, 1, 1, dy_ps=True, seed=4)
+    print(f"halo wgrad dy_ps: dW {e_w:.2e}  db {e_b:.2e}")
+    assert e_w < 5e-6 and e_b < 5e-6
+
+
+def test_wgrad_explicit_split_count_on_tile_loop():
+    """zsplits is honoured by the tile-loop kernels too (a geometry the halo kernel rejects: 1x1)"""
+    k = K()
+    g = torch.Generator().manual_seed(6)
+    N, H, W, Ci, Co = 3, 8, 20, 64, 48
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    geom = k.ConvGeom(N, H, W, Ci, Co, 1, 1, 0, 0)
+    assert k.wgrad_halo_plan(geom) is None
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().to(DEV)
+    for Z in (1, 3, 7):
+        part = torch.full((Z, geom.K, Co), float("nan"), device=DEV)
+        xd, dyd = nhwc(x), nhwc(dy)
+        k.conv_wgrad(k.make_wgrad_args(k.make_conv_args(geom, xd), dyd, part, None, zsplits=Z))
+        dw = torch.zeros(Co, Ci, 1, 1, device=DEV)
+        k.wgrad_reduce(part, None, Z, geom, dw, None, accumulate=False)
+        torch.cuda.synchronize()
+        assert ((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()).item() < 5e-6, Z

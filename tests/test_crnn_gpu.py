@@ -224,16 +224,27 @@ def test_crnn_gradients_vs_oracle():
     (yd * gl.to(DEV)).sum().backward()
     assert (yd.detach().cpu() - y.detach()).abs().max() < 1e-4
     gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
-    bad = []
+    # Two tiers.  Everything ABOVE the last max-pool (conv6, both BiLSTMs) must agree at the fp32 level.  BELOW a pool the
+    # gradient is a discontinuous function of the forward values: one pooling window whose two largest inputs differ by less than
+    # the forward's fp32 rounding noise picks the other position in one of the two implementations, which reroutes that window's
+    # whole gradient (tools/lab/xbf_diverge.py shows it: with identical arithmetic the same layers agree to 1e-6, and changing
+    # only the accumulation ORDER of a conv -- fp32 matrix cores vs split bf16, tile loop vs halo kernel -- moves the figure
+    # between 3e-3 and 9e-3 on this 3-image batch).  Those layers get the looser bound; the full-size tests (test_fullsize_gpu.py)
+    # hold the training-step gates that matter (loss, gradient norm, PSNR, arg-max priors).
+    above = ("cnn.conv6", "cnn.batchnorm6", "rnn.")          # the last pool follows conv5
+    bad, worst_above, worst_below = [], 0.0, 0.0
     for n, q in net.named_parameters():
         ref = p[n].grad
         rel = (q.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-3 * gmax)
-        if rel > 3e-3 * NOISE:
+        top = n.startswith(above)
+        worst_above, worst_below = (max(worst_above, rel), worst_below) if top else (worst_above, max(worst_below, rel))
+        if rel > (3e-3 if top else 2e-2):
             bad.append((n, rel))
+    print(f"crnn grads: worst above the last pool {worst_above:.2e}, below {worst_below:.2e}")
     assert not bad, bad[:10]
     rel = (gd.grad.cpu() - gr.grad).norm().item() / gr.grad.norm().item()
     print("dgray rel err", rel)
-    assert rel < 3e-3 * NOISE
+    assert rel < 2e-2
 
 
 def _c3_models(seeds=(301, 302, 303), stn=True, n_sr=1, n_stu=1):

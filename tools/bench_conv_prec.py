@@ -38,14 +38,15 @@ def case(name, N, Hh, Ww, Ci, Co, KH, KW, ph, pw):
     out = torch.empty(g.M, Co, device=DEV)
     b = torch.randn(Co, device=DEV)
     dy = torch.randn(g.M, Co, device=DEV)
-    Z = K.wgrad_splits(g.M, g.K, Co)
-    part = torch.empty(Z, g.K, Co, device=DEV)
     K.make_bf_twin(wf, Ci)
-    fa, wa = [], []
+    fa, wa, keep = [], [], []
     for prec in ("f32", "x3", "bf16"):
         K.set_conv_prec(prec)
         fa.append(K.make_conv_args(g, x, wf, out, bias=b))
-        wa.append(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, None))
+        Z = K.wgrad_splits(g.M, g.K, Co, geom=g)          # (the halo weight-gradient kernel's own split count where it applies)
+        part = torch.empty(Z, g.K, Co, device=DEV)
+        keep.append(part)
+        wa.append(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, None, zsplits=Z))
     K.set_conv_prec("f32")
     tf = time_fns([lambda a=a: K.conv_fwd(a) for a in fa])
     tw = time_fns([lambda a=a: K.conv_wgrad(a) for a in wa])

@@ -34,7 +34,8 @@ class ConvArgs(C.Structure):
 
 
 class WgradArgs(C.Structure):
-    _fields_ = [("c", ConvArgs), ("dy", vp), ("dy_ld", ci), ("dy_coff", ci), ("dy_ps", ci), ("part", vp), ("dbpart", vp)]
+    _fields_ = [("c", ConvArgs), ("dy", vp), ("dy_ld", ci), ("dy_coff", ci), ("dy_ps", ci), ("part", vp), ("dbpart", vp),
+                ("zsplits", ci), ("reserved1", ci), ("dy_bf", vp)]
 
 
 class PackDesc(C.Structure):
@@ -87,6 +88,7 @@ _SIGS = {
     "tpgsr_conv_fwd": (ci, [C.POINTER(ConvArgs), vp]),
     "tpgsr_wgrad_splits": (ci, [ci, ci, ci]),
     "tpgsr_conv_wgrad": (ci, [C.POINTER(WgradArgs), vp]),
+    "tpgsr_wgrad_halo_plan": (ci, [C.POINTER(ConvArgs), C.POINTER(ci), C.POINTER(C.c_longlong)]),
     "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
     "tpgsr_wgrad_reduce_blocks": (ci, [ci, ci, ci]),
     "tpgsr_wgrad_reduce_program": (ci, [vp, ci, ci, vp]),

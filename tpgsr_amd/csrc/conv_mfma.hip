@@ -317,6 +317,7 @@ __global__ __launch_bounds__(768) void conv3x3_wstat_kernel(tpgsr_conv_args a, c
 
 extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, int K, int ld, hipStream_t st);
 extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long M, int K, int Z, int MB, int ld, hipStream_t st);
+extern "C" int tpgsr_conv_wgrad_halo_launch(const tpgsr_wgrad_args* w, long long M, int ld, hipStream_t st);
 
 static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
   TPGSR_CHECK_ARG(a && a->in, "%s: null input", who);
@@ -617,6 +618,10 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   int K = a->KH * a->KW * a->Cin;
   int Z, MB;
   wgrad_plan(M, K, a->Cout, &Z, &MB);
+  if (w->zsplits > 0) {   // the caller's split count: whole 64-pixel tiles per split (what the halo kernel walks)
+    Z = w->zsplits;
+    MB = cdiv(cdiv(M, 64), Z) * 64;
+  }
   dim3 grid(cdiv(K, WK) * cdiv(a->Cout, BN) * Z);
   // rows padded to a multiple of 4 floats keep an odd channel count (the 37 classes) on the vector path: the loads of the
   // last quad stay inside the padded row, columns >= Cout are never stored
@@ -626,6 +631,9 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   const int ld = loader_bits(a);
   if (a->terms > 0 && (a->Cin & 3) == 0 && (vecY || w->dy_ps)) {
     TPGSR_CHECK_ARG(a->terms == 1 || a->terms == 3, "tpgsr_conv_wgrad: terms must be 0, 1 or 3");
+    const int h = tpgsr_conv_wgrad_halo_launch(w, M, ld, st);
+    if (h < 0) return h;
+    if (h > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_wgrad(bf16 MFMA, halo)");
     return tpgsr_conv_wgrad_xbf_launch(w, M, K, Z, MB, ld, st);
   }
 #define TPGSR_WG_CASE(B) case B: hipLaunchKernelGGL(conv_wgrad_kernel<B>, grid, dim3(256), 0, st, *w, (int)M, K, MB, vecY); break;

@@ -976,6 +976,391 @@ extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// weight gradient of KH x KW > 1 x 1 convolutions: HALO kernel (the forward kernel's mirror image).
+//   part[z][k = tap Cin + ci][n] = sum over the pixels m of split z of  A[m][k] dy[m][n]
+// The tile loop above re-loads and re-splits A once per tap AND dy once per 64-row k-block (9x each for a 3x3), with 12 MFMAs
+// between two barriers.  Here a workgroup owns (pixel split z, channel block of 32, 64 output channels) and walks its pixels in
+// tiles of 64: the producers keep the halo of the tile (as in the forward kernel: every input pixel any tap touches, split once)
+// in LDS, the consumers contract over the tile's pixels for EVERY tap out of that one image --
+//   A^T fragments (32 channels x 16 pixels): ds_read_b64_tr_b16 from the pixel-major halo image at (entry of the pixel) + tap offset,
+//   dy fragments (16 pixels x 32 channels): pre-split ONCE per launch by dy_split_kernel into MFMA fragment order
+//   [term][m / 16][n / 32][lane][8] and loaded straight into registers (like the weights of the forward kernel),
+// and keep the [taps x 32 x 64] result block in registers across all tiles of the split (no atomics; the splits are summed by
+// tpgsr_wgrad_reduce as before).  12 waves = 8 consumers (2 column halves x 4 tap groups of <= 3 taps: 48 accumulator
+// registers) + 4 producers, one workgroup per CU at <= 168 registers.
+// Bias gradient: column sums of dy = ones[32 x 16] x dy fragments on the matrix pipe (tap group 0 of channel block 0).
+// ------------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void dy_split_kernel(const float* __restrict__ dy, int dy_ld, int dy_coff, int dy_ps, int M, int Cout,
+                                                       int OH, int OW, unsigned short* __restrict__ out, int MB16, int NB32) {
+  const int lane = threadIdx.x & 63;
+  const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= (long long)MB16 * NB32) return;
+  const int mb = (int)(b / NB32), nb = (int)(b - (long long)mb * NB32);
+  const int n = nb * 32 + (lane & 31), p0 = mb * 16 + (lane >> 5) * 8;
+  __bf16 h[8][T];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = p0 + j;
+    float v = 0.f;
+    if (m < M && n < Cout) {
+      if (!dy_ps) {
+        v = dy[(size_t)m * dy_ld + dy_coff + n];
+      } else {   // logical channel n = (cs, i, jj) of a [N][2 OH][2 OW][Cout / 4] tensor
+        const int ohw = OH * OW, nn = m / ohw, rem = m - nn * ohw, oh = rem / OW, ow = rem - oh * OW;
+        v = dy[((size_t)(nn * 2 * OH + 2 * oh + ((n >> 1) & 1)) * (2 * OW) + 2 * ow + (n & 1)) * (Cout >> 2) + (n >> 2)];
+      }
+    }
+    split_bf<T>(v, h[j]);
+  }
+  const size_t plane = (size_t)MB16 * NB32 * 512;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = h[j][t];
+    *reinterpret_cast<bf16x8*>(out + t * plane + ((size_t)b * 64 + lane) * 8) = v;
+  }
+}
+
+template <int LD, int T, int NE>
+__global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_args w, int M, int Lcap, int Z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];   // [2 buffers][T][Lcap entries][64 B], then [2][64] entry table
+  const tpgsr_conv_args& a = w.c;
+  const int PLANE = Lcap * 64, BUF = T * PLANE;
+  int* etab = reinterpret_cast<int*>(hsm + 2 * BUF);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nnb = (a.Cout + 63) >> 6, NC = a.Cin >> 5;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);     // column tile fastest: the workgroups sharing a halo sit on one XCD
+  const int nbk = blk % nnb, cc = (blk / nnb) % NC, z = blk / (nnb * NC);
+  const int n0 = nbk * 64;
+  const int tiles = (M + 63) >> 6, tpz = (tiles + Z - 1) / Z;
+  const int t_beg = z * tpz, t_end = min(tiles, t_beg + tpz);
+  const int taps = a.KH * a.KW;
+  const int Hp = a.OH + a.KH - 1, Wp = a.OW + a.KW - 1, ohw = a.OH * a.OW;
+  const int K = taps * a.Cin;
+  auto qbase = [&](int m) __attribute__((always_inline)) {
+    const int n = m / ohw, r = m - n * ohw, oh = r / a.OW;
+    return (n * Hp + oh) * Wp + (r - oh * a.OW);
+  };
+
+  if (wave >= 8) {
+    // ------------------------------- producers (as in the forward kernel; an item = one pixel tile) -------------------------------
+    const int pt = tid - 512, aq = pt & 7, er = pt >> 3;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (size_t)a.N * a.H * a.W * a.in_ld);
+    const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
+    const int c = cc * 32 + aq * 4;
+    float4 qs = make_float4(1.f, 1.f, 1.f, 1.f), qt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LD & 1) {
+      qs = *reinterpret_cast<const float4*>(a.in_scale + c);
+      qt = *reinterpret_cast<const float4*>(a.in_shift + c);
+    }
+    int hpix[NE];
+    int q0 = 0;
+    auto decode_tile = [&](const int t) __attribute__((always_inline)) {
+      const int m0 = t * 64;
+      q0 = qbase(m0);
+      const int L = qbase(min(m0 + 63, M - 1)) - q0 + (a.KH - 1) * Wp + a.KW;
+      const int q = q0 + er;
+      int n = q / (Hp * Wp);
+      const int rem = q - n * (Hp * Wp);
+      int r = rem / Wp, sx = rem - r * Wp;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int ih = r - a.pad_h, iw = sx - a.pad_w;
+        const bool in = n < a.N && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        hpix[i] = 32 * i + er < L ? (in ? (n * a.H + ih) * a.W + iw : -1) : -2;
+        sx += 32;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          const bool c1 = sx >= Wp;
+          sx -= c1 ? Wp : 0;
+          r += c1 ? 1 : 0;
+          const bool c2 = r >= Hp;
+          r -= c2 ? Hp : 0;
+          n += c2 ? 1 : 0;
+        }
+      }
+    };
+    constexpr bool DB = !(LD & 4);
+    ARaw hr[DB ? 2 : 1][NE];
+    int tab[2] = {0, 0};      // this thread's table entry (threads 0..63): entry of tile pixel pt, per register set
+    auto load_item = [&](auto set_tag, const int t) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const bool ok = hpix[i] >= 0;
+        hr[S][i].ok = ok;
+        hr[S][i].raw = hpix[i] > -2;
+        hr[S][i].v = buf_load4(rs_in, ok ? ((unsigned)hpix[i] * (unsigned)a.in_ld + (unsigned)(a.in_coff + c)) * 4u : OOB_OFF);
+        if (LD & 4) hr[S][i].v2 = buf_load4(rs_in2, ok ? ((unsigned)hpix[i] * (unsigned)a.in2_ld + (unsigned)c) * 4u : OOB_OFF);
+      }
+      // pixels past the end of the problem point at the last real pixel's entry: finite data, multiplied by dy = 0
+      tab[S] = pt < 64 ? qbase(min(t * 64 + pt, M - 1)) - q0 : 0;
+    };
+    auto store_item = [&](auto set_tag, const int j) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+      unsigned char* buf = hsm + (j & 1) * BUF;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const bool part = hr[S][i].raw;
+        hr[S][i].raw = false;
+        const float4 v = finish_a<LD>(a, hr[S][i], qs, qt);
+        uint2 h[T];
+        split4<T>(v, h);
+        const int e = 32 * i + er;
+        const int off = e * 64 + (((aq >> 1) ^ ((e >> 2) & 3)) << 4) + (aq & 1) * 8;
+        if (part) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) *reinterpret_cast<uint2*>(buf + t * PLANE + off) = h[t];
+        }
+      }
+      if (pt < 64) etab[(j & 1) * 64 + pt] = tab[S];
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using PN = std::integral_constant<int, DB ? 1 : 0>;
+    int t = t_beg, j = 0;
+    if (t < t_end) {
+      decode_tile(t);
+      if (DB) load_item(P0{}, t);
+      auto item = [&](auto cur_tag, auto nxt_tag) __attribute__((always_inline)) -> bool {
+        const bool more = t + 1 < t_end;
+        if (!DB) load_item(cur_tag, t);
+        if (more) decode_tile(t + 1);
+        if (DB && more) load_item(nxt_tag, t + 1);
+        store_item(cur_tag, j);
+        __syncthreads();      // barrier j: tile j is in LDS, and the consumers are done with tile j - 1
+        ++j;
+        ++t;
+        return more;
+      };
+      while (true) {
+        if (!item(P0{}, PN{})) break;
+        if (!item(PN{}, P0{})) break;
+      }
+    }
+    return;
+  }
+
+  // ------------------------------- consumers -------------------------------
+  const int wn = wave & 1, tg = wave >> 1;
+  const int TPG = (taps + 3) >> 2;                      // taps per group (<= 3, launcher)
+  const int tap0 = tg * TPG, ntap = max(0, min(taps, tap0 + TPG) - tap0);
+  int tapoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tp = min(tap0 + i, taps - 1);
+    tapoff[i] = (tp / a.KW) * Wp + tp % a.KW;
+  }
+  const int NB32 = (a.Cout + 31) >> 5, MB16 = (M + 15) >> 4;
+  const int nb32 = (n0 >> 5) + wn;
+  const bool ncol = nb32 < NB32;
+  const size_t plane_y = (size_t)MB16 * NB32 * 1024;    // bytes per term
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(reinterpret_cast<const float*>(w.dy_bf), (size_t)T * MB16 * NB32 * 256);
+  const bool want_db = w.dbpart != nullptr && cc == 0 && tg == 0;
+  // transposing fragment fetch (frag_tr above, on the halo image): 16-lane group G, lane q of the group addresses pixel row
+  // (G >> 1) * 8 + (q >> 2) (+4 for the upper half) of the 16-pixel step, channels (G & 1) * 16 + (q & 3) * 4 ..+3
+  const int G = lane >> 4, q = lane & 15;
+  const int prow = (G >> 1) * 8 + (q >> 2);
+  const int c0 = (G & 1) * 16 + (q & 3) * 4;
+  auto a_off = [&](const int e) __attribute__((always_inline)) { return e * 64 + (((c0 >> 3) ^ ((e >> 2) & 3)) << 4) + (c0 & 4) * 2; };
+
+  floatx16 acc[3], accdb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = acc[2][r] = accdb[r] = 0.f;
+  u32x4 by[2][T];           // dy fragments of a 16-pixel step, two register sets (one step ahead)
+  bf16x8 av[2][T];          // A^T fragments of one (step, tap), two sets (one tap ahead)
+  auto fetch_y = [&](auto set_tag, const int mb16) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const size_t off = t * plane_y + ((size_t)mb16 * NB32 + nb32) * 1024 + lane * 16;
+      by[S][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (ncol && mb16 < MB16) ? (int)off : (int)OOB_OFF, 0, 0);
+    }
+  };
+  auto fetch_a = [&](auto set_tag, const unsigned char* buf, const int e_lo, const int e_hi) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value;
+    const int o_lo = a_off(e_lo), o_hi = a_off(e_hi);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(buf + t * PLANE + o_lo));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(buf + t * PLANE + o_hi));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      av[S][t] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+  int j = 0;
+  if (t_beg < t_end) fetch_y(I0{}, t_beg * 4);
+  for (int t = t_beg; t < t_end; ++t, ++j) {
+    __syncthreads();          // barrier j
+    const unsigned char* buf = hsm + (j & 1) * BUF;
+    int e8[4][2];             // entries of this lane's pixel rows: step s, lower / upper half
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      e8[s][0] = etab[(j & 1) * 64 + s * 16 + prow];
+      e8[s][1] = etab[(j & 1) * 64 + s * 16 + prow + 4];
+    }
+    // one 16-pixel step: dy fragments of the next step on their way, then the group's taps; sets alternate by step / tap parity
+    auto step = [&](auto ys_tag, const int s, const int mb16) __attribute__((always_inline)) {
+      constexpr int YS = decltype(ys_tag)::value;
+      fetch_y(std::integral_constant<int, YS ^ 1>{}, mb16 + 1);     // (next tile's first step included; past the end: zeros)
+      if (ntap > 0) fetch_a(I0{}, buf, e8[s][0] + tapoff[0], e8[s][1] + tapoff[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 bv[T];
+#pragma unroll
+      for (int t2 = 0; t2 < T; ++t2) bv[t2] = __builtin_bit_cast(bf16x8, by[YS][t2]);
+      if (want_db) {
+#pragma unroll
+        for (int t2 = T - 1; t2 >= 0; --t2) accdb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv[t2], accdb, 0, 0, 0);
+      }
+      if (ntap > 0) {
+        if (ntap > 1) fetch_a(I1{}, buf, e8[s][0] + tapoff[1], e8[s][1] + tapoff[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma_terms<T>(av[0], bv, acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ntap > 1) {
+          if (ntap > 2) fetch_a(I0{}, buf, e8[s][0] + tapoff[2], e8[s][1] + tapoff[2]);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1] = mfma_terms<T>(av[1], bv, acc[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ntap > 2) {
+            acc[2] = mfma_terms<T>(av[0], bv, acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    step(I0{}, 0, t * 4 + 0);
+    step(I1{}, 1, t * 4 + 1);
+    step(I0{}, 2, t * 4 + 2);
+    step(I1{}, 3, t * 4 + 3);
+  }
+
+  // ---- the split's slab: rows k = tap Cin + cc 32 + row, columns n0 + wn 32 + (lane & 31) ----
+  const int n = n0 + wn * 32 + (lane & 31);
+  float* dst = w.part + (size_t)z * K * a.Cout;
+  if (n < a.Cout) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < ntap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = (tap0 + i) * a.Cin + cc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          dst[(size_t)k * a.Cout + n] = acc[i][r];
+        }
+      }
+    if (want_db && lane < 32) w.dbpart[(size_t)z * a.Cout + n] = accdb[0];
+  }
+}
+
+// geometry test shared by the plan and the launcher
+static bool wgrad_halo_shape_ok(const tpgsr_conv_args* a, int* Lcap_out) {
+  const int taps = a->KH * a->KW;
+  // at least four channel blocks (TPGSR_XBF_WGRAD_HALO_MINC overrides): measured at batch 48, the recognizer's 128..512-channel
+  // convolutions gain 15-30 % over the tile loop (conv5 225 -> 157 us) while the 64-channel trunk convolutions lose (42 -> 45 us:
+  // two channel blocks x 128 pixel splits, every workgroup writes a slab for six tiles of work, plus the dy pre-split) and the
+  // whole C3 step came out 1 % slower with them on -- profiles/r02b_wgrad_halo.md
+  static const int minc = [] { const char* e = getenv("TPGSR_XBF_WGRAD_HALO_MINC"); return e ? atoi(e) : 128; }();
+  if (a->Cin < minc) return false;
+  if (taps < 2 || taps > 12 || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_ps || a->in_b || a->OW + a->KW - 1 < 8) return false;
+  const int Lcap = halo_capacity(a);
+  if (Lcap > 32 * 9) return false;
+  *Lcap_out = Lcap;
+  return true;
+}
+
+extern "C" int tpgsr_wgrad_halo_plan(const tpgsr_conv_args* a, int* zsplits, long long* dy_bf_bytes) {
+  static const bool on = [] { const char* e = getenv("TPGSR_XBF_WGRAD_HALO"); return !(e && e[0] == '0'); }();
+  int Lcap = 0;
+  if (!on || !a || a->terms <= 0 || !wgrad_halo_shape_ok(a, &Lcap)) return 0;
+  const long long M = (long long)a->N * a->OH * a->OW;
+  const int tiles = (int)cdiv(M, 64);
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus < 1) cus = 256;
+  const int groups = (a->Cin >> 5) * cdiv(a->Cout, 64);
+  int Z = cus / groups;                                   // one workgroup per CU
+  if (Z < 1) Z = 1;
+  if (Z > tiles) Z = tiles;
+  const int tpz = cdiv(tiles, Z);
+  Z = cdiv(tiles, tpz);
+  if (zsplits) *zsplits = Z;
+  if (dy_bf_bytes) *dy_bf_bytes = 3ll * cdiv(M, 16) * cdiv(a->Cout, 32) * 1024;
+  return 1;
+}
+
+// returns 1 when launched, 0 when not this kernel's case, < 0 on error
+extern "C" int tpgsr_conv_wgrad_halo_launch(const tpgsr_wgrad_args* w, long long M, int ld, hipStream_t st) {
+  const tpgsr_conv_args* a = &w->c;
+  const int T = a->terms;
+  int Lcap = 0;
+  if (w->zsplits <= 0 || !w->dy_bf || T <= 0 || (ld & ~7) || ld == 6 || !wgrad_halo_shape_ok(a, &Lcap)) return 0;
+  static const bool on = [] { const char* e = getenv("TPGSR_XBF_WGRAD_HALO"); return !(e && e[0] == '0'); }();
+  const size_t lds = (size_t)2 * T * Lcap * 64 + 512;
+  if (!on || lds > 150 * 1024) return 0;
+  const int MB16 = (int)cdiv(M, 16), NB32 = cdiv(a->Cout, 32);
+  {
+    dim3 g((unsigned)cdiv((long long)MB16 * NB32, 4));
+    if (T == 1)
+      hipLaunchKernelGGL(dy_split_kernel<1>, g, dim3(256), 0, st, w->dy, w->dy_ld, w->dy_coff, w->dy_ps, (int)M, a->Cout, a->OH, a->OW,
+                         (unsigned short*)w->dy_bf, MB16, NB32);
+    else
+      hipLaunchKernelGGL(dy_split_kernel<3>, g, dim3(256), 0, st, w->dy, w->dy_ld, w->dy_coff, w->dy_ps, (int)M, a->Cout, a->OH, a->OW,
+                         (unsigned short*)w->dy_bf, MB16, NB32);
+  }
+  const bool small = Lcap <= 32 * 7;
+  const void* fn = nullptr;
+#define XBF_WGH_CASE(B)                                                                                                          \
+  case B:                                                                                                                        \
+    fn = T == 1 ? (small ? (const void*)conv_wgrad_halo_kernel<B, 1, 7> : (const void*)conv_wgrad_halo_kernel<B, 1, 9>)          \
+                : (small ? (const void*)conv_wgrad_halo_kernel<B, 3, 7> : (const void*)conv_wgrad_halo_kernel<B, 3, 9>);         \
+    break;
+  switch (ld) {
+    XBF_HALO_LD_CASES(XBF_WGH_CASE)
+    default: return 0;
+  }
+#undef XBF_WGH_CASE
+  if (lds > 64 * 1024) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void*, int>, size_t>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+      tpgsr_set_error("tpgsr_conv_wgrad: hipGetDevice failed");
+      return TPGSR_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    size_t* cur = nullptr;
+    for (auto& d : done)
+      if (d.first.first == fn && d.first.second == dev) cur = &d.second;
+    if (!cur || *cur < lds) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        tpgsr_set_error("tpgsr_conv_wgrad: LDS opt-in (%zu bytes) for the halo kernel failed", lds);
+        return TPGSR_ERR_LAUNCH;
+      }
+      if (cur) *cur = lds; else done.push_back({{fn, dev}, lds});
+    }
+  }
+  const int Z = w->zsplits;
+  dim3 grid((unsigned)((a->Cin >> 5) * cdiv(a->Cout, 64) * Z));
+  int Mi = (int)M, Lc = Lcap, Zi = Z;
+  tpgsr_wgrad_args args = *w;
+  void* params[] = {&args, &Mi, &Lc, &Zi};
+  if (hipLaunchKernel(fn, grid, dim3(768), params, lds, st) != hipSuccess) {
+    tpgsr_set_error("tpgsr_conv_wgrad(halo): launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return TPGSR_ERR_LAUNCH;
+  }
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // operand splitting: fp32 [K][ld] (k-major, as packed for the fp32 kernels) -> bf16 planes in MFMA FRAGMENT ORDER
 //   dst[((t * NB32 + n / 32) * KB16 + k / 16) * 64 + ((k >> 3) & 1) * 32 + (n & 31)][k & 7],  NB32 = ceil(N / 32), KB16 = Kp / 16,
 // Kp = K rounded up to 32, zero padded in k and n: the B operand of one (32-column, 16-k) block is 1 KB contiguous, lane-major.

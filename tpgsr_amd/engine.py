@@ -202,12 +202,12 @@ class ConvLayer:
         """dW += A^T dy and db += colsum(dy), straight into the gradient arena."""
         eng = self.eng
         g = self.geom(N, H, W)
-        Z = K.wgrad_splits(g.M, g.K, g.Cout)
+        Z = K.wgrad_splits(g.M, g.K, g.Cout, geom=g)
         has_b = self.b is not None and not self.tail
         part, dbp = eng.wgrad_buffers(Z * g.K * g.Cout, Z * g.Cout if has_b else 0)
         ca = K.make_conv_args(g, x, **(loader or {}))
         with K.side():
-            K.conv_wgrad(K.make_wgrad_args(ca, dy, part, dbp, **(dy_kw or {})))
+            K.conv_wgrad(K.make_wgrad_args(ca, dy, part, dbp, zsplits=Z, **(dy_kw or {})))
             K.wgrad_reduce(part, dbp, Z, g, eng.G[self.wname], eng.G[self.bname] if has_b else None,
                            layout=2 if self.tail else 0, accumulate=True, gscale=self.wscale)
 

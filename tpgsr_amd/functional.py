@@ -131,10 +131,10 @@ class _Conv2d(torch.autograd.Function):
             dx = _new(x, g.N, g.H, g.W, g.Cin)
             K.conv_fwd(K.make_conv_args(g.dgrad(), dy, wt_d, dx, in_ps=out_ps))
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            Z = K.wgrad_splits(g.M, g.K, g.Cout)
+            Z = K.wgrad_splits(g.M, g.K, g.Cout, geom=g)
             part = _new(x, Z, g.K, g.Cout)
             dbp = _new(x, Z, g.Cout) if has_b else None
-            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, dbp, dy_ps=out_ps))
+            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, dbp, dy_ps=out_ps, zsplits=Z))
             dw = torch.empty_like(w)
             db = _new(x, g.Cout) if has_b else None
             K.wgrad_reduce(part, dbp, Z, g, dw, db, layout=1 if transposed else 0, accumulate=False, gscale=wscale)

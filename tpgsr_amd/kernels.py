@@ -437,11 +437,44 @@ def conv_fwd(args: ConvArgs):
     _launch("tpgsr_conv_fwd", C.byref(args))
 
 
-def wgrad_splits(M, K, Cout) -> int:
+def wgrad_splits(M, K, Cout, geom: "ConvGeom" = None) -> int:
+    """number of pixel splits Z of a weight gradient (the caller sizes part [Z][K][Cout] / dbpart [Z][Cout] with it).
+    With `geom` and the bf16 matrix-core policy on, convolutions the halo weight-gradient kernel takes get ITS split count
+    (one workgroup per CU); pass the same Z to make_wgrad_args(zsplits=Z)."""
+    if geom is not None and CONV_TERMS and not DRYRUN:
+        plan = wgrad_halo_plan(geom)
+        if plan is not None:
+            return plan[0]
     return _lib.load().tpgsr_wgrad_splits(M, K, Cout)
 
 
-def make_wgrad_args(cargs: ConvArgs, dy, part, dbpart=None, *, dy_ld=None, dy_coff=0, dy_ps=False) -> WgradArgs:
+def wgrad_halo_plan(g: "ConvGeom"):
+    """(Z, scratch bytes) when the halo weight-gradient kernel takes this geometry under the current policy, else None"""
+    a = ConvArgs()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = g.N, g.H, g.W, g.Cin, g.Cout, g.KH, g.KW
+    a.pad_h, a.pad_w, a.OH, a.OW = g.pad_h, g.pad_w, g.OH, g.OW
+    a.terms = CONV_TERMS
+    z, nbytes = C.c_int(0), C.c_longlong(0)
+    if not _lib.load().tpgsr_wgrad_halo_plan(C.byref(a), C.byref(z), C.byref(nbytes)):
+        return None
+    return z.value, nbytes.value
+
+
+# scratch for the pre-split dy of the halo weight-gradient kernel: one buffer per (device, stream), grown by allocating a larger one
+# (earlier buffers stay alive: recorded plans keep pointing at them; everything on one stream is ordered, so sharing is safe)
+_DY_SCRATCH = {}
+
+
+def _dy_scratch(nbytes: int, device) -> torch.Tensor:
+    key = (str(device), current_stream().cuda_stream)
+    bufs = _DY_SCRATCH.setdefault(key, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+    return bufs[-1]
+
+
+def make_wgrad_args(cargs: ConvArgs, dy, part, dbpart=None, *, dy_ld=None, dy_coff=0, dy_ps=False, zsplits=0) -> WgradArgs:
+    """zsplits: the Z the caller sized `part` with when it came from wgrad_splits(..., geom=...) (0: the legacy count)"""
     w = WgradArgs()
     w.c = cargs
     w.dy = _p(dy)
@@ -450,6 +483,14 @@ def make_wgrad_args(cargs: ConvArgs, dy, part, dbpart=None, *, dy_ld=None, dy_co
     w.dy_ps = int(bool(dy_ps))
     w.part = _p(part)
     w.dbpart = _p(dbpart)
+    w.zsplits = int(zsplits)
+    if zsplits and cargs.terms and not DRYRUN and isinstance(dy, torch.Tensor):
+        z, nbytes = C.c_int(0), C.c_longlong(0)
+        if _lib.load().tpgsr_wgrad_halo_plan(C.byref(cargs), C.byref(z), C.byref(nbytes)):
+            buf = _dy_scratch(nbytes.value, dy.device)
+            w.dy_bf = buf.data_ptr()
+            if _REC is not None:
+                _REC.keep.append(buf)
     return w
 
 
