@@ -164,7 +164,7 @@ __device__ __forceinline__ void xbf_epilogue(const tpgsr_conv_args& a, floatx16 
 //   Why the blocks per wave matter (x3 mode, per 32x32x16 MFMA = 32 cycles of one SIMD, i.e. one MFMA per 8 clk per CU at
 //     peak): a 1 x 1 wave tile needs 3 A + 3 W fragments (6 KB) per 6 MFMAs = 512 B of LDS reads AND 512 B of L1 reads per
 //     MFMA -- 50 % of the LDS pipe (128 B/clk) and 100 % of the vector L1 (64 B/clk) at matrix peak, which is where the
-//     1 x 1 kernel sat (31 % matrix-pipe busy, LDS 46 %: rocprofv3 PMC, profiles/r02_pmc_conv_v3.md).  2 x 1 halves the W
+//     1 x 1 kernel sat (31 % matrix-pipe busy, LDS 46 %: rocprofv3 PMC, profiles/r02_pmc_conv.md).  2 x 1 halves the W
 //     bytes per MFMA, 2 x 2 halves both.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int xa_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
