@@ -354,6 +354,14 @@ int tpgsr_lstm_rec_gemm(const float* a0, const float* a1, long long a_stride, co
  * bwd: dhc [nsplit][2][N][Hh] = W_hh^T dG of the previous backward step, dcc [N][2][Hh]. */
 int tpgsr_lstm_step_fwd(float* G, const float* gh, int nsplit, const float* bhh /* [2][4Hh], optional */, float* Cst, float* out,
                         int N, int T, int Hh, int step, void* stream);
+/* BiLSTM forward as ONE persistent launch (replaces the T x (tpgsr_lstm_rec_gemm + tpgsr_lstm_step_fwd) loop; model/crnn/crnn.py:10,
+ * nn.LSTM(bidirectional=True)): Hh == 256, N <= 64.  G / Cst / out as for tpgsr_lstm_step_fwd, whhT [2][Hh][4Hh] = W_hh^T of both
+ * directions, bhh [2][4Hh] or NULL.  hx: exchange buffer of tpgsr_lstm_seq_hx_bytes() bytes, ZEROED ONCE by the caller (reusable across
+ * calls on one stream); sync: 4 x u32 scratch, zeroed by the call; sync[2] != 0 afterwards = a grid barrier timed out (the 64
+ * workgroups were not co-resident within ~1 s) and the result is invalid. */
+int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hx, unsigned* sync, int N, int T,
+                       int Hh, void* stream);
+long long tpgsr_lstm_seq_hx_bytes(void);
 int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, int nsplit, float* dcc, int N, int T,
                         int Hh, int step, void* stream);
 /* p = softmax(logits [N][T][C]); prior (N,C,1,T) = p with samples [0, drop_n) zeroed (prior dropout); with q: partial

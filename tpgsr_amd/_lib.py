@@ -126,6 +126,8 @@ _SIGS = {
     "tpgsr_pool2d_bwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_lstm_rec_gemm": (ci, [vp, vp, ll, vp, vp, ci, ci, ci, ci, vp, vp]),
     "tpgsr_lstm_step_fwd": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "tpgsr_lstm_seq_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "tpgsr_lstm_seq_hx_bytes": (C.c_longlong, []),
     "tpgsr_lstm_step_bwd": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, vp]),
     "tpgsr_softmax_prior_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]),
     "tpgsr_semantic_loss_finalize": (ci, [vp, ci, ll, cf, vp, vp]),

@@ -113,6 +113,16 @@ class LstmLayer:
         """x [N][T][Cin] -> G (gates) -> out [N][T][2Hh] -> e = Linear(out) [N][T][nOut]"""
         Hh, G4, P = self.Hh, 4 * self.Hh, self.eng.P
         K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, self.Cin, 2 * G4), x, self.wih_f, G, bias=self.bih, **loader))
+        if K.LSTM_SEQ and Hh == 256 and N <= 64:             # the whole recurrence as one persistent launch
+            if not hasattr(self, "_seq"):
+                self._seq = {}
+            key = K.current_stream().cuda_stream               # one exchange buffer per stream (the teacher runs on its own)
+            if key not in self._seq:
+                self._seq[key] = K.lstm_seq_buffers(self.eng.device)
+            hx, sync = self._seq[key]
+            K.lstm_seq_fwd(G, self.whh_f, self.bhh, Cst, out, hx, sync, N, T, Hh)
+            self.emb.fwd(N, 1, T, out, e)
+            return
         S = Hh // 32                                          # one 32-deep K chunk per workgroup: 2 * S * 4Hh/64 workgroups
         for s in range(T):
             if s > 0:     # gh = h_prev W_hh^T, both directions in one split-K launch (h_prev: time s-1 / T-s of `out`)

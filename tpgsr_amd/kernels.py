@@ -702,6 +702,22 @@ def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
     _launch("tpgsr_lstm_rec_gemm", a0, a1, a_stride, _p(b0), _p(b1), Nrows, Kd, Nc, S, _p(out))
 
 
+# persistent BiLSTM forward (Hh == 256, N <= 64): ONE launch with a grid barrier per time step instead of two launches per step.
+# Correct (the CRNN parity tests pass with it) but measured SLOWER on MI355X -- C3 10.15 vs 9.99 ms/step: the per-step agent-scope
+# release / acquire pair costs more than the two ~5 us launches it replaces while other streams keep the L2 dirty -- so it is opt-in
+LSTM_SEQ = os.environ.get("TPGSR_LSTM_SEQ", "0") == "1"
+
+
+def lstm_seq_fwd(G, whhT, bhh, Cst, out, hx, sync, N, T, Hh):
+    _launch("tpgsr_lstm_seq_fwd", _p(G), _p(whhT), _p(bhh), _p(Cst), _p(out), _p(hx), _p(sync), N, T, Hh)
+
+
+def lstm_seq_buffers(device):
+    """(hx, sync) for lstm_seq_fwd: the exchange buffer must start zeroed (rows of sequences >= N are never written)"""
+    hx = torch.zeros(_lib.load().tpgsr_lstm_seq_hx_bytes(), dtype=torch.uint8, device=device)
+    return hx, torch.zeros(4, dtype=torch.int32, device=device)
+
+
 def lstm_step_fwd(G, gh, nsplit, bhh, Cst, out, N, T, Hh, step):
     _launch("tpgsr_lstm_step_fwd", _p(G), _p(gh), nsplit, _p(bhh), _p(Cst), _p(out), N, T, Hh, step)
 
