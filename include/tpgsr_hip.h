@@ -354,6 +354,13 @@ int tpgsr_lstm_rec_gemm(const float* a0, const float* a1, long long a_stride, co
  * bwd: dhc [nsplit][2][N][Hh] = W_hh^T dG of the previous backward step, dcc [N][2][Hh]. */
 int tpgsr_lstm_step_fwd(float* G, const float* gh, int nsplit, const float* bhh /* [2][4Hh], optional */, float* Cst, float* out,
                         int N, int T, int Hh, int step, void* stream);
+/* BiLSTM time step as ONE launch: recurrent projection (bf16 matrix cores, split operands, full K per workgroup) + gate math, Hh == 256,
+ * N <= 64; replaces tpgsr_lstm_rec_gemm + tpgsr_lstm_step_fwd.  wfr = tpgsr_lstm_wfrag(whhT) once per pass (tpgsr_lstm_wfrag_bytes()
+ * bytes); hx as for tpgsr_lstm_seq_fwd (zeroed once; step s reads parity (s-1)&1 and writes s&1). */
+long long tpgsr_lstm_wfrag_bytes(void);
+int tpgsr_lstm_wfrag(const float* whhT /* [2][Hh][4Hh] */, void* wfr, int Hh, void* stream);
+int tpgsr_lstm_stepx_fwd(float* G, const void* wfr, const float* bhh, float* Cst, float* out, void* hx, int N, int T, int Hh, int step,
+                         void* stream);
 /* BiLSTM forward as ONE persistent launch (replaces the T x (tpgsr_lstm_rec_gemm + tpgsr_lstm_step_fwd) loop; model/crnn/crnn.py:10,
  * nn.LSTM(bidirectional=True)): Hh == 256, N <= 64.  G / Cst / out as for tpgsr_lstm_step_fwd, whhT [2][Hh][4Hh] = W_hh^T of both
  * directions, bhh [2][4Hh] or NULL.  hx: exchange buffer of tpgsr_lstm_seq_hx_bytes() bytes, ZEROED ONCE by the caller (reusable across

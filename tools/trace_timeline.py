@@ -10,8 +10,8 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     rows = db.execute("select name, queue_id, start, end from kernels order by start").fetchall()
-    # a step starts at the pack_program launch
-    starts = [i for i, r in enumerate(rows) if r[0].startswith("pack_program")]
+    # a step starts after the last optimiser launch of the previous one (C3 has several pack programs per step)
+    starts = [i + 1 for i, r in enumerate(rows[:-1]) if r[0].startswith("adam_step") and not rows[i + 1][0].startswith("adam_step")]
     a, b = starts[-back - 1], starts[-back]
     step = rows[a:b]
     t0 = step[0][2]

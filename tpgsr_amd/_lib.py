@@ -128,6 +128,9 @@ _SIGS = {
     "tpgsr_lstm_step_fwd": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_hx_bytes": (C.c_longlong, []),
+    "tpgsr_lstm_wfrag_bytes": (C.c_longlong, []),
+    "tpgsr_lstm_wfrag": (ci, [vp, vp, ci, vp]),
+    "tpgsr_lstm_stepx_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "tpgsr_lstm_step_bwd": (ci, [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, vp]),
     "tpgsr_softmax_prior_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]),
     "tpgsr_semantic_loss_finalize": (ci, [vp, ci, ll, cf, vp, vp]),

@@ -5,6 +5,7 @@
 //   * softmax over the 37 classes + SemanticLoss (loss/semantic_loss.py:21-39) + the (N,37,1,26) prior with the
 //     deterministic prior dropout of interfaces/super_resolution.py:376-382
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------------
 // bicubic (A = -0.75, align_corners = False, no antialias) + luminance
@@ -639,6 +640,155 @@ extern "C" int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh,
 }
 /* bytes of the exchange buffer `hx` of tpgsr_lstm_seq_fwd */
 extern "C" long long tpgsr_lstm_seq_hx_bytes(void) { return 2ll * 2 * 3 * 2 * 16 * 512 * 2; }
+
+// ------------------------------------------------------------------------------------------------------
+// BiLSTM time step as ONE launch (Hh = 256, N <= 64): recurrent projection + gate math fused, no split-K slabs, no
+// inter-workgroup exchange inside the launch.  2 x 16 workgroups; workgroup (d, ub) owns hidden units 16 ub .. 16 ub + 15 of
+// direction d = 64 gate columns (column c: gate c >> 4, unit 16 ub + (c & 15)); its four waves compute the four 32 x 32 blocks of
+//   gh[n][64] = h_prev[n][256] x W[256][64]
+// over the FULL K on the bf16 matrix cores with split operands (16 k-blocks x 6 MFMAs per wave = 1.3 us), both operands straight
+// from global memory in fragment order: W pre-split once per pass by lstm_wfrag_kernel, h_prev published by the previous step's
+// launch as bf16 terms in A-fragment order (a k-block of 16 = exactly one workgroup's units: 1 KB per row block and term).
+// Then the gate math for the workgroup's 16 units of all sequences.  Replaces tpgsr_lstm_rec_gemm + tpgsr_lstm_step_fwd
+// (128 + 96 workgroups, two launches, ~10.5 us + a launch gap) per step.
+//   wfr  [2 dir][16 ub][2 col blocks][3 terms][16 k-blocks][64 lanes][8] bf16
+//   hx   [2 parity][2 dir][3 terms][2 row blocks][16 k-blocks][64 lanes][8] bf16, zeroed once by the caller
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_wfrag_kernel(const float* __restrict__ whhT, unsigned short* __restrict__ wfr) {
+  constexpr int Hh = 256, G4 = 1024;
+  const int d = blockIdx.x >> 4, ub = blockIdx.x & 15;
+  const float* W = whhT + (size_t)d * Hh * G4;
+  unsigned short* dst0 = wfr + (size_t)blockIdx.x * 2 * 3 * 16 * 512;
+  for (int idx = threadIdx.x; idx < 2 * 16 * 64; idx += 256) {
+    const int cb = idx >> 10, kb = (idx >> 6) & 15, l = idx & 63;
+    const int c = cb * 32 + (l & 31);
+    const int col = (c >> 4) * Hh + ub * 16 + (c & 15);
+    unsigned short hv[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ls_split3(W[(size_t)(kb * 16 + (l >> 5) * 8 + j) * G4 + col], hv[j]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      unsigned short v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = hv[j][t];
+      *reinterpret_cast<ls_u32x4*>(dst0 + ((size_t)((cb * 3 + t) * 16 + kb) * 64 + l) * 8) = *reinterpret_cast<ls_u32x4*>(v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_stepx_fwd_kernel(float* __restrict__ G, const unsigned short* __restrict__ wfr,
+                                                             const float* __restrict__ bhh, float* __restrict__ Cst,
+                                                             float* __restrict__ out, unsigned short* __restrict__ hx, int N, int T,
+                                                             int s) {
+  constexpr int Hh = 256, G4 = 1024;
+  __shared__ __attribute__((aligned(16))) float red[64 * 64];      // gh[row][col]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.x >> 4, ub = blockIdx.x & 15;
+  const int t = d == 0 ? s : T - 1 - s;
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const size_t par_elems = (size_t)2 * 3 * 2 * 16 * 512;
+  if (s > 0) {
+    const int rb = wave & 1, cb = wave >> 1;
+    const unsigned short* hp = hx + (size_t)((s - 1) & 1) * par_elems + (size_t)d * 3 * 2 * 16 * 512;
+    const unsigned short* wp = wfr + ((size_t)blockIdx.x * 2 + cb) * 3 * 16 * 512;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ls_u32x4 av[2][4][3], bv[2][4][3];      // two register sets of four k-blocks each: loads of the next four under these MFMAs
+    auto fetch = [&](auto set_tag, const int kb0) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          av[S][i][tt] = *reinterpret_cast<const ls_u32x4*>(hp + (((size_t)(tt * 2 + rb) * 16 + kb0 + i) * 64 + lane) * 8);
+          bv[S][i][tt] = *reinterpret_cast<const ls_u32x4*>(wp + (((size_t)tt * 16 + kb0 + i) * 64 + lane) * 8);
+        }
+    };
+    auto multiply = [&](auto set_tag) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ls_bf16x8 a[3], b[3];
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          a[tt] = __builtin_bit_cast(ls_bf16x8, av[S][i][tt]);
+          b[tt] = __builtin_bit_cast(ls_bf16x8, bv[S][i][tt]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    fetch(S0{}, 0);
+    fetch(S1{}, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(S0{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(S0{}, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(S1{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(S1{}, 12);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(S0{});
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(S1{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      red[row * 64 + cb * 32 + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+  }
+  unsigned short* hw = hx + (size_t)(s & 1) * par_elems + (size_t)d * 3 * 2 * 16 * 512;
+  for (int item = tid; item < N * 16; item += 256) {
+    const int n = item >> 4, ul = item & 15, unit = ub * 16 + ul;
+    float* g = G + (((size_t)n * T + t) * 2 + d) * G4;
+    const float* b = bhh ? bhh + (size_t)d * G4 : nullptr;
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pre[q] = g[q * Hh + unit] + (b ? b[q * Hh + unit] : 0.f);
+      if (s > 0) pre[q] += red[n * 64 + q * 16 + ul];
+    }
+    const float cprev = s > 0 ? Cst[(((size_t)n * T + tp) * 2 + d) * Hh + unit] : 0.f;
+    const float ig = sigmoid_f(pre[0]), fg = sigmoid_f(pre[1]), gg = tanh_f(pre[2]), og = sigmoid_f(pre[3]);
+    const float c = fg * cprev + ig * gg;
+    const float h = og * tanh_f(c);
+    g[unit] = ig;
+    g[Hh + unit] = fg;
+    g[2 * Hh + unit] = gg;
+    g[3 * Hh + unit] = og;
+    Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = c;
+    out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = h;
+    unsigned short hv[3];
+    ls_split3(h, hv);
+    const int ln = ((ul >> 3) & 1) * 32 + (n & 31);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) hw[(((size_t)(tt * 2 + (n >> 5)) * 16 + ub) * 64 + ln) * 8 + (ul & 7)] = hv[tt];
+  }
+}
+
+extern "C" long long tpgsr_lstm_wfrag_bytes(void) { return 2ll * 16 * 2 * 3 * 16 * 512 * 2; }
+extern "C" int tpgsr_lstm_wfrag(const float* whhT, void* wfr, int Hh, void* stream) {
+  TPGSR_CHECK_ARG(whhT && wfr && Hh == 256, "tpgsr_lstm_wfrag: needs Hh == 256 and non-null buffers");
+  hipLaunchKernelGGL(lstm_wfrag_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, whhT, (unsigned short*)wfr);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_wfrag");
+}
+extern "C" int tpgsr_lstm_stepx_fwd(float* G, const void* wfr, const float* bhh, float* Cst, float* out, void* hx, int N, int T, int Hh,
+                                    int step, void* stream) {
+  TPGSR_CHECK_ARG(G && wfr && Cst && out && hx && N > 0 && N <= 64 && T > 0 && Hh == 256 && step >= 0 && step < T,
+                  "tpgsr_lstm_stepx_fwd: needs Hh == 256, 1 <= N <= 64, 0 <= step < T and non-null buffers");
+  hipLaunchKernelGGL(lstm_stepx_fwd_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, G, (const unsigned short*)wfr, bhh, Cst, out,
+                     (unsigned short*)hx, N, T, step);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_stepx_fwd");
+}
 
 // backward step s' (reverse of the forward order): t = T-1-s' (forward dir), t = s' (reverse dir).
 //   dout [N][T][2*Hh] gradient w.r.t. the hidden states,  dhc [S][2][N][Hh] recurrent gradient W_hh^T dG[t_next] as K-split slabs

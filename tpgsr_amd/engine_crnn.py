@@ -123,6 +123,18 @@ class LstmLayer:
             K.lstm_seq_fwd(G, self.whh_f, self.bhh, Cst, out, hx, sync, N, T, Hh)
             self.emb.fwd(N, 1, T, out, e)
             return
+        if K.LSTM_STEPX and Hh == 256 and N <= 64:           # one fused launch per time step
+            if not hasattr(self, "_stepx"):
+                self._stepx = {}
+            key = K.current_stream().cuda_stream               # per stream (the teacher runs on its own)
+            if key not in self._stepx:
+                self._stepx[key] = K.lstm_stepx_buffers(self.eng.device)
+            wfr, hx = self._stepx[key]
+            K.lstm_wfrag(self.whh_f, wfr, Hh)
+            for s in range(T):
+                K.lstm_stepx_fwd(G, wfr, self.bhh, Cst, out, hx, N, T, Hh, s)
+            self.emb.fwd(N, 1, T, out, e)
+            return
         S = Hh // 32                                          # one 32-deep K chunk per workgroup: 2 * S * 4Hh/64 workgroups
         for s in range(T):
             if s > 0:     # gh = h_prev W_hh^T, both directions in one split-K launch (h_prev: time s-1 / T-s of `out`)

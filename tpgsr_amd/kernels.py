@@ -708,6 +708,27 @@ def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
 LSTM_SEQ = os.environ.get("TPGSR_LSTM_SEQ", "0") == "1"
 
 
+# fused recurrent projection + gate step (Hh == 256, N <= 64): one 32-workgroup launch per time step instead of a 128-workgroup
+# split-K GEMM + a 96-workgroup gate kernel.  Correct, measured slower (C3 10.18 vs 10.02 ms/step): with one wave per SIMD on 32 CUs
+# every L2 round trip of the step is exposed, the two wide launches hide them -- opt-in
+LSTM_STEPX = os.environ.get("TPGSR_LSTM_STEPX", "0") == "1"
+
+
+def lstm_wfrag(whhT, wfr, Hh):
+    _launch("tpgsr_lstm_wfrag", _p(whhT), _p(wfr), Hh)
+
+
+def lstm_stepx_fwd(G, wfr, bhh, Cst, out, hx, N, T, Hh, step):
+    _launch("tpgsr_lstm_stepx_fwd", _p(G), _p(wfr), _p(bhh), _p(Cst), _p(out), _p(hx), N, T, Hh, step)
+
+
+def lstm_stepx_buffers(device):
+    """(wfr, hx): fragment planes of W_hh^T (rebuilt per pass) and the zero-initialised h exchange buffer"""
+    lib = _lib.load()
+    return (torch.empty(lib.tpgsr_lstm_wfrag_bytes(), dtype=torch.uint8, device=device),
+            torch.zeros(lib.tpgsr_lstm_seq_hx_bytes(), dtype=torch.uint8, device=device))
+
+
 def lstm_seq_fwd(G, whhT, bhh, Cst, out, hx, sync, N, T, Hh):
     _launch("tpgsr_lstm_seq_fwd", _p(G), _p(whhT), _p(bhh), _p(Cst), _p(out), _p(hx), _p(sync), N, T, Hh)
 
