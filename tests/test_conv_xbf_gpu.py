@@ -16,9 +16,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-# the halo weight-gradient kernel is switched on from 128 input channels up (a performance heuristic, read once per process);
-# this module drives it at 32 and 64 channels as well
-os.environ.setdefault("TPGSR_XBF_WGRAD_HALO_MINC", "32")
+# the halo weight-gradient kernel is switched on from Cin x Cout = 16384 up (a performance heuristic, read once per process);
+# this module drives it on small layers as well
+os.environ.setdefault("TPGSR_XBF_WGRAD_HALO_MINWORK", "0")
 
 from oracle import tpgsr_oracle as O  # noqa: E402
 

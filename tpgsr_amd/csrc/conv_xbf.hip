@@ -1264,12 +1264,13 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
 // geometry test shared by the plan and the launcher
 static bool wgrad_halo_shape_ok(const tpgsr_conv_args* a, int* Lcap_out) {
   const int taps = a->KH * a->KW;
-  // at least four channel blocks (TPGSR_XBF_WGRAD_HALO_MINC overrides): measured at batch 48, the recognizer's 128..512-channel
-  // convolutions gain 15-30 % over the tile loop (conv5 225 -> 157 us) while the 64-channel trunk convolutions lose (42 -> 45 us:
-  // two channel blocks x 128 pixel splits, every workgroup writes a slab for six tiles of work, plus the dy pre-split) and the
-  // whole C3 step came out 1 % slower with them on -- profiles/r02b_wgrad_halo.md
-  static const int minc = [] { const char* e = getenv("TPGSR_XBF_WGRAD_HALO_MINC"); return e ? atoi(e) : 128; }();
-  if (a->Cin < minc) return false;
+  // only where it pays (TPGSR_XBF_WGRAD_HALO_MINWORK overrides the Cin x Cout threshold): measured at batch 48, the recognizer's
+  // 128..512-channel convolutions and the 64->256 upsample convolution gain 15-30 % over the tile loop (conv5 225 -> 157 us,
+  // upsample 156 -> 121 us) while the 64->64 trunk and 64->128 convolutions lose (42 -> 45 us: two channel blocks x 128 pixel
+  // splits, every workgroup writes a slab for six tiles of work, plus the dy pre-split) and the whole C3 step came out 1 % slower
+  // with them on -- profiles/r02b_wgrad_halo.md
+  static const long long minwork = [] { const char* e = getenv("TPGSR_XBF_WGRAD_HALO_MINWORK"); return e ? atoll(e) : 16384ll; }();
+  if ((long long)a->Cin * a->Cout < minwork) return false;
   if (taps < 2 || taps > 12 || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_ps || a->in_b || a->OW + a->KW - 1 < 8) return false;
   const int Lcap = halo_capacity(a);
   if (Lcap > 32 * 9) return false;
