@@ -135,7 +135,7 @@ class LstmLayer:
                 K.lstm_stepx_fwd(G, wfr, self.bhh, Cst, out, hx, N, T, Hh, s)
             self.emb.fwd(N, 1, T, out, e)
             return
-        S = Hh // 32                                          # one 32-deep K chunk per workgroup: 2 * S * 4Hh/64 workgroups
+        S = Hh // (32 * K.LSTM_FWD_KCHUNKS)                   # K-split of the recurrent projection: 2 * S * 4Hh/64 workgroups
         for s in range(T):
             if s > 0:     # gh = h_prev W_hh^T, both directions in one split-K launch (h_prev: time s-1 / T-s of `out`)
                 a = [out.data_ptr() + 4 * ((s - 1 if d == 0 else T - s) * 2 * Hh + d * Hh) for d in range(2)]
@@ -149,7 +149,7 @@ class LstmLayer:
         Hh, G4 = self.Hh, 4 * self.Hh
         self.emb.wgrad(N, 1, T, out, de)
         self.emb.dgrad(N, 1, T, de, dout)
-        S = G4 // 32
+        S = G4 // (32 * K.LSTM_BWD_KCHUNKS)                 # K-split of the recurrent gradient GEMM (K = 4 Hh)
         for s in range(T):
             if s > 0:     # dh_prev = dG[t_next] W_hh (operand [K=4Hh][Hh] is the PyTorch weight itself), split over K
                 a = [G.data_ptr() + 4 * (((T - s if d == 0 else s - 1) * 2 + d) * G4) for d in range(2)]

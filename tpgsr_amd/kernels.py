@@ -697,6 +697,11 @@ def pool2d_bwd(x, dout, N, H, W, C_, scale, shift, act, k, s, pd, dz):
             _p(dz))
 
 
+# 32-deep K chunks per workgroup of the BiLSTM backward's recurrent GEMM (K = 1024): more chunks = fewer slabs for the gate kernel to add
+LSTM_BWD_KCHUNKS = int(os.environ.get("TPGSR_LSTM_BWD_KCHUNKS", "4"))
+LSTM_FWD_KCHUNKS = int(os.environ.get("TPGSR_LSTM_FWD_KCHUNKS", "1"))      # forward: K = 256
+
+
 def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
     """a0 / a1: raw device addresses (ints) of row 0 of the two directions' A operands inside a kept-alive tensor"""
     _launch("tpgsr_lstm_rec_gemm", a0, a1, a_stride, _p(b0), _p(b1), Nrows, Kd, Nc, S, _p(out))
