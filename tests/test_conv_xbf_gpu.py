@@ -471,3 +471,43 @@ def test_wgrad_explicit_split_count_on_tile_loop():
         k.wgrad_reduce(part, None, Z, geom, dw, None, accumulate=False)
         torch.cuda.synchronize()
         assert ((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()).item() < 5e-6, Z
+
+
+
+def test_halo_kernels_strided_operands():
+    """input, output and dy living inside wider buffers (in_ld / in_coff, out_ld / out_coff, dy_ld / dy_coff): forward through the
+    halo kernel and weight gradient through the halo weight-gradient kernel against fp64"""
+    k = K()
+    g = torch.Generator().manual_seed(13)
+    N, H, W, Ci, Co = 4, 8, 25, 64, 96
+    in_ld, in_coff, out_ld, out_coff, dy_ld, dy_coff = 160, 32, 224, 64, 128, 32
+    xfull = torch.randn(N * H * W, in_ld, generator=g)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).double().requires_grad_(True)
+    b = torch.randn(Co, generator=g).double().requires_grad_(True)
+    x = xfull[:, in_coff:in_coff + Ci].reshape(N, H, W, Ci).permute(0, 3, 1, 2).double()
+    y = F.conv2d(x, w, b, padding=1)
+    dyfull = torch.randn(N * H * W, dy_ld, generator=g)
+    dy = dyfull[:, dy_coff:dy_coff + Co].reshape(N, H, W, Co).permute(0, 3, 1, 2).double()
+    y.backward(dy)
+    geom = k.ConvGeom(N, H, W, Ci, Co, 3, 3, 1, 1)
+    wf = w.detach().float().permute(2, 3, 1, 0).reshape(9 * Ci, Co).contiguous().to(DEV)
+    k.make_bf_twin(wf, Ci)
+    xd, dyd, bd = xfull.to(DEV), dyfull.to(DEV), b.detach().float().to(DEV)
+    out = torch.full((N * H * W, out_ld), 7.0, device=DEV)
+    k.conv_fwd(k.make_conv_args(geom, xd, wf, out, bias=bd, in_ld=in_ld, in_coff=in_coff, out_ld=out_ld, out_coff=out_coff))
+    torch.cuda.synchronize()
+    got = out[:, out_coff:out_coff + Co].cpu().double().reshape(N, H, W, Co).permute(0, 3, 1, 2)
+    assert ((got - y.detach()).abs().max() / y.detach().abs().max()).item() < 3e-6
+    rest = torch.cat([out[:, :out_coff], out[:, out_coff + Co:]], 1)
+    assert (rest == 7.0).all(), "columns outside [out_coff, out_coff + Cout) were written"
+    Z = k.wgrad_splits(geom.M, geom.K, Co, geom=geom)
+    part = torch.full((Z, geom.K, Co), float("nan"), device=DEV)
+    dbp = torch.full((Z, Co), float("nan"), device=DEV)
+    wa = k.make_wgrad_args(k.make_conv_args(geom, xd, in_ld=in_ld, in_coff=in_coff), dyd, part, dbp, dy_ld=dy_ld, dy_coff=dy_coff, zsplits=Z)
+    assert wa.dy_bf
+    k.conv_wgrad(wa)
+    dw, db = torch.zeros(Co, Ci, 3, 3, device=DEV), torch.zeros(Co, device=DEV)
+    k.wgrad_reduce(part, dbp, Z, geom, dw, db, accumulate=False)
+    torch.cuda.synchronize()
+    assert ((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()).item() < 5e-6
+    assert ((db.cpu().double() - b.grad).abs().max() / b.grad.abs().max()).item() < 5e-6
