@@ -214,6 +214,9 @@ typedef struct tpgsr_split_desc {
 } tpgsr_split_desc;
 int tpgsr_split_bf_blocks(int K, int N);
 int tpgsr_split_bf_program(const tpgsr_split_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+/* host-only: the halo kernels' LDS entry capacity for this geometry = an upper bound of the halo length of any tile of 64
+ * consecutive output pixels (reads OH, OW, KH, KW) */
+int tpgsr_halo_capacity(const tpgsr_conv_args* a);
 /* diagnostic: time line of the halo convolution kernel.  buf = 8 * 8 * 256 uint64 of device memory ([workgroup][wave][slot],
  * 100 MHz wall-clock stamps, see csrc/conv_xbf.hip) or NULL to switch it off.  Not thread safe; off by default. */
 int tpgsr_halo_trace(unsigned long long* buf);

@@ -170,6 +170,7 @@ _SIGS = {
     "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_tr_probe": (ci, [vp, vp]),
     "tpgsr_halo_trace": (ci, [vp]),
+    "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 

@@ -680,6 +680,8 @@ static int halo_capacity(const tpgsr_conv_args* a) {
   return 63 + row_wraps * (a->KW - 1) + img_wraps * (a->KH - 1) * Wp + (a->KH - 1) * Wp + a->KW;
 }
 
+extern "C" int tpgsr_halo_capacity(const tpgsr_conv_args* a) { return a ? halo_capacity(a) : -1; }   // (host-only; tests/test_halo_host_cpu.py)
+
 #define XBF_HALO_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
 
 // returns 1 when launched, 0 when the shape is not one of the halo kernel's, < 0 on error
