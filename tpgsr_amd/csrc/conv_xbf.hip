@@ -428,9 +428,10 @@ __global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a
   if (wave >= 4) {
     // ------------------------------- producers -------------------------------
     const int pt = tid - 256, aq = pt & 7, er = pt >> 3;      // quad aq of entries er, er + 32, ...
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (size_t)a.N * a.H * a.W * a.in_ld);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (LD & 8) ? (size_t)a.N * a.H * a.W * a.Cin : (size_t)a.N * a.H * a.W * a.in_ld);
     const __amdgpu_buffer_rsrc_t rs_in2 = make_rsrc(a.in2 ? a.in2 : a.in, (size_t)a.N * a.H * a.W * a.in2_ld);
     int hpix[NE];          // of the tile being LOADED; input pixel of entry 32 i + er: >= 0, -1 = padding (stored as zeros), -2 = not part of the halo
+    int hcol[(LD & 8) ? NE : 1];   // un-PixelShuffle gather (LD & 8): hpix holds the image row n H + ih, hcol the column iw
     auto decode_tile = [&](const int t) __attribute__((always_inline)) {
       const int mblk = xcd_remap(t, ntiles) / nbn;
       const int m0 = mblk * 64;
@@ -446,7 +447,12 @@ __global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a
       for (int i = 0; i < NE; ++i) {
         const int ih = r - a.pad_h, iw = sx - a.pad_w;
         const bool in = n < a.N && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        hpix[i] = 32 * i + er < L ? (in ? (n * a.H + ih) * a.W + iw : -1) : -2;
+        if (LD & 8) {
+          hpix[i] = 32 * i + er < L ? (in ? n * a.H + ih : -1) : -2;
+          hcol[i] = iw;
+        } else {
+          hpix[i] = 32 * i + er < L ? (in ? (n * a.H + ih) * a.W + iw : -1) : -2;
+        }
         sx += 32;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -474,7 +480,16 @@ __global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a
         const bool ok = hpix[i] >= 0;
         hr[S][i].ok = ok;
         hr[S][i].raw = hpix[i] > -2;
-        hr[S][i].v = buf_load4(rs_in, ok ? ((unsigned)hpix[i] * (unsigned)a.in_ld + (unsigned)(a.in_coff + c)) * 4u : OOB_OFF);
+        if (LD & 8) {   // logical channels c..c+3 = (cs = c / 4, i, j) of the stored [N][2H][2W][Cin / 4] tensor
+          const unsigned C4 = (unsigned)a.Cin >> 2, W2 = 2u * (unsigned)a.W;
+          const unsigned b = ok ? ((2u * (unsigned)hpix[i] * W2 + 2u * (unsigned)hcol[i]) * C4 + ((unsigned)c >> 2)) * 4u : OOB_OFF;
+          hr[S][i].v.x = buf_load1(rs_in, b);
+          hr[S][i].v.y = buf_load1(rs_in, ok ? b + C4 * 4u : OOB_OFF);
+          hr[S][i].v.z = buf_load1(rs_in, ok ? b + W2 * C4 * 4u : OOB_OFF);
+          hr[S][i].v.w = buf_load1(rs_in, ok ? b + (W2 * C4 + C4) * 4u : OOB_OFF);
+        } else {
+          hr[S][i].v = buf_load4(rs_in, ok ? ((unsigned)hpix[i] * (unsigned)a.in_ld + (unsigned)(a.in_coff + c)) * 4u : OOB_OFF);
+        }
         if (LD & 4) hr[S][i].v2 = buf_load4(rs_in2, ok ? ((unsigned)hpix[i] * (unsigned)a.in2_ld + (unsigned)c) * 4u : OOB_OFF);
       }
       if (LD & 1) {
@@ -688,8 +703,8 @@ extern "C" int tpgsr_halo_capacity(const tpgsr_conv_args* a) { return a ? halo_c
 static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
   static const bool on = [] { const char* e = getenv("TPGSR_XBF_HALO"); return !(e && e[0] == '0'); }();
   const int T = a->terms;
-  if (!on || a->KH * a->KW < 2 || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_ps ||
-      a->in_b || (ld & ~7) || ld == 6 || a->OW + a->KW - 1 < 8)
+  if (!on || a->KH * a->KW < 2 || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 ||
+      a->in_b || ((ld & ~7) && ld != 8) || ld == 6 || a->OW + a->KW - 1 < 8)
     return 0;
   const int Lcap = halo_capacity(a);
   const size_t lds = (size_t)2 * T * Lcap * 64 + 2048;      // two halo buffers + two 1 KB statistics scratch areas
@@ -705,6 +720,7 @@ static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, h
     break;
   switch (ld) {
     XBF_HALO_LD_CASES(XBF_HALO_CASE)
+    XBF_HALO_CASE(8)        // plain un-PixelShuffle gather (the data gradient of the upsample block's convolution)
     default: return 0;
   }
 #undef XBF_HALO_CASE
