@@ -234,12 +234,19 @@ def main():
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TPGSR_BENCH_SHARED_GPU=1 (self-test of the multi-rank code path on a one-GPU box, NOT a measurement): all ranks share
+    # cuda:0 and talk over gloo
+    shared = os.environ.get("TPGSR_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if shared:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from tpgsr_amd import kernels as K
     if args.prec:
