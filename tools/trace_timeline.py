@@ -35,6 +35,18 @@ def main():
         depth += d
         last = t
     print("time with N kernels in flight:", {k: round(v, 1) for k, v in sorted(t_by_depth.items())})
+    # the longest stretches with NOTHING in flight: what ended before, what started after
+    iv = sorted((s, e, n) for n, q, s, e in step)
+    gaps, cur_end, last_name = [], iv[0][1], iv[0][2]
+    for s_, e_, n_ in iv[1:]:
+        if s_ > cur_end:
+            gaps.append(((s_ - cur_end) / 1e3, (cur_end - t0) / 1e3, last_name[:40], n_[:40]))
+        if e_ > cur_end:
+            cur_end, last_name = e_, n_
+    print("idle gaps (us, at us, after, before):")
+    for g in sorted(gaps, reverse=True)[:12]:
+        print(f"   {g[0]:7.1f} at {g[1]:8.1f}   {g[2]}  ->  {g[3]}")
+    print(f"   {len(gaps)} gaps, total {sum(g[0] for g in gaps):.1f} us; of them > 10 us: {sum(g[0] for g in gaps if g[0] > 10):.1f} us")
     # phases: find first bwd kernel (tail_bwd) and optimizer (sumsq)
     for mark in ("tail_bwd_kernel", "sumsq", "adam"):
         for n, q, s, e in step:
