@@ -214,6 +214,24 @@ typedef struct tpgsr_split_desc {
 } tpgsr_split_desc;
 int tpgsr_split_bf_blocks(int K, int N);
 int tpgsr_split_bf_program(const tpgsr_split_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * ASTER evaluation recognizer, greedy decode (model/recognizer/*, interfaces/base.py:844-864): csrc/aster.hip
+ * ---------------------------------------------------------------------------------------------- */
+/* parse_aster_data: out[n][oh][ow][c] = scale * bicubic(in[n][c])(oh, ow) + shift for the first C of Ctot NCHW planes
+ * (F.interpolate(mode='bicubic'), align_corners False; interfaces/base.py:852-858 with scale 2, shift -1) */
+int tpgsr_bicubic_resize(const float* in_nchw, int N, int Ctot, int C, int H, int W, int OH, int OW, float scale, float shift,
+                         float* out_nhwc, void* stream);
+/* AttentionUnit + context (attention_recognition_head.py:196-218, :258-260): xproj [N][T][A], sproj [N][A], wv [A], bv [1], x [N][T][D]
+ * -> alpha [N][T], context [N][D] */
+int tpgsr_aster_attention(const float* xproj, const float* sproj, const float* wv, const float* bv, const float* x, int N, int T, int A,
+                          int D, float* alpha, float* context, void* stream);
+/* out[n] = [ emb[ids[n]] | ctx[n] ]  (tgt_embedding + torch.cat, :262-264) */
+int tpgsr_embed_concat(const int* ids, const float* emb, int V, int E, const float* ctx, int D, int N, float* out, void* stream);
+/* nn.GRU cell gate math from the two projections gi = W_ih x + b_ih, gh = W_hh h + b_hh ([N][3 Hd], gate order r, z, n) */
+int tpgsr_gru_cell(const float* gi, const float* gh, const float* h, int N, int Hd, float* hnew, void* stream);
+/* greedy decision (:60-61): ids[n*ld+col] = first arg-max of logits[n], score[n*ld+col] = its softmax probability; ids_next (optional) [N] */
+int tpgsr_softmax_max(const float* logits, int N, int C, int* ids, float* score, int ld, int col, int* ids_next, void* stream);
+
 /* host-only: the halo kernels' LDS entry capacity for this geometry = an upper bound of the halo length of any tile of 64
  * consecutive output pixels (reads OH, OW, KH, KW) */
 int tpgsr_halo_capacity(const tpgsr_conv_args* a);

@@ -169,6 +169,11 @@ _SIGS = {
     "tpgsr_split_bf_blocks": (ci, [ci, ci]),
     "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_tr_probe": (ci, [vp, vp]),
+    "tpgsr_bicubic_resize": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, cf, cf, vp, vp]),
+    "tpgsr_aster_attention": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_embed_concat": (ci, [vp, vp, ci, ci, vp, ci, ci, vp, vp]),
+    "tpgsr_gru_cell": (ci, [vp, vp, vp, ci, ci, vp, vp]),
+    "tpgsr_softmax_max": (ci, [vp, ci, ci, vp, vp, ci, ci, vp, vp]),
     "tpgsr_halo_trace": (ci, [vp]),
     "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),

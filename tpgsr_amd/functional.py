@@ -637,3 +637,52 @@ def tps_grid(ctrl, inv_kernel, coord_repr, HW):
 
 def grid_sample(x, grid, out_hw, align_corners=False):
     return _GridSample.apply(x, grid, int(out_hw[0]), int(out_hw[1]), bool(align_corners))
+
+
+# ---- evaluation-only helpers of the ASTER recognizer (model/recognizer/*) -------------------------------------------------
+class PackedLinear:
+    """y = x W^T + b with the weight packed (and split, under the bf16 matrix-core policies) ONCE: decode loops call the same
+    nn.Linear a hundred times.  No autograd (evaluation paths only)."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor] = None):
+        _chk(w, b)
+        self.Cout, self.Cin = w.shape
+        self.wt_f, _, _, _, _, _ = _pack(_c(w.detach()).reshape(self.Cout, self.Cin, 1, 1), False, 1.0)
+        self.b = None if b is None else _c(b.detach())
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        _chk(x)
+        x = _c(x)
+        rows = x.numel() // self.Cin
+        out = _new(x, rows, self.Cout)
+        K.conv_fwd(K.make_conv_args(ConvGeom(1, 1, rows, self.Cin, self.Cout), x, self.wt_f, out, bias=self.b))
+        return out
+
+
+def bilstm_eval(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    """one bidirectional LSTM layer, batch-first (N, T, C) -> (N, T, 2 Hh), zero initial state, evaluation only: the input
+    projections of both directions as two linear launches, then per time step the split-K recurrent GEMM + the gate kernel of the
+    text-prior generator (csrc/crnn.hip)"""
+    _chk(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+    if x.requires_grad:
+        raise RuntimeError("bilstm_eval is an evaluation path (no gradient)")
+    with torch.no_grad():
+        N, T, Cin = x.shape
+        Hh = w_hh.shape[1]
+        G4 = 4 * Hh
+        xf = _c(x).reshape(N * T, Cin)
+        G = cat([PackedLinear(w_ih, b_ih)(xf).reshape(N, 1, T, G4), PackedLinear(w_ih_r, b_ih_r)(xf).reshape(N, 1, T, G4)])   # [N][T][2][4Hh]
+        whh = _new(x, 2, Hh, G4)
+        bhh = _new(x, 2, G4)
+        for d, (w, b) in enumerate(((w_hh, b_hh), (w_hh_r, b_hh_r))):
+            K.pack_conv_weight(_c(w.detach()).reshape(G4, Hh, 1, 1), G4, Hh, 1, 1, whh[d], None)
+            K.copy(_c(b.detach()), bhh[d], G4)
+        S = max(1, Hh // 32)
+        gh = _new(x, S, 2, N, G4)
+        Cst, out = _new(x, N, T, 2, Hh), _new(x, N, T, 2 * Hh)
+        for s in range(T):
+            if s > 0:
+                a = [out.data_ptr() + 4 * ((s - 1 if d == 0 else T - s) * 2 * Hh + d * Hh) for d in range(2)]
+                K.lstm_rec_gemm(a[0], a[1], T * 2 * Hh, whh[0], whh[1], N, Hh, G4, S, gh)
+            K.lstm_step_fwd(G, gh if s > 0 else None, S, bhh, Cst, out, N, T, Hh, s)
+        return out

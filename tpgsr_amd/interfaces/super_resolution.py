@@ -332,12 +332,26 @@ class TPGSRTrainStep:
         return self._graph_loss
 
 
+def parse_aster_data(imgs_input: torch.Tensor, max_len: int = 100):
+    """interfaces/base.py:844-864 (fixed-resolution branch): the ASTER recognizer's input dict from (N, C >= 3, H, W) images in [0, 1]:
+    RGB planes, bicubic resize to 32 x 128, [0, 1] -> [-1, 1] -- one HIP kernel; 'rec_targets' / 'rec_lengths' are the reference's dummies"""
+    if not imgs_input.is_cuda:
+        raise RuntimeError("parse_aster_data runs on the GPU only")
+    x = imgs_input.contiguous().float()
+    N, C, H, W = x.shape
+    out = torch.empty(N, 32, 128, 3, device=x.device)
+    K.bicubic_resize(x, N, C, 3, H, W, 32, 128, 2.0, -1.0, out)
+    from .. import functional as Fh
+    return {"images": Fh.to_nchw(out), "rec_targets": torch.ones(N, max_len, dtype=torch.int32), "rec_lengths": [max_len] * N}
+
+
 class TextSREvaluator:
     """The evaluation pass of interfaces/super_resolution.py:540-900 for the `tsrn_tl` / cascade architectures, on the HIP
     kernels end to end: eval-mode networks (BatchNorm from running statistics, folded into the consumer convs' loaders; STN
     skipped, model/tsrn.py:183), per stage: parse_crnn_data -> text-prior generator -> softmax -> (N, 37, 1, 26) prior ->
     SR network; then PSNR / SSIM of the last SR image against HR (tpgsr_psnr / tpgsr_ssim) and recognition of LR / SR / HR by
-    an evaluation recogniser with on-device CTC greedy decoding + string comparison (utils/metrics.py, utils/util.py).
+    an evaluation recogniser -- CRNN with on-device CTC greedy decoding, or the ASTER recognizer (model/recognizer) with its greedy
+    attention decode -- + string comparison (utils/metrics.py, utils/util.py).
     No dropout of the prior, no gradient state, no host round trip before the strings are built."""
 
     def __init__(self, sr_models, tpg_models, recognizer=None, stu_iter=1, sr_share=True, tpg_share=False, voc_type="lower"):
@@ -377,8 +391,14 @@ class TextSREvaluator:
 
     @torch.no_grad()
     def recognize(self, images):
-        """evaluation recogniser + CTC greedy decoding -> list of strings"""
+        """evaluation recogniser -> list of strings.  CRNN (`--test_model CRNN`): CTC greedy decoding; an ASTER `RecognizerBuilder`
+        (`--test_model ASTER`, interfaces/super_resolution.py:107-135): parse_aster_data + its greedy attention decode"""
         from ..utils.metrics import get_string_crnn
+        from ..model.recognizer import RecognizerBuilder
+        if isinstance(self.recognizer, RecognizerBuilder):
+            from ..utils.metrics import get_string_aster, get_vocabulary
+            out = self.recognizer(parse_aster_data(images, self.recognizer.max_len_labels))["output"]
+            return get_string_aster(out["pred_rec"], get_vocabulary("all"))
         x = images.contiguous().float()
         N, C, H, W = x.shape
         gray = torch.empty(N, 1, 32, 100, device=x.device)

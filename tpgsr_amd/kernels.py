@@ -898,3 +898,24 @@ def psnr(a, b, N, Ctot, H, W, partial, nblk, out):
 
 def ssim(a, b, window, KS, N, Ctot, H, W, partial, nblk, out):
     _launch("tpgsr_ssim", _p(a), _p(b), _p(window), KS, N, Ctot, H, W, _p(partial), nblk, _p(out))
+
+
+# ---- ASTER evaluation recognizer, greedy decode (csrc/aster.hip) ----------------------------------------------------
+def bicubic_resize(x_nchw, N, Ctot, C_, H, W, OH, OW, scale, shift, out_nhwc):
+    _launch("tpgsr_bicubic_resize", _p(x_nchw), N, Ctot, C_, H, W, OH, OW, float(scale), float(shift), _p(out_nhwc))
+
+
+def aster_attention(xproj, sproj, wv, bv, x, N, T, A, D, alpha, context):
+    _launch("tpgsr_aster_attention", _p(xproj), _p(sproj), _p(wv), _p(bv), _p(x), N, T, A, D, _p(alpha), _p(context))
+
+
+def embed_concat(ids, emb, V, E, ctx, D, N, out):
+    _launch("tpgsr_embed_concat", _p(ids), _p(emb), V, E, _p(ctx), D, N, _p(out))
+
+
+def gru_cell(gi, gh, h, N, Hd, hnew):
+    _launch("tpgsr_gru_cell", _p(gi), _p(gh), _p(h), N, Hd, _p(hnew))
+
+
+def softmax_max(logits, N, C_, ids, score, ld, col, ids_next=None):
+    _launch("tpgsr_softmax_max", _p(logits), N, C_, _p(ids), _p(score), ld, col, _p(ids_next))

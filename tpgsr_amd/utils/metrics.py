@@ -38,3 +38,27 @@ def str_filt(str_, voc_type):
         if char not in alpha_dict[voc_type]:
             str_ = str_.replace(char, "")
     return str_
+
+
+def get_vocabulary(voc_type="all", EOS="EOS", PADDING="PADDING", UNKNOWN="UNKNOWN"):
+    """utils/labelmaps.py:6-28 (the ASTER recognizer's label set)"""
+    import string
+    voc = {"digit": string.digits, "lower": string.digits + string.ascii_lowercase, "upper": string.digits + string.ascii_letters,
+           "all": string.digits + string.ascii_letters + string.punctuation}[voc_type]
+    return list(voc) + [EOS, PADDING, UNKNOWN]
+
+
+def get_string_aster(output, voc=None, EOS="EOS", UNKNOWN="UNKNOWN"):
+    """prediction half of utils/metrics.py:20-70: (N, max_len) label ids -> strings up to the first EOS, UNKNOWN skipped"""
+    voc = voc or get_vocabulary("all")
+    eos, unk = voc.index(EOS), voc.index(UNKNOWN)
+    out = []
+    for row in output.tolist():
+        chars = []
+        for c in row:
+            if c == eos:
+                break
+            if c != unk:
+                chars.append(voc[c])
+        out.append("".join(chars))
+    return out
