@@ -232,6 +232,9 @@ int tpgsr_gru_cell(const float* gi, const float* gh, const float* h, int N, int 
 /* greedy decision (:60-61): ids[n*ld+col] = first arg-max of logits[n], score[n*ld+col] = its softmax probability; ids_next (optional) [N] */
 int tpgsr_softmax_max(const float* logits, int N, int C, int* ids, float* score, int ld, int col, int* ids_next, void* stream);
 
+/* tuning knob of the halo forward kernel: weight-plane bytes above which tiles are walked column-major per XCD (keeps an XCD's slice of
+ * the weights in its L2); -1 never, 0 whenever the column-tile count allows, default 3 MB.  Results do not depend on it. */
+void tpgsr_halo_set_colmajor_min_bytes(long long v);
 /* host-only: the halo kernels' LDS entry capacity for this geometry = an upper bound of the halo length of any tile of 64
  * consecutive output pixels (reads OH, OW, KH, KW) */
 int tpgsr_halo_capacity(const tpgsr_conv_args* a);

@@ -511,3 +511,21 @@ def test_halo_kernels_strided_operands():
     torch.cuda.synchronize()
     assert ((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()).item() < 5e-6
     assert ((db.cpu().double() - b.grad).abs().max() / b.grad.abs().max()).item() < 5e-6
+
+
+
+@pytest.mark.parametrize("shape", [(9, 4, 26, 64, 512, 3, 3, 1, 1),      # 8 column tiles: one per XCD
+                                   (3, 8, 25, 64, 1024, 3, 3, 1, 1),     # 16 column tiles: two per XCD
+                                   (9, 8, 25, 64, 256, 3, 3, 1, 1),      # 4 column tiles
+                                   (48, 16, 64, 64, 128, 3, 3, 1, 1)])   # 2 column tiles, persistent (several tiles per workgroup)
+def test_halo_kernel_colmajor_tile_order(shape):
+    """the column-major-per-XCD tile order (default only for weight planes > 3 MB) forced on: same results, BN partial rows included"""
+    from tpgsr_amd import _lib
+    lib = _lib.load()
+    lib.tpgsr_halo_set_colmajor_min_bytes(0)
+    try:
+        e_out, e_bn = _halo_case(*shape, affine=False, act=False, resid=False, bn=True, bias=True, seed=17)
+    finally:
+        lib.tpgsr_halo_set_colmajor_min_bytes(3 << 20)
+    print(f"halo col-major {shape}: out {e_out:.2e}  bn {e_bn:.2e}")
+    assert e_out < 3e-6 and e_bn < 2e-5

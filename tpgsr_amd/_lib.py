@@ -176,6 +176,7 @@ _SIGS = {
     "tpgsr_softmax_max": (ci, [vp, ci, ci, vp, vp, ci, ci, vp, vp]),
     "tpgsr_halo_trace": (ci, [vp]),
     "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
+    "tpgsr_halo_set_colmajor_min_bytes": (None, [C.c_longlong]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 

@@ -401,6 +401,19 @@ __device__ unsigned long long* g_halo_trace = nullptr;
       __builtin_nontemporal_store((unsigned long long)wall_clock64(), trace + (blockIdx.x * 8 + wave) * 256 + (slot));                \
   } while (0)
 
+// persistent tile t -> logical tile (m-block major).  Default: every XCD a contiguous range of tiles (neighbouring pixel tiles share
+// halo rows in its L2).  Column-major per XCD (reserved0 bit 0, chosen by the launcher when the split weight planes exceed an L2):
+// block b runs on XCD b % 8 and the grid is a multiple of 8, so tile t = 8 j + x is always handled on XCD x -- give XCD x the column
+// tiles x nper .. (x + 1) nper - 1 (nbn = 8 nper) of ALL pixel tiles: its slice of W (1/8 of the planes) stays in L2 instead of every
+// XCD streaming all of W once per pixel tile (conv5: 178 MB of memory-side reads per launch for 35 MB of operands).  For nbn = 1, 2, 4
+// the plain order t = mblk nbn + nblk already pins column tile t % nbn to XCD t % 8.  Placement only affects speed.
+__device__ __forceinline__ int halo_tile(int t, int ntiles, int nbn, int colmajor) {
+  if (!colmajor) return xcd_remap(t, ntiles);
+  if (nbn < 8) return t;
+  const int nper = nbn >> 3, x = t & 7, j = t >> 3;
+  return (j / nper) * nbn + x * nper + j % nper;
+}
+
 template <int LD, int T, int NE>   // NE: halo entries per producer thread (capacity 32 NE entries)
 __global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a, int M, int Lcap) {
   // PERSISTENT: the grid is what the chip holds at once (two workgroups per CU for the 3x3 x3 shapes); workgroup b runs
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a
     int hpix[NE];          // of the tile being LOADED; input pixel of entry 32 i + er: >= 0, -1 = padding (stored as zeros), -2 = not part of the halo
     int hcol[(LD & 8) ? NE : 1];   // un-PixelShuffle gather (LD & 8): hpix holds the image row n H + ih, hcol the column iw
     auto decode_tile = [&](const int t) __attribute__((always_inline)) {
-      const int mblk = xcd_remap(t, ntiles) / nbn;
+      const int mblk = halo_tile(t, ntiles, nbn, a.reserved0 & 1) / nbn;
       const int m0 = mblk * 64;
       const int q0 = qbase(m0);
       const int L = qbase(min(m0 + 63, M - 1)) - q0 + (a.KH - 1) * Wp + a.KW;     // <= Lcap (host bound)
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(512, 4) void conv_halo_xbf_kernel(tpgsr_conv_args a
   };
   int j = 0, pend_mblk = -1, pend_n0 = 0, ntile_done = 0;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int tile = xcd_remap(t, ntiles);
+    const int tile = halo_tile(t, ntiles, nbn, a.reserved0 & 1);
     const int mblk = tile / nbn;
     const int m0 = mblk * 64, n0 = (tile - mblk * nbn) * 64;
     const int q0 = qbase(m0);
@@ -696,6 +709,11 @@ static int halo_capacity(const tpgsr_conv_args* a) {
 }
 
 extern "C" int tpgsr_halo_capacity(const tpgsr_conv_args* a) { return a ? halo_capacity(a) : -1; }   // (host-only; tests/test_halo_host_cpu.py)
+
+static long long g_nmajor_min_bytes = 3ll << 20;
+/* weight-plane size above which the halo forward kernel walks its tiles column-major per XCD (-1: never; 0: whenever the column-tile
+ * count allows); default 3 MB */
+extern "C" void tpgsr_halo_set_colmajor_min_bytes(long long v) { g_nmajor_min_bytes = v; }
 
 #define XBF_HALO_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
 
@@ -777,6 +795,10 @@ static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, h
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
   int Mi = (int)M, Lc = Lcap;
   tpgsr_conv_args args = *a;
+  // column-major tile order per XCD when the split weight planes would not stay in a 4 MB L2 next to the activations
+  const int nbn = cdiv(a->Cout, 64);
+  const long long w_bytes = (long long)T * a->kp * cdiv(a->Cout, 32) * 32 * 2;
+  args.reserved0 = (g_nmajor_min_bytes >= 0 && w_bytes > g_nmajor_min_bytes && (nbn % 8 == 0 || 8 % nbn == 0) && nbn > 1 && (grid.x % 8 == 0 || grid.x == ntiles)) ? 1 : 0;
   void* params[] = {&args, &Mi, &Lc};
   if (hipLaunchKernel(fn, grid, dim3(512), params, lds, st) != hipSuccess) {
     tpgsr_set_error("tpgsr_conv_fwd(halo): launch failed: %s", hipGetErrorString(hipGetLastError()));
