@@ -235,6 +235,9 @@ int tpgsr_softmax_max(const float* logits, int N, int C, int* ids, float* score,
 /* tuning knob of the halo forward kernel: weight-plane bytes above which tiles are walked column-major per XCD (keeps an XCD's slice of
  * the weights in its L2); -1 never, 0 whenever the column-tile count allows, default 3 MB.  Results do not depend on it. */
 void tpgsr_halo_set_colmajor_min_bytes(long long v);
+/* smallest tap count (KH * KW) the halo forward kernel takes: 2 (default) or 1 (1x1 convolutions with Cin % 32 == 0 as well;
+ * TPGSR_XBF_HALO_MINTAPS=1 at load time).  Results do not depend on it beyond fp32 summation order. */
+void tpgsr_halo_set_min_taps(int v);
 /* host-only: the halo kernels' LDS entry capacity for this geometry = an upper bound of the halo length of any tile of 64
  * consecutive output pixels (reads OH, OW, KH, KW) */
 int tpgsr_halo_capacity(const tpgsr_conv_args* a);

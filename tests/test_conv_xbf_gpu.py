@@ -529,3 +529,22 @@ def test_halo_kernel_colmajor_tile_order(shape):
         lib.tpgsr_halo_set_colmajor_min_bytes(3 << 20)
     print(f"halo col-major {shape}: out {e_out:.2e}  bn {e_bn:.2e}")
     assert e_out < 3e-6 and e_bn < 2e-5
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ((48, 16, 64, 192, 64, 1, 1, 0, 0), dict(affine=False, act=False, resid=False, bn=False, bias=False)),   # GRU projection data gradient
+    ((48, 16, 64, 64, 192, 1, 1, 0, 0), dict(affine=False, act=False, resid=True, bn=False, bias=True)),     # GRU projection (residual-add loader)
+    ((48, 1, 26, 512, 2048, 1, 1, 0, 0), dict(affine=True, act=False, resid=False, bn=False, bias=True)),    # LSTM input projection (T = 26)
+    ((3, 5, 9, 32, 40, 1, 1, 0, 0), dict(affine=True, act=True, resid=False, bn=True, bias=True)),           # ragged everything, one channel block
+])
+def test_halo_kernel_takes_1x1_when_asked(shape, kw):
+    """tpgsr_halo_set_min_taps(1): 1x1 convolutions go through the halo kernel (one tap per channel block, the odd-tap path)"""
+    from tpgsr_amd import _lib
+    lib = _lib.load()
+    lib.tpgsr_halo_set_min_taps(1)
+    try:
+        e_out, e_bn = _halo_case(*shape, seed=23, **kw)
+    finally:
+        lib.tpgsr_halo_set_min_taps(2)
+    print(f"halo 1x1 {shape}: out {e_out:.2e}  bn {e_bn:.2e}")
+    assert e_out < 3e-6 and e_bn < 2e-5

@@ -357,6 +357,30 @@ def test_bn_backward(act):
     assert relerr(dy.cpu(), yr.grad) < 5e-5, relerr(dy.cpu(), yr.grad)
 
 
+@pytest.mark.parametrize("M,C,nblk,two", [(1000, 256, 7, False), (130, 512, 1, True), (3 * 64 + 5, 64, 3, False), (4096, 32, 64, True)])
+def test_bn_backward_reduce_shapes(M, C, nblk, two):
+    """the statistics pass alone (rows per block not a multiple of the 4-row unroll, one / two gradient operands, 4..128 channel
+    quads): per-channel sum dz and sum dz * xhat vs fp64"""
+    k = K()
+    g = torch.Generator().manual_seed(M + C)
+    y = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    da = torch.randn(M, C, generator=g)
+    da2 = torch.randn(M, C, generator=g) if two else None
+    sc = torch.rand(C, generator=g) + 0.5; sh = torch.randn(C, generator=g) * 0.2
+    mean = y.double().mean(0); rstd = 1 / torch.sqrt(y.double().var(0, unbiased=False) + 1e-5)
+    z = y.double() * sc.double() + sh.double()
+    sp = F.softplus(z); t = torch.tanh(sp)
+    dmish = t + z * (1 - t * t) * torch.sigmoid(z)
+    dz = (da.double() + (da2.double() if two else 0.0)) * dmish
+    ref = torch.stack([dz.sum(0), (dz * (y.double() - mean) * rstd).sum(0)])
+    part = torch.full((nblk, 2, C), float("nan"), device=DEV)
+    k.bn_bwd_reduce(da.to(DEV), da2.to(DEV) if two else None, y.to(DEV), M, C, sc.to(DEV), sh.to(DEV), mean.float().to(DEV),
+                    rstd.float().to(DEV), "mish", part, nblk)
+    torch.cuda.synchronize()
+    got = part.double().sum(0).cpu()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-5
+
+
 @pytest.mark.parametrize("pool", [(2, 2), (1, 2), (1, 1)])
 def test_affine_act_pool(pool):
     k = K()

@@ -177,6 +177,7 @@ _SIGS = {
     "tpgsr_halo_trace": (ci, [vp]),
     "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_halo_set_colmajor_min_bytes": (None, [C.c_longlong]),
+    "tpgsr_halo_set_min_taps": (None, [ci]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 

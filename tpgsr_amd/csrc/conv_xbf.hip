@@ -715,13 +715,18 @@ static long long g_nmajor_min_bytes = 3ll << 20;
  * count allows); default 3 MB */
 extern "C" void tpgsr_halo_set_colmajor_min_bytes(long long v) { g_nmajor_min_bytes = v; }
 
+/* smallest tap count the halo kernel takes (default 2; 1 sends 1x1 convolutions with Cin % 32 == 0 through it as well --
+ * TPGSR_XBF_HALO_MINTAPS, experiment switch) */
+static int g_halo_min_taps = [] { const char* e = getenv("TPGSR_XBF_HALO_MINTAPS"); return e && e[0] == '1' ? 1 : 2; }();
+extern "C" void tpgsr_halo_set_min_taps(int v) { g_halo_min_taps = v < 1 ? 1 : v; }
+
 #define XBF_HALO_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
 
 // returns 1 when launched, 0 when the shape is not one of the halo kernel's, < 0 on error
 static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
   static const bool on = [] { const char* e = getenv("TPGSR_XBF_HALO"); return !(e && e[0] == '0'); }();
   const int T = a->terms;
-  if (!on || a->KH * a->KW < 2 || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 ||
+  if (!on || a->KH * a->KW < g_halo_min_taps || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 ||
       a->in_b || ((ld & ~7) && ld != 8) || ld == 6 || a->OW + a->KW - 1 < 8)
     return 0;
   const int Lcap = halo_capacity(a);

@@ -2,6 +2,7 @@
 // activation + max-pool materialisation (STN head), PReLU, layout transposes, small reductions.
 // All tensors are [M][C] row-major (NHWC flattened); channel loops are float4-vectorised when C % 4 == 0.
 #include "common.h"
+#include <type_traits>
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -124,25 +125,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   long long r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
   float4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(save_mean + c), rs = ld4(save_rstd + c);
   float4 s = make_float4(0, 0, 0, 0), sx = make_float4(0, 0, 0, 0);
-  for (long long r = r0 + lane_r; r < r1; r += rl) {
-    float4 g = ld4(da + r * C + c);
-    if (da2) {
-      float4 g2 = ld4(da2 + r * C + c);
-      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+  // four rows' loads in flight per thread (the loop is latency-bound: a block owns ~64 rows, 4 per thread); the sums run in the
+  // same order as a row-at-a-time loop, rows past the end contribute +0.  Two instances (with / without the second gradient
+  // operand) so that no branch -- and with it a full s_waitcnt -- sits between the loads.
+  constexpr int U = 4;
+  auto sweep = [&](auto has2_tag) __attribute__((always_inline)) {
+    constexpr bool HAS2 = decltype(has2_tag)::value;
+    for (long long r = r0 + lane_r; r < r1; r += (long long)U * rl) {
+      float4 g[U], g2[HAS2 ? U : 1], yv[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long rr = r + (long long)u * rl;
+        ok[u] = rr < r1;
+        const long long o = (ok[u] ? rr : r) * C + c;
+        g[u] = ld4(da + o);
+        if (HAS2) g2[u] = ld4(da2 + o);
+        yv[u] = ld4(y + o);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (HAS2) {
+          g[u].x += g2[u].x; g[u].y += g2[u].y; g[u].z += g2[u].z; g[u].w += g2[u].w;
+        }
+        if (!ok[u]) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) {
+          g[u].x *= act_grad(yv[u].x * sc.x + sh.x, act);
+          g[u].y *= act_grad(yv[u].y * sc.y + sh.y, act);
+          g[u].z *= act_grad(yv[u].z * sc.z + sh.z, act);
+          g[u].w *= act_grad(yv[u].w * sc.w + sh.w, act);
+        }
+        s.x += g[u].x; s.y += g[u].y; s.z += g[u].z; s.w += g[u].w;
+        sx.x += g[u].x * (yv[u].x - mu.x) * rs.x;
+        sx.y += g[u].y * (yv[u].y - mu.y) * rs.y;
+        sx.z += g[u].z * (yv[u].z - mu.z) * rs.z;
+        sx.w += g[u].w * (yv[u].w - mu.w) * rs.w;
+      }
     }
-    float4 yv = ld4(y + r * C + c);
-    if (act) {
-      g.x *= act_grad(yv.x * sc.x + sh.x, act);
-      g.y *= act_grad(yv.y * sc.y + sh.y, act);
-      g.z *= act_grad(yv.z * sc.z + sh.z, act);
-      g.w *= act_grad(yv.w * sc.w + sh.w, act);
-    }
-    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-    sx.x += g.x * (yv.x - mu.x) * rs.x;
-    sx.y += g.y * (yv.y - mu.y) * rs.y;
-    sx.z += g.z * (yv.z - mu.z) * rs.z;
-    sx.w += g.w * (yv.w - mu.w) * rs.w;
-  }
+  };
+  if (da2) sweep(std::true_type{}); else sweep(std::false_type{});
   float* a0 = sm + ((size_t)lane_r * 2 + 0) * C + c;
   float* a1 = sm + ((size_t)lane_r * 2 + 1) * C + c;
   *reinterpret_cast<float4*>(a0) = s;
