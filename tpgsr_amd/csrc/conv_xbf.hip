@@ -726,7 +726,7 @@ extern "C" void tpgsr_halo_set_min_taps(int v) { g_halo_min_taps = v < 1 ? 1 : v
 static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
   static const bool on = [] { const char* e = getenv("TPGSR_XBF_HALO"); return !(e && e[0] == '0'); }();
   const int T = a->terms;
-  if (!on || a->KH * a->KW < g_halo_min_taps || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 ||
+  if (!on || a->KH * a->KW < g_halo_min_taps || (a->wt_bf_cin != a->Cin && !(a->KH * a->KW == 1 && a->wt_bf_cin == 0)) || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 ||
       a->in_b || ((ld & ~7) && ld != 8) || ld == 6 || a->OW + a->KW - 1 < 8)
     return 0;
   const int Lcap = halo_capacity(a);

@@ -401,8 +401,6 @@ class _EngineBase:
         self._compose: List[tuple] = []
         self._live: Dict[int, int] = {}      # module-API workspace slot -> generation of the forward that owns it
         self._gen = 0
-        self._external_pack = frozenset()    # slots whose forward plan leaves the operand re-pack to the caller (set_external_pack)
-        self._rec_slot = 0
 
     # ---- workspace slots of the nn.Module API --------------------------------------------------------------------
     # A training-mode forward saves its activations / BN statistics / GRU-LSTM gates in a workspace slot until its
@@ -648,19 +646,7 @@ class TSRNEngine(_EngineBase):
     def plans(self, N, H, W, training, slot=0):
         """slot: independent activation workspace (a shared SR net runs once per cascade stage, each stage's backward
         needs its own saved activations -- interfaces/super_resolution.py:306-385 with --sr_share)"""
-        self._rec_slot = slot
         return self._two_pass((N, H, W, bool(training), slot), lambda ws, final: self._record(N, H, W, training, ws, final))
-
-    def set_external_pack(self, slots):
-        """The TRAINING forward plans of these workspace slots do NOT begin with the operand re-pack (pack_all): the caller issues it
-        itself, once per optimiser step and off the critical path (TPGSRTrainStep packs the SR networks on a side stream while
-        the student recogniser runs; a shared SR network is packed once instead of once per cascade stage).  Every other slot
-        -- the module API's among them -- keeps packing inside its plan."""
-        slots = frozenset(slots)
-        if slots != self._external_pack:
-            for key in [k for k in self._plans if k[-1] in (slots ^ self._external_pack)]:
-                del self._plans[key]
-            self._external_pack = slots
 
     def _record(self, N, H, W, training, ws, final):
         fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
@@ -685,8 +671,7 @@ class TSRNEngine(_EngineBase):
     def _record_fwd(self, N, H, W, training, ws):
         Cc, Ci = self.C, self.in_planes
         P1 = N * H * W
-        if not (training and self._rec_slot in self._external_pack):   # (eval-mode plans always pack for themselves)
-            self.pack_all()
+        self.pack_all()
         x = ws("x_nhwc", P1, Ci)
         K.nchw_to_nhwc(K.DynPtr("x"), N, Ci, H, W, x)
         xin = x

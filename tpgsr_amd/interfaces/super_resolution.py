@@ -5,7 +5,6 @@ no LMDB loaders, logging, evaluation or checkpoint rotation -- SURVEY.md section
 backward; clip_grad_norm_(model, 0.25); Adam(lr 1e-3, betas (0.5, 0.999)).  The whole step is a fixed sequence of
 HIP kernel launches on one stream (forward plan, loss, backward plan, optional RCCL all-reduce of the flat gradient
 arena, clip + Adam), so it can be captured once into a hipGraph and replayed (`capture()`)."""
-import os
 from typing import Optional
 
 import torch
@@ -181,12 +180,6 @@ class TPGSRTrainStep:
         self._dbg = {}
         self._exch = None
         self._overlap_exchange = True      # False while capturing hipGraphs (the all-reduce stays between the graphs)
-        # the SR networks' operand re-pack (GEMM layouts + bf16 split planes of the freshly updated weights) leaves their
-        # forward plans: once per step on its own stream next to the student's forward pass (TPGSR_PACK_ASIDE=0: inside
-        # every SR forward plan, as the module API does)
-        self._pack_aside = os.environ.get("TPGSR_PACK_ASIDE", "1") != "0"
-        for m in self.sr:
-            m._engine().set_external_pack(range(stu_iter) if self._pack_aside else ())
 
     def _buffers(self, lr_img):
         dev, N = lr_img.device, lr_img.shape[0]
@@ -222,13 +215,6 @@ class TPGSRTrainStep:
             K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
             t_logits = self.teacher._engine().forward(st["gray_hr"], False)
             K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
-        pk = None
-        if self._pack_aside:
-            pk = K.aux_stream(lr_img.device, 1)
-            pk.wait_stream(main)
-            with K.stream_ctx(pk):
-                for m in (self.sr[:1] if self.sr_share else self.sr[:self.stu_iter]):
-                    m._engine().pack_all()
         cascade, ch, cw = lr_img, H, W
         srs, logits_keep = [], []
         for i in range(self.stu_iter):
@@ -240,8 +226,6 @@ class TPGSRTrainStep:
                 main.wait_stream(aux)           # the teacher's distribution q is needed from here on
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
             K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
-            if i == 0 and pk is not None:
-                main.wait_stream(pk)            # the SR networks' packed operands
             sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i)
             K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
             n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0

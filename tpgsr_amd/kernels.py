@@ -151,15 +151,15 @@ def side_stream(device=None) -> "torch.cuda.Stream":
 _AUX = {}
 
 
-def aux_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
-    """Further per-device streams for host-level overlap of independent work: 0 -- the frozen teacher recogniser of the
-    text-prior path runs next to the student's forward pass; 1 -- the SR networks' operand packing (same overlap)."""
+def aux_stream(device=None) -> "torch.cuda.Stream":
+    """A further per-device stream for host-level overlap of independent sub-networks (the frozen teacher recogniser of the
+    text-prior path runs on it next to the student's forward pass)."""
     if DRYRUN:
         return _DummyStream()
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    st = _AUX.get((idx, which))
+    st = _AUX.get(idx)
     if st is None:
-        st = _AUX[(idx, which)] = torch.cuda.Stream(device=idx)
+        st = _AUX[idx] = torch.cuda.Stream(device=idx)
     return st
 
 
