@@ -248,6 +248,8 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
+    if os.environ.get("TPGSR_BENCH_MAIN_PRIORITY"):     # experiment switch: the step's main stream at another HIP priority
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["TPGSR_BENCH_MAIN_PRIORITY"])))
     from tpgsr_amd import kernels as K
     if args.prec:
         K.set_conv_prec(args.prec)

@@ -143,7 +143,8 @@ def side_stream(device=None) -> "torch.cuda.Stream":
                 check(-2, "tpgsr_stream_create")
             st = torch.cuda.ExternalStream(raw, device=idx)
         else:
-            st = torch.cuda.Stream(device=idx)
+            # TPGSR_SIDE_PRIORITY (experiment switch): HIP priority of the weight-gradient stream
+            st = torch.cuda.Stream(device=idx, priority=int(os.environ.get("TPGSR_SIDE_PRIORITY", "0")))
         _SIDE[idx] = st
     return st
 
