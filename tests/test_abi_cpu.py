@@ -49,6 +49,27 @@ def test_error_reporting_without_gpu(lib):
     assert lib.tpgsr_version() >= 1
 
 
+def test_conv_rejects_operands_past_the_buffer_window(lib):
+    """the conv loaders address operands with 32-bit byte offsets in a 2 GiB window: a bigger operand is rejected before any
+    launch instead of being read as zeros"""
+    from tpgsr_amd import _lib
+    lib.tpgsr_last_error.restype = ctypes.c_char_p
+    a = _lib.ConvArgs()
+    a.in_ = 0x1000
+    a.wt = 0x2000
+    a.out = 0x3000
+    a.N, a.H, a.W, a.Cin, a.in_ld = 4096, 32, 128, 64, 64            # 4 GiB of fp32 activations
+    a.Cout, a.KH, a.KW, a.pad_h, a.pad_w, a.OH, a.OW, a.out_ld = 64, 3, 3, 1, 1, 32, 128, 64
+    rc = lib.tpgsr_conv_fwd(ctypes.byref(a), None)
+    assert rc == -1 and b"2 GiB" in lib.tpgsr_last_error()
+    a.N = 1024                                                        # 1 GiB input, but a dy of 1024 x 4096 x 640 floats
+    w = _lib.WgradArgs()
+    w.c = a
+    w.dy, w.part, w.dy_ld = 0x4000, 0x5000, 640
+    rc = lib.tpgsr_conv_wgrad(ctypes.byref(w), None)
+    assert rc == -1 and b"2 GiB" in lib.tpgsr_last_error()
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from tpgsr_amd.model import tsrn

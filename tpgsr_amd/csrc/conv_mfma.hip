@@ -336,6 +336,12 @@ static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
                     "%s: vector loader needs 16-byte aligned rows", who);
   if (a->in2) TPGSR_CHECK_ARG(a->in2_ld >= a->Cin && ((a->Cin & 3) || (a->in2_ld & 3) == 0), "%s: bad in2_ld", who);
   TPGSR_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "%s: in_scale/in_shift must come together", who);
+  // the loaders address their operands through buffer resources: 32-bit byte offsets inside a 2 GiB window (make_rsrc).  Fail
+  // loudly instead of reading zeros past it (one operand of bs x 64 channels x 32x128 reaches 2 GiB at bs = 2048).
+  const long long pix = (long long)a->N * a->H * a->W, win = 0x7fffffffll;
+  TPGSR_CHECK_ARG(pix * (a->in_ps ? a->Cin : a->in_ld) * 4 <= win, "%s: input operand exceeds the 2 GiB buffer-addressing window (%lld pixels x %d)",
+                  who, pix, a->in_ps ? a->Cin : a->in_ld);
+  if (a->in2) TPGSR_CHECK_ARG(pix * a->in2_ld * 4 <= win, "%s: second input operand exceeds the 2 GiB buffer-addressing window", who);
   return 0;
 }
 
@@ -616,6 +622,8 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   else TPGSR_CHECK_ARG(w->dy_ld >= a->Cout + w->dy_coff, "tpgsr_conv_wgrad: dy_ld too small");
   long long M = (long long)a->N * a->OH * a->OW;
   int K = a->KH * a->KW * a->Cin;
+  TPGSR_CHECK_ARG(M < (1ll << 31) && M * (w->dy_ps ? a->Cout : w->dy_ld) * 4 <= 0x7fffffffll,
+                  "tpgsr_conv_wgrad: dy exceeds the 2 GiB buffer-addressing window (M %lld)", M);
   int Z, MB;
   wgrad_plan(M, K, a->Cout, &Z, &MB);
   if (w->zsplits > 0) {   // the caller's split count: whole 64-pixel tiles per split (what the halo kernel walks)
