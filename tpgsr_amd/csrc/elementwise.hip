@@ -277,10 +277,20 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   }
 }
 
+__global__ void affine_act_pool_kernel(const float* __restrict__ x, int N, int H, int W, int C, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, int act, int ph, int pw, float* __restrict__ out);
+
 extern "C" int tpgsr_affine_act(const float* x, long long M, int C, const float* scale, const float* shift, int act, float* out,
                                 void* stream) {
-  TPGSR_CHECK_ARG(x && out && M > 0 && C > 0 && (C & 3) == 0, "tpgsr_affine_act: bad arguments (C must be a multiple of 4)");
+  TPGSR_CHECK_ARG(x && out && M > 0 && C > 0, "tpgsr_affine_act: bad arguments");
   TPGSR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "tpgsr_affine_act: scale/shift must come together");
+  if (C & 3) {   // channel counts that are no multiple of 4 (the one-channel offset map of MORAN's rectifier): the scalar 1x1 "pool"
+    TPGSR_CHECK_ARG(M < (1ll << 31), "tpgsr_affine_act: M too large for the scalar path");
+    const long long total = M * C;
+    const int grid = (int)min((long long)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(affine_act_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, 1, 1, (int)M, C, scale, shift, act, 1, 1, out);
+    TPGSR_LAUNCH_CHECK("tpgsr_affine_act");
+  }
   long long total4 = M * C / 4;
   int grid = (int)min((long long)8192, (total4 + 255) / 256);
   hipLaunchKernelGGL(affine_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, total4, C, scale, shift, act, out);

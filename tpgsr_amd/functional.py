@@ -650,11 +650,15 @@ class PackedLinear:
         self.wt_f, _, _, _, _, _ = _pack(_c(w.detach()).reshape(self.Cout, self.Cin, 1, 1), False, 1.0)
         self.b = None if b is None else _c(b.detach())
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        _chk(x)
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out: optional contiguous (rows, Cout) destination (a row block of a decode loop's result)"""
+        _chk(x, out)
         x = _c(x)
         rows = x.numel() // self.Cin
-        out = _new(x, rows, self.Cout)
+        if out is None:
+            out = _new(x, rows, self.Cout)
+        elif not out.is_contiguous() or out.numel() != rows * self.Cout:
+            raise ValueError(f"PackedLinear: out must be a contiguous ({rows}, {self.Cout}) tensor")
         K.conv_fwd(K.make_conv_args(ConvGeom(1, 1, rows, self.Cin, self.Cout), x, self.wt_f, out, bias=self.b))
         return out
 
@@ -686,3 +690,34 @@ def bilstm_eval(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
                 K.lstm_rec_gemm(a[0], a[1], T * 2 * Hh, whh[0], whh[1], N, Hh, G4, S, gh)
             K.lstm_step_fwd(G, gh if s > 0 else None, S, bhh, Cst, out, N, T, Hh, s)
         return out
+
+
+# ---- evaluation-only helpers of the MORAN recognizer (model/moran/*) -------------------------------------------------------
+def signed_relu_pool_diff(x, kernel, stride):
+    """max_pool(relu(x)) - max_pool(relu(-x)) (morn.py:61-63), x NHWC, no autograd: two fused scale-activation-pool launches and a
+    subtraction"""
+    _chk(x)
+    x = _c(x)
+    N, H, W, C = x.shape
+    k = (kernel, kernel) if isinstance(kernel, int) else tuple(kernel)
+    s = (stride, stride) if isinstance(stride, int) else tuple(stride)
+    OH, OW = (H - k[0]) // s[0] + 1, (W - k[1]) // s[1] + 1
+    pos, neg = _new(x, N, OH, OW, C), _new(x, N, OH, OW, C)
+    minus, zero = torch.full((C,), -1.0, dtype=F32, device=x.device), torch.zeros(C, dtype=F32, device=x.device)
+    K.pool2d_fwd(x, N, H, W, C, None, None, "relu", k, s, (0, 0), pos)
+    K.pool2d_fwd(x, N, H, W, C, minus, zero, "relu", k, s, (0, 0), neg)
+    K.scale_(neg, neg.numel(), minus[:1])
+    out = torch.empty_like(pos)
+    K.add(pos, neg, pos.numel(), out)
+    return out
+
+
+def offset_grid_y(grid, dy):
+    """sampling grid (N, H, W, 2) of (x, y) with dy (N, H, W, 1) added to its y coordinates (morn.py:66-67), no autograd"""
+    _chk(grid, dy)
+    grid, dy = _c(grid), _c(dy)
+    out = torch.empty_like(grid)
+    M = grid.numel() // 2
+    K.copy(grid, out, grid.numel())
+    K.copy_strided(dy, 1, 0, out, 2, 1, M, 1, accumulate=True)
+    return out

@@ -345,6 +345,21 @@ def parse_aster_data(imgs_input: torch.Tensor, max_len: int = 100):
     return {"images": Fh.to_nchw(out), "rec_targets": torch.ones(N, max_len, dtype=torch.int32), "rec_lengths": [max_len] * N}
 
 
+def parse_moran_data(imgs_input: torch.Tensor, max_iter: int = 20):
+    """interfaces/base.py:608-632 (fixed-resolution branch): the MORAN recognizer's inputs from (N, C >= 3, H, W) images in [0, 1]:
+    luminance of the bicubic 32 x 100 resize (one HIP kernel, the same as parse_crnn_data's) and the reference's dummy targets --
+    every sample is decoded for max_iter = 20 steps (text = 20 x '0', index 0 of the alphabet).  -> (tensor, length, text, text)"""
+    if not imgs_input.is_cuda:
+        raise RuntimeError("parse_moran_data runs on the GPU only")
+    x = imgs_input.contiguous().float()
+    N, C, H, W = x.shape
+    gray = torch.empty(N, 1, 32, 100, device=x.device)
+    K.bicubic_gray_fwd(x, N, C, H, W, 32, 100, gray)
+    text = torch.zeros(N * max_iter, dtype=torch.long)
+    length = torch.full((N,), max_iter, dtype=torch.int32)
+    return gray, length, text, text
+
+
 class TextSREvaluator:
     """The evaluation pass of interfaces/super_resolution.py:540-900 for the `tsrn_tl` / cascade architectures, on the HIP
     kernels end to end: eval-mode networks (BatchNorm from running statistics, folded into the consumer convs' loaders; STN
@@ -392,13 +407,20 @@ class TextSREvaluator:
     @torch.no_grad()
     def recognize(self, images):
         """evaluation recogniser -> list of strings.  CRNN (`--test_model CRNN`): CTC greedy decoding; an ASTER `RecognizerBuilder`
-        (`--test_model ASTER`, interfaces/super_resolution.py:107-135): parse_aster_data + its greedy attention decode"""
+        (`--test_model ASTER`, interfaces/super_resolution.py:107-135): parse_aster_data + its greedy attention decode; a `MORAN`
+        (`--test_model MORAN`): parse_moran_data + rectifier + its left-to-right attention decoder"""
         from ..utils.metrics import get_string_crnn
         from ..model.recognizer import RecognizerBuilder
         if isinstance(self.recognizer, RecognizerBuilder):
             from ..utils.metrics import get_string_aster, get_vocabulary
             out = self.recognizer(parse_aster_data(images, self.recognizer.max_len_labels))["output"]
             return get_string_aster(out["pred_rec"], get_vocabulary("all"))
+        from ..model.moran import MORAN
+        if isinstance(self.recognizer, MORAN):      # `--test_model MORAN`, interfaces/super_resolution.py:1389-1396
+            from ..utils.metrics import get_string_moran
+            x, length, text, text_rev = parse_moran_data(images)
+            preds = self.recognizer(x, length, text, text_rev, test=True)
+            return get_string_moran(preds[0] if isinstance(preds, tuple) else preds, length)
         x = images.contiguous().float()
         N, C, H, W = x.shape
         gray = torch.empty(N, 1, 32, 100, device=x.device)

@@ -62,3 +62,33 @@ def get_string_aster(output, voc=None, EOS="EOS", UNKNOWN="UNKNOWN"):
                 chars.append(voc[c])
         out.append("".join(chars))
     return out
+
+
+MORAN_ALPHABET = list(string.digits + string.ascii_lowercase + "$")      # interfaces/base.py:589, :232-234 ('$' ends a word)
+
+
+def moran_decode(ids, length, alphabet=None):
+    """strLabelConverterForAttention.decode (utils/utils_moran.py:79-107): flat label ids + per-sample lengths -> strings"""
+    abc = alphabet or MORAN_ALPHABET
+    ids = [int(v) for v in (ids.tolist() if hasattr(ids, "tolist") else ids)]
+    lens = [int(v) for v in (length.tolist() if hasattr(length, "tolist") else length)]
+    if len(ids) != sum(lens):
+        raise ValueError(f"texts with length: {len(ids)} does not match declared length: {sum(lens)}")
+    out, i = [], 0
+    for n in lens:
+        out.append("".join(abc[c] for c in ids[i:i + n]))
+        i += n
+    return out
+
+
+def get_string_moran(preds, length, alphabet=None):
+    """interfaces/super_resolution.py:1393-1396: arg-max of the (sum(length), nclass) class scores of MORAN's left-to-right decoder,
+    decoded, every word cut at its first '$'"""
+    if preds.is_cuda:       # first arg-max per row on the device (tpgsr_softmax_max), like the decoder's own feedback
+        from .. import kernels as K
+        rows, ncls = preds.shape
+        ids = torch.empty(rows, dtype=torch.int32, device=preds.device)
+        K.softmax_max(preds.contiguous().float(), rows, ncls, ids, torch.empty(rows, device=preds.device), 1, 0)
+    else:
+        ids = preds.argmax(1)
+    return [s.split("$")[0] for s in moran_decode(ids, length, alphabet)]
