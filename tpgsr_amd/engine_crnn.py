@@ -319,6 +319,11 @@ class CRNNEngine(_EngineBase):
                 else:
                     xin, ld = t[f"s{pi}"], (dict(in_act="relu", **pbn.loader) if pbn else dict(in_act="relu"))
             conv.wgrad(N, h, w, xin, ds, loader=ld)
+            if i == 3 and K.deferring() and os.environ.get("TPGSR_CRNN_EARLY_REDUCE", "1") != "0":
+                # the slab reduce of everything recorded so far (both BiLSTMs, conv6..conv3: 92 % of the parameters) goes out now and
+                # overlaps with the rest of this backward pass; the reduce at the end of the plan -- on the step's critical tail,
+                # nothing is left to hide it -- then only covers conv2..conv0
+                K.flush_wgrad_reduces()
             da = ws(f"da{i - 1}", N * h * w, conv.Cin)
             conv.dgrad(N, h, w, ds, da)
 
