@@ -76,7 +76,8 @@ typedef struct {
   /* --- bf16 matrix-core path with split fp32 operands (csrc/conv_xbf.hip) --- */
   int terms;              /* 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  3: fp32-equivalent on the bf16 matrix cores: every fp32
                              operand is the exact sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product block.
-                             1: plain bf16 operands, fp32 accumulate.  Needs the vector loader (Cin % 4 == 0) and, for
+                             2: two-term split (a1 b1 + a1 b2 + a2 b1: three MFMAs, ~16 significand bits per operand, what is
+                             dropped is <= 3 * 2^-18 |a b| per product).  1: plain bf16 operands, fp32 accumulate.  Needs the vector loader (Cin % 4 == 0) and, for
                              tpgsr_conv_fwd, wt_bf; otherwise the call silently stays on the fp32 kernel. */
   int kp;                 /* K rounded up to a multiple of 32 = row length of wt_bf */
   const void* wt_bf;      /* `wt` pre-split by tpgsr_split_bf_program: bf16 planes in MFMA fragment order
@@ -391,11 +392,18 @@ int tpgsr_lstm_stepx_fwd(float* G, const void* wfr, const float* bhh, float* Cst
 /* BiLSTM forward as ONE persistent launch (replaces the T x (tpgsr_lstm_rec_gemm + tpgsr_lstm_step_fwd) loop; model/crnn/crnn.py:10,
  * nn.LSTM(bidirectional=True)): Hh == 256, N <= 64.  G / Cst / out as for tpgsr_lstm_step_fwd, whhT [2][Hh][4Hh] = W_hh^T of both
  * directions, bhh [2][4Hh] or NULL.  hx: exchange buffer of tpgsr_lstm_seq_hx_bytes() bytes, ZEROED ONCE by the caller (reusable across
- * calls on one stream); sync: 4 x u32 scratch, zeroed by the call; sync[2] != 0 afterwards = a grid barrier timed out (the 64
- * workgroups were not co-resident within ~1 s) and the result is invalid. */
+ * calls on one stream); sync: 4 x u32 scratch, zeroed by the call; sync[2] != 0 afterwards = a step's hand-off timed out (the 64
+ * workgroups were not co-resident within seconds) and the result is invalid.  csrc/lstm_seq.hip: per-step exchange by write-through
+ * stores + one relaxed arrival counter, no fences. */
 int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hx, unsigned* sync, int N, int T,
                        int Hh, void* stream);
 long long tpgsr_lstm_seq_hx_bytes(void);
+/* BiLSTM backward recurrence (BPTT of nn.LSTM, model/crnn/crnn.py:10) as ONE persistent launch (replaces the T x (tpgsr_lstm_rec_gemm +
+ * tpgsr_lstm_step_bwd) loop): G activated gates in, gate gradients out; dout [N][T][2Hh] = dL/dh; w0 / w1 = weight_hh_l0 / _reverse
+ * [4Hh][Hh] as stored; px: exchange buffer of tpgsr_lstm_seq_px_bytes() bytes (no initialisation); sync as above. */
+int tpgsr_lstm_seq_bwd(float* G, const float* Cst, const float* dout, const float* w0, const float* w1, void* px, unsigned* sync, int N,
+                       int T, int Hh, void* stream);
+long long tpgsr_lstm_seq_px_bytes(void);
 int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, int nsplit, float* dcc, int N, int T,
                         int Hh, int step, void* stream);
 /* p = softmax(logits [N][T][C]); prior (N,C,1,T) = p with samples [0, drop_n) zeroed (prior dropout); with q: partial

@@ -1,0 +1,157 @@
+"""GPU: the persistent BiLSTM recurrences (csrc/lstm_seq.hip: one launch per BiLSTM and pass, 2 x 32 workgroups exchanging h /
+partial dh once per time step by write-through stores + a relaxed arrival counter) against nn.LSTM's gate equations written out in
+fp64 (model/crnn/crnn.py:10 -- gate order i, f, g, o; h0 = c0 = 0) and against the per-step launches they replace."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+Hh = 256
+
+
+def _reference(Gin, WT, b, dout):
+    """fp64 CPU: out [N][T][2Hh], Cst [N][T][2][Hh], activated gates [N][T][2][4Hh], d(loss)/d(Gin) for loss = sum(out * dout)"""
+    N, T = Gin.shape[:2]
+    Gin = Gin.double().cpu().clone().requires_grad_(True)
+    WT, b, dout = WT.double().cpu(), b.double().cpu(), dout.double().cpu()
+    outs, cs, gates = [], [], []
+    for d in range(2):
+        h = torch.zeros(N, Hh, dtype=torch.float64)
+        c = torch.zeros(N, Hh, dtype=torch.float64)
+        hs, cl, gl = [None] * T, [None] * T, [None] * T
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            pre = Gin[:, t, d] + b[d] + h @ WT[d]
+            i, f, g, o = pre.split(Hh, -1)
+            i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            hs[t], cl[t], gl[t] = h, c, torch.cat([i, f, g, o], -1)
+        outs.append(torch.stack(hs, 1))
+        cs.append(torch.stack(cl, 1))
+        gates.append(torch.stack(gl, 1))
+    out = torch.cat(outs, -1)
+    (out * dout).sum().backward()
+    return out.detach(), torch.stack(cs, 2).detach(), torch.stack(gates, 2).detach(), Gin.grad
+
+
+@pytest.mark.parametrize("N,T", [(48, 26), (5, 3), (64, 7), (33, 1)])
+def test_lstm_seq_fwd_bwd_vs_fp64_cell(N, T):
+    from tpgsr_amd import kernels as K
+    g = torch.Generator().manual_seed(100 * N + T)
+    Gin = torch.randn(N, T, 2, 4 * Hh, generator=g).to(DEV)
+    WT = (torch.randn(2, Hh, 4 * Hh, generator=g) / Hh ** 0.5).to(DEV)        # [d][K = Hh][4Hh] = W_hh^T
+    b = torch.randn(2, 4 * Hh, generator=g).to(DEV)
+    dout = torch.randn(N, T, 2 * Hh, generator=g).to(DEV)
+    ref_out, ref_c, ref_gates, ref_dG = _reference(Gin, WT, b, dout)
+
+    hx, sync = K.lstm_seq_buffers(torch.device(DEV))
+    runs = []
+    for rep in range(2):
+        G = Gin.clone()
+        Cst = torch.full((N, T, 2, Hh), float("nan"), device=DEV)
+        out = torch.full((N, T, 2 * Hh), float("nan"), device=DEV)
+        K.lstm_seq_fwd(G, WT, b, Cst, out, hx, sync, N, T, Hh)
+        torch.cuda.synchronize()
+        assert int(sync[2].item()) == 0, "a hand-off of the persistent forward kernel timed out"
+        runs.append((G, Cst, out))
+    G, Cst, out = runs[0]
+    assert all(torch.equal(a, b_) for a, b_ in zip(runs[0], runs[1]))           # fixed accumulation order: bitwise reproducible
+    assert (out.double().cpu() - ref_out).abs().max() < 5e-6
+    assert (Cst.double().cpu() - ref_c).abs().max() < 1e-5
+    assert (G.double().cpu() - ref_gates).abs().max() < 5e-6
+
+    # backward recurrence on the kernel's own saved state; W_hh in PyTorch layout [4Hh][Hh]
+    w = [WT[d].t().contiguous() for d in range(2)]
+    px, syncb = K.lstm_seq_bwd_buffers(torch.device(DEV))
+    got = []
+    for rep in range(2):
+        Gb = G.clone()
+        K.lstm_seq_bwd(Gb, Cst, dout, w[0], w[1], px, syncb, N, T, Hh)
+        torch.cuda.synchronize()
+        assert int(syncb[2].item()) == 0, "a hand-off of the persistent backward kernel timed out"
+        got.append(Gb)
+    assert torch.equal(got[0], got[1])
+    scale = max(1.0, ref_dG.abs().max().item())
+    err = (got[0].double().cpu() - ref_dG).abs().max().item()
+    assert err < 2e-5 * scale, (err, scale)
+
+
+def test_lstm_seq_matches_the_per_step_launches():
+    """same inputs through tpgsr_lstm_rec_gemm + tpgsr_lstm_step_{fwd,bwd} (fp32 matrix cores, split-K slabs) and through the
+    persistent kernels (split bf16 operands): both are fp32-equivalent, so they agree to fp32 rounding"""
+    from tpgsr_amd import kernels as K
+    N, T = 48, 26
+    g = torch.Generator().manual_seed(7)
+    Gin = torch.randn(N, T, 2, 4 * Hh, generator=g).to(DEV)
+    WT = (torch.randn(2, Hh, 4 * Hh, generator=g) / Hh ** 0.5).to(DEV)
+    b = torch.randn(2, 4 * Hh, generator=g).to(DEV)
+    dout = torch.randn(N, T, 2 * Hh, generator=g).to(DEV)
+    w = [WT[d].t().contiguous() for d in range(2)]
+    G4 = 4 * Hh
+    # per-step path (what engine_crnn.LstmLayer records with TPGSR_LSTM_SEQ=0)
+    G1, C1, o1 = Gin.clone(), torch.zeros(N, T, 2, Hh, device=DEV), torch.zeros(N, T, 2 * Hh, device=DEV)
+    S = Hh // 32
+    gh = torch.empty(S, 2, N, G4, device=DEV)
+    for s in range(T):
+        if s > 0:
+            a = [o1.data_ptr() + 4 * ((s - 1 if d == 0 else T - s) * 2 * Hh + d * Hh) for d in range(2)]
+            K.lstm_rec_gemm(a[0], a[1], T * 2 * Hh, WT[0], WT[1], N, Hh, G4, S, gh)
+        K.lstm_step_fwd(G1, gh if s > 0 else None, S, b, C1, o1, N, T, Hh, s)
+    Sb = G4 // (32 * K.LSTM_BWD_KCHUNKS)
+    dhc, dcc = torch.empty(G4 // 32, 2, N, Hh, device=DEV), torch.zeros(N, 2, Hh, device=DEV)
+    G1b = G1.clone()
+    for s in range(T):
+        if s > 0:
+            a = [G1b.data_ptr() + 4 * (((T - s if d == 0 else s - 1) * 2 + d) * G4) for d in range(2)]
+            K.lstm_rec_gemm(a[0], a[1], T * 2 * G4, w[0], w[1], N, G4, Hh, Sb, dhc)
+        K.lstm_step_bwd(G1b, C1, dout, dhc if s > 0 else None, Sb, dcc, N, T, Hh, s)
+    # persistent path
+    hx, sync = K.lstm_seq_buffers(torch.device(DEV))
+    px, syncb = K.lstm_seq_bwd_buffers(torch.device(DEV))
+    G2, C2, o2 = Gin.clone(), torch.zeros(N, T, 2, Hh, device=DEV), torch.zeros(N, T, 2 * Hh, device=DEV)
+    K.lstm_seq_fwd(G2, WT, b, C2, o2, hx, sync, N, T, Hh)
+    G2b = G2.clone()
+    K.lstm_seq_bwd(G2b, C2, dout, w[0], w[1], px, syncb, N, T, Hh)
+    torch.cuda.synchronize()
+    assert int(sync[2].item()) == 0 and int(syncb[2].item()) == 0
+    assert (o1 - o2).abs().max() < 5e-6 and (C1 - C2).abs().max() < 1e-5 and (G1 - G2).abs().max() < 5e-6
+    assert (G1b - G2b).abs().max() < 2e-5 * max(1.0, G1b.abs().max().item())
+
+
+def test_lstm_seq_under_load_from_another_stream():
+    """the hand-offs must not depend on what else keeps the L2s busy / dirty: run the persistent forward next to a stream of
+    large memory-bound kernels and compare bitwise with the quiet run (fixed accumulation order)"""
+    from tpgsr_amd import kernels as K
+    N, T = 48, 26
+    g = torch.Generator().manual_seed(11)
+    Gin = torch.randn(N, T, 2, 4 * Hh, generator=g).to(DEV)
+    WT = (torch.randn(2, Hh, 4 * Hh, generator=g) / Hh ** 0.5).to(DEV)
+    b = torch.randn(2, 4 * Hh, generator=g).to(DEV)
+    dout = torch.randn(N, T, 2 * Hh, generator=g).to(DEV)
+    w = [WT[d].t().contiguous() for d in range(2)]
+    hx, sync = K.lstm_seq_buffers(torch.device(DEV))
+    px, syncb = K.lstm_seq_bwd_buffers(torch.device(DEV))
+
+    def run():
+        G, C, o = Gin.clone(), torch.zeros(N, T, 2, Hh, device=DEV), torch.zeros(N, T, 2 * Hh, device=DEV)
+        K.lstm_seq_fwd(G, WT, b, C, o, hx, sync, N, T, Hh)
+        Gb = G.clone()
+        K.lstm_seq_bwd(Gb, C, dout, w[0], w[1], px, syncb, N, T, Hh)
+        return o, C, Gb
+
+    quiet = run()
+    torch.cuda.synchronize()
+    noise_a, noise_b = torch.randn(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                K.copy(noise_a, noise_b, noise_a.numel())
+                K.add(noise_a, noise_b, noise_a.numel(), noise_b)
+        loaded = run()
+        torch.cuda.synchronize()
+        assert int(sync[2].item()) == 0 and int(syncb[2].item()) == 0
+        for a, b_ in zip(quiet, loaded):
+            assert torch.equal(a, b_)

@@ -128,6 +128,8 @@ _SIGS = {
     "tpgsr_lstm_step_fwd": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_hx_bytes": (C.c_longlong, []),
+    "tpgsr_lstm_seq_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "tpgsr_lstm_seq_px_bytes": (C.c_longlong, []),
     "tpgsr_lstm_wfrag_bytes": (C.c_longlong, []),
     "tpgsr_lstm_wfrag": (ci, [vp, vp, ci, vp]),
     "tpgsr_lstm_stepx_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),

@@ -368,7 +368,7 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   const int ld = loader_bits(a);
   // bf16 matrix cores with split operands (conv_xbf.hip): vector loader + pre-split weights required
   if (a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) {
-    TPGSR_CHECK_ARG(a->terms == 1 || a->terms == 3, "tpgsr_conv_fwd: terms must be 0, 1 or 3");
+    TPGSR_CHECK_ARG(a->terms >= 1 && a->terms <= 3, "tpgsr_conv_fwd: terms must be 0, 1, 2 or 3");
     TPGSR_CHECK_ARG(a->kp >= K && (a->kp & 31) == 0 && ((uintptr_t)a->wt_bf & 15) == 0, "tpgsr_conv_fwd: bad split operand (kp %d, K %d)", a->kp, K);
     return tpgsr_conv_fwd_xbf_launch(a, M, K, ld, st);
   }
@@ -638,7 +638,7 @@ extern "C" int tpgsr_conv_wgrad(const tpgsr_wgrad_args* w, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
   if (a->terms > 0 && (a->Cin & 3) == 0 && (vecY || w->dy_ps)) {
-    TPGSR_CHECK_ARG(a->terms == 1 || a->terms == 3, "tpgsr_conv_wgrad: terms must be 0, 1 or 3");
+    TPGSR_CHECK_ARG(a->terms >= 1 && a->terms <= 3, "tpgsr_conv_wgrad: terms must be 0, 1, 2 or 3");
     const int h = tpgsr_conv_wgrad_halo_launch(w, M, ld, st);
     if (h < 0) return h;
     if (h > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_wgrad(bf16 MFMA, halo)");

@@ -70,6 +70,10 @@ __device__ __forceinline__ floatx16 mfma_terms(const bf16x8 (&a)[T], const bf16x
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
   }
+  if (T == 2) {   // two-term split: a1 b1 + a1 b2 + a2 b1, what is dropped is <= 3 * 2^-18 |a b| per product
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  }
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
@@ -320,6 +324,10 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
             lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], bv[1], lo, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], bv[1], lo, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], bv[0], lo, 0, 0, 0);
+          }
+          if (T == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], bv[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], bv[0], acc[i][j], 0, 0, 0);
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], bv[0], acc[i][j], 0, 0, 0);
         }
@@ -739,6 +747,7 @@ static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, h
 #define XBF_HALO_CASE(B)                                                                                                      \
   case B:                                                                                                                     \
     fn = T == 1 ? (small ? (const void*)conv_halo_xbf_kernel<B, 1, 7> : (const void*)conv_halo_xbf_kernel<B, 1, 9>)           \
+       : T == 2 ? (small ? (const void*)conv_halo_xbf_kernel<B, 2, 7> : (const void*)conv_halo_xbf_kernel<B, 2, 9>)           \
                 : (small ? (const void*)conv_halo_xbf_kernel<B, 3, 7> : (const void*)conv_halo_xbf_kernel<B, 3, 9>);          \
     break;
   switch (ld) {
@@ -837,6 +846,7 @@ extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, 
 #define XBF_FWD_CASE(B)                  \
   case B:                                \
     if (T == 1) { XBF_FWD_T(B, 1) }      \
+    else if (T == 2) { XBF_FWD_T(B, 2) } \
     else { XBF_FWD_T(B, 3) }             \
     break;
   switch (ld) {
@@ -1014,6 +1024,7 @@ extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long 
 #define XBF_WG_CASE(B)                                                                                       \
   case B:                                                                                                    \
     if (T == 1) hipLaunchKernelGGL((conv_wgrad_xbf_kernel<B, 1>), grid, dim3(256), 0, st, *w, (int)M, K, MB); \
+    else if (T == 2) hipLaunchKernelGGL((conv_wgrad_xbf_kernel<B, 2>), grid, dim3(256), 0, st, *w, (int)M, K, MB); \
     else hipLaunchKernelGGL((conv_wgrad_xbf_kernel<B, 3>), grid, dim3(256), 0, st, *w, (int)M, K, MB);        \
     break;
   switch (ld) {
@@ -1364,6 +1375,9 @@ extern "C" int tpgsr_conv_wgrad_halo_launch(const tpgsr_wgrad_args* w, long long
     if (T == 1)
       hipLaunchKernelGGL(dy_split_kernel<1>, g, dim3(256), 0, st, w->dy, w->dy_ld, w->dy_coff, w->dy_ps, (int)M, a->Cout, a->OH, a->OW,
                          (unsigned short*)w->dy_bf, MB16, NB32);
+    else if (T == 2)
+      hipLaunchKernelGGL(dy_split_kernel<2>, g, dim3(256), 0, st, w->dy, w->dy_ld, w->dy_coff, w->dy_ps, (int)M, a->Cout, a->OH, a->OW,
+                         (unsigned short*)w->dy_bf, MB16, NB32);
     else
       hipLaunchKernelGGL(dy_split_kernel<3>, g, dim3(256), 0, st, w->dy, w->dy_ld, w->dy_coff, w->dy_ps, (int)M, a->Cout, a->OH, a->OW,
                          (unsigned short*)w->dy_bf, MB16, NB32);
@@ -1373,6 +1387,7 @@ extern "C" int tpgsr_conv_wgrad_halo_launch(const tpgsr_wgrad_args* w, long long
 #define XBF_WGH_CASE(B)                                                                                                          \
   case B:                                                                                                                        \
     fn = T == 1 ? (small ? (const void*)conv_wgrad_halo_kernel<B, 1, 7> : (const void*)conv_wgrad_halo_kernel<B, 1, 9>)          \
+       : T == 2 ? (small ? (const void*)conv_wgrad_halo_kernel<B, 2, 7> : (const void*)conv_wgrad_halo_kernel<B, 2, 9>)          \
                 : (small ? (const void*)conv_wgrad_halo_kernel<B, 3, 7> : (const void*)conv_wgrad_halo_kernel<B, 3, 9>);         \
     break;
   switch (ld) {

@@ -482,7 +482,8 @@ extern "C" int tpgsr_lstm_step_fwd(float* G, const float* gh, int nsplit, const 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// BiLSTM forward as ONE persistent launch (Hh = 256, N <= 64): 2 x 32 workgroups, workgroup (d, u) owns hidden units
+// Helpers shared with lstm_seq.hip (BiLSTM forward / backward as ONE persistent launch each).  Exchange layout of the forward pass:
+// 2 x 32 workgroups, workgroup (d, u) owns hidden units
 // 8u .. 8u+7 of direction d -- its 32 gate columns of W_hh^T stay in LDS, pre-split into three bf16 terms in MFMA fragment order,
 // for all T steps.  Per step every workgroup computes  gh[n][32 cols] = h_prev[n][256] x W[256][32]  on the bf16 matrix cores with
 // split operands (fp32-equivalent, as the conv kernels), adds the input projections, runs the gate math for its 8 units of
@@ -507,137 +508,7 @@ __device__ __forceinline__ void ls_split3(float x, unsigned short (&h)[3]) {
   h[2] = __builtin_bit_cast(unsigned short, c);
 }
 
-__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G, const float* __restrict__ whhT,
-                                                           const float* __restrict__ bhh, float* __restrict__ Cst,
-                                                           float* __restrict__ out, unsigned short* __restrict__ hx,
-                                                           unsigned* __restrict__ sync, int N, int T) {
-  constexpr int Hh = 256, G4 = 1024;
-  // one LDS object: W fragments [3 terms][16 k-blocks][64 lanes][8] bf16 (48 KB) | partial sums [2 k-halves][64 rows][32 cols] f32 (16 KB)
-  // | cell state [64][8] f32 (2 KB)
-  __shared__ __attribute__((aligned(16))) unsigned char lsm[48 * 1024 + 16 * 1024 + 2 * 1024];
-  unsigned short* wfr = reinterpret_cast<unsigned short*>(lsm);
-  float* red = reinterpret_cast<float*>(lsm + 48 * 1024);
-  float* cst = reinterpret_cast<float*>(lsm + 64 * 1024);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int d = blockIdx.x / LS_NW, u0 = (blockIdx.x % LS_NW) * 8;
-  const float* W = whhT + (size_t)d * Hh * G4;
-  // W fragments: B operand of k-block kb: lane l holds column c = l & 31 (gate c >> 3, unit u0 + (c & 7)), k = 16 kb + 8 (l >> 5) + j
-  for (int idx = tid; idx < 16 * 64; idx += 256) {
-    const int kb = idx >> 6, l = idx & 63, c = l & 31;
-    const int col = (c >> 3) * Hh + u0 + (c & 7);
-    unsigned short hv[8][3];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ls_split3(W[(size_t)(kb * 16 + (l >> 5) * 8 + j) * G4 + col], hv[j]);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      unsigned short* dst = wfr + ((size_t)(t * 16 + kb) * 64 + l) * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dst[j] = hv[j][t];
-    }
-  }
-  for (int i = tid; i < 64 * 8; i += 256) cst[i] = 0.f;
-  __syncthreads();
-  const int rb = wave & 1, kh = wave >> 1;
-  const size_t par_elems = (size_t)2 * 3 * 2 * 16 * 512;       // elements per parity buffer
-  for (int s = 0; s < T; ++s) {
-    const int t = d == 0 ? s : T - 1 - s;
-    if (s > 0) {
-      // gh partial of this wave: row block rb, k-blocks 8 kh .. 8 kh + 7
-      const unsigned short* hp = hx + ((size_t)((s - 1) & 1) * par_elems) + (size_t)d * 3 * 2 * 16 * 512;
-      floatx16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      ls_u32x4 av[8][3];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt)
-          av[i][tt] = *reinterpret_cast<const ls_u32x4*>(hp + (((size_t)(tt * 2 + rb) * 16 + kh * 8 + i) * 64 + lane) * 8);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        ls_bf16x8 a[3], b[3];
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
-          a[tt] = __builtin_bit_cast(ls_bf16x8, av[i][tt]);
-          b[tt] = *reinterpret_cast<const ls_bf16x8*>(wfr + ((size_t)(tt * 16 + kh * 8 + i) * 64 + lane) * 8);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        red[(kh * 64 + row) * 32 + (lane & 31)] = acc[r];
-      }
-      __syncthreads();
-    }
-    // gate math: item = (sequence n, local unit ul)
-    unsigned short* hw = hx + ((size_t)(s & 1) * par_elems) + (size_t)d * 3 * 2 * 16 * 512;
-    for (int item = tid; item < N * 8; item += 256) {
-      const int n = item >> 3, ul = item & 7, unit = u0 + ul;
-      float* g = G + (((size_t)n * T + t) * 2 + d) * G4;
-      const float* b = bhh ? bhh + (size_t)d * G4 : nullptr;
-      float pre[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pre[q] = g[q * Hh + unit] + (b ? b[q * Hh + unit] : 0.f);
-        if (s > 0) pre[q] += red[n * 32 + q * 8 + ul] + red[(64 + n) * 32 + q * 8 + ul];
-      }
-      const float ig = sigmoid_f(pre[0]), fg = sigmoid_f(pre[1]), gg = tanh_f(pre[2]), og = sigmoid_f(pre[3]);
-      const float c = fg * cst[item] + ig * gg;
-      const float h = og * tanh_f(c);
-      cst[item] = c;
-      g[unit] = ig;
-      g[Hh + unit] = fg;
-      g[2 * Hh + unit] = gg;
-      g[3 * Hh + unit] = og;
-      Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = c;
-      out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = h;
-      unsigned short hv[3];
-      ls_split3(h, hv);
-      const int kb = unit >> 4, ln = ((unit >> 3) & 1) * 32 + (n & 31);
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) hw[(((size_t)(tt * 2 + (n >> 5)) * 16 + kb) * 64 + ln) * 8 + (unit & 7)] = hv[tt];
-    }
-    if (s + 1 < T) {   // direction-local grid barrier: everybody's h of this step is visible before anybody's next GEMM
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&sync[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (unsigned)(s + 1) * LS_NW;
-        int spins = 0;
-        while (__hip_atomic_load(&sync[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 22)) {   // ~1 s: a workgroup never arrived (not co-resident?) -- flag it and fall through rather than hang
-            __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-    }
-  }
-}
-
-extern "C" int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hx, unsigned* sync, int N,
-                                  int T, int Hh, void* stream) {
-  TPGSR_CHECK_ARG(G && whhT && Cst && out && hx && sync && N > 0 && N <= 64 && T > 0 && Hh == 256,
-                  "tpgsr_lstm_seq_fwd: needs Hh == 256, 1 <= N <= 64, T >= 1 and non-null buffers (got Hh %d, N %d, T %d)", Hh, N, T);
-  if (hipMemsetAsync(sync, 0, 4 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
-    tpgsr_set_error("tpgsr_lstm_seq_fwd: hipMemsetAsync failed");
-    return TPGSR_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(2 * LS_NW), dim3(256), 0, (hipStream_t)stream, G, whhT, bhh, Cst, out, (unsigned short*)hx,
-                     sync, N, T);
-  TPGSR_LAUNCH_CHECK("tpgsr_lstm_seq_fwd");
-}
+// (the persistent kernels themselves live in lstm_seq.hip)
 /* bytes of the exchange buffer `hx` of tpgsr_lstm_seq_fwd */
 extern "C" long long tpgsr_lstm_seq_hx_bytes(void) { return 2ll * 2 * 3 * 2 * 16 * 512 * 2; }
 

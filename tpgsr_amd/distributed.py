@@ -41,15 +41,22 @@ class GradientExchanger:
     xGMI sizing: MI355X links are point-to-point (7 x ~153 GB/s), a ring all-reduce is per-link bound, so buckets are
     as large as the dependency structure allows (two for C3/C4: 14 MB + 33 MB) rather than DDP's 25 MB default."""
 
-    def __init__(self, flat_grad: torch.Tensor, bounds, group=None, scale_fn=None):
+    def __init__(self, flat_grad: torch.Tensor, bounds, group=None, scale_fn=None, force: bool = False):
+        """force: issue the collectives at world size 1 too (one rank: the all-reduce is the identity, the average a multiplication
+        by 1.0) -- how a one-GPU box drives RCCL's stream semantics through exactly the code path of an 8-GPU job"""
         self.flat, self.group = flat_grad, group
         self.bounds = [(int(a), int(b)) for a, b in bounds]
         self.scale_fn = scale_fn
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force) and dist.is_available() and dist.is_initialized())
+        self._work = {}
+
+    def begin(self):
+        """start of a step: forget handles a failed step left behind (a step that raised after launch(0) never reached finish())"""
         self._work = {}
 
     def launch(self, b: int):
-        if self.world == 1:
+        if not self.active:
             return
         if b in self._work:
             raise RuntimeError(f"bucket {b} was already launched in this step")
@@ -58,7 +65,7 @@ class GradientExchanger:
 
     def finish(self):
         """launch whatever has not been launched, wait for everything, average"""
-        if self.world == 1:
+        if not self.active:
             return
         for b in range(len(self.bounds)):
             if b not in self._work:
@@ -87,15 +94,35 @@ class DataParallel(torch.nn.Module):
         self.module = module
         self.process_group = process_group
         self._inv = None
-        module._grad_sync = self._sync
-        if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
-            dev = next(module.parameters()).device
-            eng = module._engine()
-            eng.bind(dev)
-            broadcast_state(eng.arena.flat, module.buffers(), 0, process_group)
+        self._fused = callable(getattr(module, "_engine", None))
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        if self._fused:
+            module._grad_sync = self._sync          # called by the module's fused autograd node at the end of its backward pass
+        else:
+            # operator-by-operator networks (SRResNet_TL / RDN_TL / VDSR_TL / SRCNN_TL, ASTER, MORAN: no fused engine, ordinary
+            # autograd): average every parameter gradient as soon as autograd has accumulated it, like DDP without buckets
+            self._hooks = [p.register_post_accumulate_grad_hook(self._sync_param) for p in module.parameters() if p.requires_grad]
+        if broadcast and multi:
+            if self._fused:
+                dev = next(module.parameters()).device
+                eng = module._engine()
+                eng.bind(dev)
+                broadcast_state(eng.arena.flat, module.buffers(), 0, process_group)
+            else:
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, 0, group=process_group)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def _sync_param(self, p):
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.process_group)
+        if world == 1 or p.grad is None:
+            return
+        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        p.grad.mul_(1.0 / world)
 
     def _sync(self, eng):
         if not (dist.is_available() and dist.is_initialized()):

@@ -643,12 +643,16 @@ class TSRNEngine(_EngineBase):
             self.NC = self.B["tps.target_control_points"].shape[0]
 
     # ------------------------------------------------------------------------------------------------------------
-    def plans(self, N, H, W, training, slot=0):
+    def plans(self, N, H, W, training, slot=0, defer_join=False):
         """slot: independent activation workspace (a shared SR net runs once per cascade stage, each stage's backward
-        needs its own saved activations -- interfaces/super_resolution.py:306-385 with --sr_share)"""
-        return self._two_pass((N, H, W, bool(training), slot), lambda ws, final: self._record(N, H, W, training, ws, final))
+        needs its own saved activations -- interfaces/super_resolution.py:306-385 with --sr_share).
+        defer_join: the backward plan does NOT end by joining the weight-gradient stream -- the caller orders its stream after the
+        side stream before anything reads the parameter gradients (TPGSRTrainStep at world size 1: the student's backward pass
+        starts while this network's weight gradients are still running; ONE join before the optimiser)"""
+        return self._two_pass((N, H, W, bool(training), slot, bool(defer_join)),
+                              lambda ws, final: self._record(N, H, W, training, ws, final, bool(defer_join)))
 
-    def _record(self, N, H, W, training, ws, final):
+    def _record(self, N, H, W, training, ws, final, defer_join=False):
         fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
         fwd.final = bwd.final = final
         bwd.overlap = self.overlap_wgrad
@@ -664,7 +668,8 @@ class TSRNEngine(_EngineBase):
                 if self.defer_reduce:
                     K.flush_wgrad_reduces()
                 self.flush_compose_bwd()
-                bwd.join()
+                if not defer_join:
+                    bwd.join()
         return dict(fwd=fwd, bwd=bwd, ws=ws)
 
     # ---- forward -------------------------------------------------------------------------------------------------
@@ -918,14 +923,15 @@ class TSRNEngine(_EngineBase):
                 conv.dgrad(N, h, w, ds, dact)
 
     # ---- execution -----------------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None, slot: int = 0,
+                defer_join: bool = False) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.module.in_planes:
             raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
         if not x.is_cuda and not K.DRYRUN:
             raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
         self.bind(x.device)
         N, _, H, W = x.shape
-        pl = self.plans(N, H, W, training, slot)
+        pl = self.plans(N, H, W, training, slot, defer_join and training)
         x = x.contiguous().float()
         sr = torch.empty(N, self.in_planes, 2 * H, 2 * W, dtype=F32, device=x.device)
         fwd = pl["fwd"]
@@ -944,9 +950,9 @@ class TSRNEngine(_EngineBase):
         return sr
 
 
-    def backward(self, x_shape, sr: torch.Tensor, dsr: torch.Tensor, slot: int = 0):
+    def backward(self, x_shape, sr: torch.Tensor, dsr: torch.Tensor, slot: int = 0, defer_join: bool = False):
         N, _, H, W = x_shape
-        pl = self.plans(N, H, W, True, slot)
+        pl = self.plans(N, H, W, True, slot, defer_join)
         self.arena.attach_grads()
         bwd = pl["bwd"]
         dsr = dsr.contiguous().float()

@@ -150,7 +150,16 @@ class LstmLayer:
         self.emb.wgrad(N, 1, T, out, de)
         self.emb.dgrad(N, 1, T, de, dout)
         S = G4 // (32 * K.LSTM_BWD_KCHUNKS)                 # K-split of the recurrent gradient GEMM (K = 4 Hh)
-        for s in range(T):
+        seq = K.LSTM_SEQ_BWD and Hh == 256 and N <= 64
+        if seq:                                              # the whole BPTT recurrence as one persistent launch
+            if not hasattr(self, "_seqb"):
+                self._seqb = {}
+            key = K.current_stream().cuda_stream
+            if key not in self._seqb:
+                self._seqb[key] = K.lstm_seq_bwd_buffers(self.eng.device)
+            px, sync = self._seqb[key]
+            K.lstm_seq_bwd(G, Cst, dout, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], px, sync, N, T, Hh)
+        for s in range(0 if seq else T):
             if s > 0:     # dh_prev = dG[t_next] W_hh (operand [K=4Hh][Hh] is the PyTorch weight itself), split over K
                 a = [G.data_ptr() + 4 * (((T - s if d == 0 else s - 1) * 2 + d) * G4) for d in range(2)]
                 K.lstm_rec_gemm(a[0], a[1], T * 2 * G4, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], N, G4, Hh, S, dhc)

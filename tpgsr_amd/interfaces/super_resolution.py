@@ -5,6 +5,7 @@ no LMDB loaders, logging, evaluation or checkpoint rotation -- SURVEY.md section
 backward; clip_grad_norm_(model, 0.25); Adam(lr 1e-3, betas (0.5, 0.999)).  The whole step is a fixed sequence of
 HIP kernel launches on one stream (forward plan, loss, backward plan, optional RCCL all-reduce of the flat gradient
 arena, clip + Adam), so it can be captured once into a hipGraph and replayed (`capture()`)."""
+import os
 from typing import Optional
 
 import torch
@@ -19,8 +20,9 @@ _NBLK = 128
 
 class TSRNTrainStep:
     def __init__(self, model, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
-                 process_group=None, world_size: int = 1):
+                 process_group=None, world_size: int = 1, force_collectives: bool = False):
         self.model = model
+        self.collective = world_size > 1 or bool(force_collectives)   # force: drive RCCL at world size 1 too (tests)
         self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
         self.pool = ArenaPool([model])
         self.opt = FusedAdam([model], lr=lr, betas=betas, clip_modules=[model], max_norm=max_norm, pool=self.pool)
@@ -62,12 +64,12 @@ class TSRNTrainStep:
         if self._exch is None or self._exch.flat.data_ptr() != self.pool.grad.data_ptr():
             inv = self._static["inv_world"]
             self._exch = GradientExchanger(self.pool.grad, [(0, self.pool.grad.numel())], self.pg,
-                                           scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv))
+                                           scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv), force=self.collective)
         return self._exch
 
     def _exchange(self):
         """ONE flat bucket: RCCL all-reduce (sum) of the gradient arena over xGMI, then the 1/world average"""
-        if self.world > 1:
+        if self.collective:
             self._exchanger().finish()
 
     def _phase_b(self):
@@ -164,7 +166,9 @@ class TPGSRTrainStep:
     over SR nets + students."""
 
     def __init__(self, sr_models, students, teacher, stu_iter=1, sr_share=True, tpg_share=False, gradient=True,
-                 loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1):
+                 loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1,
+                 force_collectives=False):
+        self.collective = world_size > 1 or bool(force_collectives)   # force: drive RCCL at world size 1 too (tests)
         self.sr = list(sr_models) if isinstance(sr_models, (list, tuple)) else [sr_models]
         self.stu = list(students) if isinstance(students, (list, tuple)) else [students]
         self.teacher = teacher
@@ -180,6 +184,10 @@ class TPGSRTrainStep:
         self._dbg = {}
         self._exch = None
         self._overlap_exchange = True      # False while capturing hipGraphs (the all-reduce stays between the graphs)
+        # world size 1: nothing reads the SR network's parameter gradients before the optimiser, so its backward plan does not join the
+        # weight-gradient stream at its end (the student's backward pass starts right away); _join_side() orders the main stream after
+        # it before clip + Adam.  With a gradient exchange the bucket launch right after the SR backward needs them: the plan joins.
+        self._defer_join = (not self.collective) and os.environ.get("TPGSR_DEFER_JOIN", "1") != "0"
 
     def _buffers(self, lr_img):
         dev, N = lr_img.device, lr_img.shape[0]
@@ -206,6 +214,8 @@ class TPGSRTrainStep:
         H2, W2 = 2 * H, 2 * W
         hr = hr_img.contiguous()
         lr_img = lr_img.contiguous()
+        if self.collective:
+            self._exchanger().begin()
         self.opt.zero_grad()
         # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
         # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
@@ -226,7 +236,7 @@ class TPGSRTrainStep:
                 main.wait_stream(aux)           # the teacher's distribution q is needed from here on
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
             K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
-            sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i)
+            sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join)
             K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
             n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
             K.image_loss_finalize(st["part_img"][i], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
@@ -245,8 +255,8 @@ class TPGSRTrainStep:
             K.image_loss_bwd(srs[i], hr, st["dloss"], N, C, H2, W2, self.gradient, self.w0, self.w1, st["dsr"][i])
             if i < self.stu_iter - 1:      # gradient arriving through the next stage's parse_crnn_data
                 K.add(st["dsr"][i], st["dcas"], st["dsr"][i].numel(), st["dsr"][i])
-            dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i)
-            if i == 0 and self.world > 1 and self._overlap_exchange:
+            dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i, defer_join=self._defer_join)
+            if i == 0 and self.collective and self._overlap_exchange:
                 # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
                 self._exchanger().launch(0)
             K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
@@ -257,6 +267,7 @@ class TPGSRTrainStep:
             if i > 0:
                 self._dbg_dgray = dgray
                 K.bicubic_gray_bwd(dgray, N, C, H2, W2, 32, 100, st["dcas"])
+        self._join_side(lr_img.device)
         self.last_sr, self.last_p = srs[-1], st["p"][self.stu_iter - 1]
         return st["loss"]
 
@@ -265,13 +276,17 @@ class TPGSRTrainStep:
             inv = self._static["inv_world"]
             b_sr, b_stu = self.pool.span(self.sr), self.pool.span(self.stu)
             self._exch = GradientExchanger(self.pool.grad, [b_sr, (b_sr[1], b_stu[1])], self.pg,
-                                           scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv))
+                                           scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv), force=self.collective)
         return self._exch
 
     def _exchange(self):
         """two buckets of ONE flat buffer (SR nets | students); bucket 0 was launched inside the backward pass"""
-        if self.world > 1:
+        if self.collective:
             self._exchanger().finish()
+
+    def _join_side(self, device):
+        if self._defer_join and not K.DRYRUN:
+            K.current_stream().wait_stream(K.side_stream(device))
 
     def _phase_b(self):
         self.opt.step()
@@ -307,11 +322,14 @@ class TPGSRTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()
-        self._overlap_exchange = False
-        with torch.cuda.graph(ga):
-            self._graph_loss = self._phase_a(self._lr, self._hr)
-            if self.world == 1:
-                self._phase_b()
+        self._overlap_exchange = False       # the all-reduce stays between the two graphs ...
+        try:
+            with torch.cuda.graph(ga):
+                self._graph_loss = self._phase_a(self._lr, self._hr)
+                if self.world == 1:
+                    self._phase_b()
+        finally:
+            self._overlap_exchange = True    # ... and eager step() calls after a capture overlap it with the backward pass again
         self._graph, self._graph_b = ga, None
         if self.world > 1:
             gb = torch.cuda.CUDAGraph()

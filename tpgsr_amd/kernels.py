@@ -33,7 +33,11 @@ DRYRUN = os.environ.get("TPGSR_PLAN_DRYRUN") == "1"
 #            FORWARD pass of the text-prior generator (CRNN) stays fp32-equivalent, so the arg-max text priors are identical
 #            to the fp32 oracle's by construction; fp32 accumulation, activations, statistics, losses and optimiser throughout
 # CONV_TERMS is the value make_conv_args stamps into launches while a plan is recorded / a kernel is called directly.
-_TERMS = {"f32": 0, "x3": 3, "bf16": 1}
+#   "x2"   : two-term split (3 MFMAs per product block instead of 6, ~16 significand bits per operand: 256x tighter than bf16) in the SR
+#            network and in every backward pass; the FORWARD pass of the text-prior generator stays fp32-equivalent like under
+#            "bf16" (TPGSR_X2_TPG_FWD=2 lowers it as well)
+_TERMS = {"f32": 0, "x3": 3, "bf16": 1, "x2": 2}
+_X2_TPG_FWD = int(os.environ.get("TPGSR_X2_TPG_FWD", "3"))
 POLICY = os.environ.get("TPGSR_CONV_PREC", "x3")
 if POLICY not in _TERMS:
     raise ValueError(f"TPGSR_CONV_PREC={POLICY!r}: expected one of {sorted(_TERMS)}")
@@ -43,7 +47,7 @@ CONV_TERMS = _TERMS[POLICY]
 
 
 def set_conv_prec(name: str):
-    """'f32' | 'x3' | 'bf16' for plans recorded from now on (engines bound earlier keep their recorded plans)"""
+    """'f32' | 'x3' | 'x2' | 'bf16' for plans recorded from now on (engines bound earlier keep their recorded plans)"""
     global CONV_TERMS, POLICY
     POLICY, CONV_TERMS = name, _TERMS[name]
 
@@ -52,6 +56,8 @@ def terms_for(net_kind: str, phase: str) -> int:
     """what an engine records under the current policy; net_kind 'sr' | 'tpg' (text-prior generator), phase 'fwd' | 'bwd'"""
     if POLICY == "bf16":
         return 3 if (net_kind == "tpg" and phase == "fwd") else 1
+    if POLICY == "x2":
+        return _X2_TPG_FWD if (net_kind == "tpg" and phase == "fwd") else 2
     return _TERMS[POLICY]
 
 
@@ -708,10 +714,11 @@ def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
     _launch("tpgsr_lstm_rec_gemm", a0, a1, a_stride, _p(b0), _p(b1), Nrows, Kd, Nc, S, _p(out))
 
 
-# persistent BiLSTM forward (Hh == 256, N <= 64): ONE launch with a grid barrier per time step instead of two launches per step.
-# Correct (the CRNN parity tests pass with it) but measured SLOWER on MI355X -- C3 10.15 vs 9.99 ms/step: the per-step agent-scope
-# release / acquire pair costs more than the two ~5 us launches it replaces while other streams keep the L2 dirty -- so it is opt-in
-LSTM_SEQ = os.environ.get("TPGSR_LSTM_SEQ", "0") == "1"
+# persistent BiLSTM recurrences (Hh == 256, N <= 64): ONE launch per BiLSTM and pass instead of two launches per time step
+# (csrc/lstm_seq.hip: per-step exchange between the 2 x 32 workgroups by write-through stores + one relaxed arrival counter).
+# TPGSR_LSTM_SEQ=0 records the per-step launches (tpgsr_lstm_rec_gemm + tpgsr_lstm_step_{fwd,bwd}) instead.
+LSTM_SEQ = os.environ.get("TPGSR_LSTM_SEQ", "1") == "1"
+LSTM_SEQ_BWD = os.environ.get("TPGSR_LSTM_SEQ_BWD", "1" if LSTM_SEQ else "0") == "1"
 
 
 # fused recurrent projection + gate step (Hh == 256, N <= 64): one 32-workgroup launch per time step instead of a 128-workgroup
@@ -743,6 +750,16 @@ def lstm_seq_buffers(device):
     """(hx, sync) for lstm_seq_fwd: the exchange buffer must start zeroed (rows of sequences >= N are never written)"""
     hx = torch.zeros(_lib.load().tpgsr_lstm_seq_hx_bytes(), dtype=torch.uint8, device=device)
     return hx, torch.zeros(4, dtype=torch.int32, device=device)
+
+
+def lstm_seq_bwd(G, Cst, dout, w0, w1, px, sync, N, T, Hh):
+    _launch("tpgsr_lstm_seq_bwd", _p(G), _p(Cst), _p(dout), _p(w0), _p(w1), _p(px), _p(sync), N, T, Hh)
+
+
+def lstm_seq_bwd_buffers(device):
+    """(px, sync) for lstm_seq_bwd (no initialisation needed: every word read in a step was written in the step before)"""
+    px = torch.empty(_lib.load().tpgsr_lstm_seq_px_bytes(), dtype=torch.uint8, device=device)
+    return px, torch.zeros(4, dtype=torch.int32, device=device)
 
 
 def lstm_step_fwd(G, gh, nsplit, bhh, Cst, out, N, T, Hh, step):
