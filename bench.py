@@ -15,9 +15,10 @@ student -- all hand-written HIP kernels behind libtpgsr_hip.so.  `--gpus N` runs
   --config c2: TSRN without text prior (BASELINE configs[1], fp32)       --config c5: stu_iter 3, sr_share, bs 32 (configs[4])
 
 Prints ONE JSON line (rank 0).  `value` = whole-job img/s with inputs resident in HBM.  `roofline` is measured live:
-the dominant kernel's launches (the MFMA implicit-GEMM conv: every conv / linear forward + data-gradient launch of the
-step, taken from the recorded plans of all networks) are replayed between HIP events on the stream they run on;
-`traffic` is null here (PMC counters need rocprofv3: the per-launch HBM bytes measured that way are in profiles/).
+the dominant kernel family's launches (the MFMA implicit-GEMM convolution: every conv / linear forward, data-gradient and
+weight-gradient launch of the step, taken from the recorded plans of all networks) are replayed between HIP events on the stream
+they run on, shape by shape;
+`traffic` comes from two rocprofv3 PMC passes over a few steps of the same workload (tools/pmc_step.sh; --no-traffic skips them).
 `cpu_baseline` times the CPU oracle (oracle/tpgsr_oracle.py, a port of the reference's step pinned against the imported
 reference) on this box's host cores -- rank 0, N=1 only, a bounded sample."""
 import argparse
@@ -45,11 +46,14 @@ CONFIGS = {
     "c5": dict(batch=32, stu_iter=3, tl=True, mb_per_img=242.0, gflop_per_img=31.7,
                name="C5: TPGSR-TSRN multi-stage, stu_iter 3, sr_share, three CRNN students + frozen teacher, full train step"),
 }
-DOMINANT = ("tpgsr_conv_fwd",)   # forward + data-gradient instances of the MFMA implicit-GEMM conv
 K_POLICY = "f32"
 ARITH = {"f32": "fp32 operands on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), fp32 accumulate",
          "x3": "fp32-equivalent: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product block, fp32 accumulate "
                "(csrc/conv_xbf.hip); everything else fp32",
+         "x3b2": "forward passes fp32-equivalent (x3: split into 3 bf16 terms, 6 MFMAs per product block); backward GEMMs (data and weight "
+                 "gradients) on the two-term split (3 MFMAs per product block); fp32 accumulate everywhere",
+         "x2": "two-term split: every fp32 operand as the sum of TWO bf16 terms (16 significand bits), 3 bf16 MFMAs per product block, fp32 "
+               "accumulate, in the SR network and all backward GEMMs; the text-prior generator's forward stays fp32-equivalent (x3)",
          "bf16": "bf16 operands (RNE from fp32) on the bf16 matrix cores with fp32 accumulation in the SR network and all backward "
                  "GEMMs; the text-prior generator's forward stays fp32-equivalent (split operands) so arg-max priors are identical "
                  "to the fp32 oracle; activations / statistics / recurrences / losses / optimiser fp32"}
@@ -57,40 +61,28 @@ ARITH = {"f32": "fp32 operands on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
 
 def synthetic_batch(n, seed, device):
     """HR = U[0,1) RGB + luminance-threshold mask channel; LR = 2x average pool of HR with its own mask."""
-    g = torch.Generator().manual_seed(seed)
-    hr = torch.rand(n, 3, LR_HW[0] * 2, LR_HW[1] * 2, generator=g)
-    lr = torch.nn.functional.avg_pool2d(hr, 2)
-
-    def add_mask(img):
-        lum = 0.299 * img[:, 0:1] + 0.587 * img[:, 1:2] + 0.114 * img[:, 2:3]
-        return torch.cat([img, (lum <= lum.mean(dim=(1, 2, 3), keepdim=True)).float()], 1)
-
-    return add_mask(lr).contiguous().to(device), add_mask(hr).contiguous().to(device)
+    from tpgsr_amd.utils.synthetic import synthetic_batch as sb
+    lr, hr = sb(n, seed, lr_hw=LR_HW)
+    return lr.to(device), hr.to(device)
 
 
 def build_step(cfg_key, dev, world=1, pg=None):
-    """networks (weights by recipe: no pretrained files exist) + the train-step driver of the chosen configuration"""
-    from oracle import tpgsr_oracle as O  # weights-by-recipe only (no oracle compute in the timed path)
+    """networks (weights by recipe: no pretrained files exist) + the train-step driver of the chosen configuration.
+    Product code only: the CPU oracle is not needed to build or run the benchmarked step."""
     from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep, TSRNTrainStep
     from tpgsr_amd.model import tsrn
     from tpgsr_amd.model.crnn import crnn
+    from tpgsr_amd.utils.synthetic import init_by_recipe
     cfg = CONFIGS[cfg_key]
     if not cfg["tl"]:
-        net = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
-        net.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 1234, tps_hw=LR_HW))
+        net = init_by_recipe(tsrn.TSRN(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 1234)
         net = net.to(dev).train()
         ts = TSRNTrainStep(net, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
                            process_group=pg, world_size=world)
         return ts, [net]
-    sr = tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
-    sr.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 11, tps_hw=LR_HW))
-    teacher = crnn.CRNN(32, 1, 37, 256)
-    teacher.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 12))
-    students = []
-    for k in range(cfg["stu_iter"]):
-        s = crnn.CRNN(32, 1, 37, 256)
-        s.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 13 + k))
-        students.append(s.to(dev).train())
+    sr = init_by_recipe(tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 11)
+    teacher = init_by_recipe(crnn.CRNN(32, 1, 37, 256), 12)
+    students = [init_by_recipe(crnn.CRNN(32, 1, 37, 256), 13 + k).to(dev).train() for k in range(cfg["stu_iter"])]
     ts = TPGSRTrainStep([sr.to(dev).train()], students, teacher.to(dev).eval(), stu_iter=cfg["stu_iter"], sr_share=True,
                         tpg_share=False, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
                         process_group=pg, world_size=world)
@@ -99,48 +91,107 @@ def build_step(cfg_key, dev, world=1, pg=None):
 
 PEAK_BY_TERMS = {0: FP32_MFMA_PEAK_TFLOPS,          # v_mfma_f32_32x32x2_f32
                  3: BF16_MFMA_PEAK_TFLOPS / 6.0,    # fp32-equivalent: six v_mfma_f32_32x32x16_bf16 per product block
+                 2: BF16_MFMA_PEAK_TFLOPS / 3.0,    # two-term split: three MFMAs per product block
                  1: BF16_MFMA_PEAK_TFLOPS}          # bf16 operands
+TERMS_NAME = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 3: "x3: split operands, 6 x v_mfma_f32_32x32x16_bf16 per block (fp32-equivalent)",
+              2: "x2: two-term split, 3 x v_mfma_f32_32x32x16_bf16 per block", 1: "bf16 operands, 1 x v_mfma_f32_32x32x16_bf16 per block"}
+
+
+def conv_family(nets):
+    """Every launch of the MFMA implicit-GEMM convolution family in ONE training step, from the recorded plans of all networks:
+    forward / data-gradient launches (tpgsr_conv_fwd), weight-gradient launches (tpgsr_conv_wgrad: the launch includes the dy
+    pre-split of the halo kernel) and the slab reduces that finish them (no FLOPs of their own, their time is charged to `wgrad`)."""
+    items = []
+    for net in nets:
+        for pl in net._engine()._plans.values():
+            for pname in ("fwd", "bwd"):
+                for name, fn, args, _sid in pl[pname].ops:
+                    if name == "tpgsr_conv_fwd":
+                        a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
+                        kind, terms = ("fwd" if pname == "fwd" else "dgrad"), (a.terms if (a.terms and a.wt_bf) else 0)
+                    elif name == "tpgsr_conv_wgrad":
+                        a = args[0]._obj.c
+                        kind, terms = "wgrad", a.terms
+                    elif name in ("tpgsr_wgrad_reduce_program", "tpgsr_wgrad_reduce"):
+                        items.append(dict(kind="wgrad", terms=None, shape=("slab reduce",), flops=0.0, bytes=0.0, fn=fn, args=args))
+                        continue
+                    else:
+                        continue
+                    M, K = a.N * a.OH * a.OW, a.KH * a.KW * a.Cin
+                    # algorithmic bytes (SURVEY 8d): the input once + the output once (fwd / dgrad); input + dy once (wgrad), fp32
+                    nbytes = 4.0 * (a.N * a.H * a.W * a.Cin + M * a.Cout)
+                    items.append(dict(kind=kind, terms=terms, shape=(a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW), flops=2.0 * M * K * a.Cout,
+                                      bytes=nbytes, fn=fn, args=args))
+    return items
 
 
 def conv_roofline(nets, reps=5):
-    """Replay only the dominant kernel's launches (forward + data-gradient instances of the MFMA implicit-GEMM conv) of one
-    training step -- every recorded plan of every network -- bracketed by HIP events on the launch stream, one timed pass
-    per arithmetic class (fp32 MFMA / split-operand bf16 MFMA / bf16 operands: they have different peaks);
-    algorithmic FLOPs = 2*M*K*Cout per launch from the recorded launch geometry.
-    frac = (time the launches would take at their class's peak) / (measured time)."""
-    classes = {}
-    for net in nets:
-        for pl in net._engine()._plans.values():
-            for plan in (pl["fwd"], pl["bwd"]):
-                for name, fn, args, _sid in plan.ops:
-                    if name in DOMINANT:
-                        a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
-                        t = a.terms if (a.terms and a.wt_bf) else 0
-                        c = classes.setdefault(t, dict(ops=[], flops=0.0))
-                        c["flops"] += 2.0 * (a.N * a.OH * a.OW) * (a.KH * a.KW * a.Cin) * a.Cout
-                        c["ops"].append((fn, args))
+    """Replay the convolution family's launches of one training step, shape group by shape group, bracketed by HIP events on the
+    stream they are launched on.  achieved = algorithmic FLOPs (2 M K Cout per launch, from the recorded geometry) / measured time;
+    peak = what the same launches would need at the peak of their arithmetic class (x3: 2500/6, x2: 2500/3, bf16: 2500, fp32 MFMA
+    157.3 TFLOP/s), i.e. frac = time at peak / measured time -- over the WHOLE family, weight gradients and their slab reduces included."""
+    items = conv_family(nets)
+    groups = {}
+    for it in items:
+        groups.setdefault((it["kind"], it["terms"], it["shape"]), []).append(it)
     s = torch.cuda.current_stream().cuda_stream
-    out = {}
-    for t, c in sorted(classes.items()):
-        for fn, args in c["ops"]:      # warm
-            fn(*args, s)
+    rows = []
+    for (kind, terms, shape), its in groups.items():
+        for it in its:      # warm
+            it["fn"](*it["args"], s)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            for fn, args in c["ops"]:
-                fn(*args, s)
+            for it in its:
+                it["fn"](*it["args"], s)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        out[t] = dict(launches=len(c["ops"]), gflop=c["flops"] / 1e9, ms=ms, tflops=c["flops"] / (ms * 1e-3) / 1e12,
-                      peak=PEAK_BY_TERMS[t])
-    flops = sum(c["gflop"] for c in out.values()) * 1e9
-    ms = sum(c["ms"] for c in out.values())
-    ms_at_peak = sum(c["gflop"] * 1e9 / (c["peak"] * 1e12) * 1e3 for c in out.values())
-    n = sum(c["launches"] for c in out.values())
-    return dict(launches=n, flops_per_step=flops, ms_per_step=ms, by_class=out, avg_us_per_launch=1e3 * ms / n,
-                tflops=flops / (ms * 1e-3) / 1e12, frac=ms_at_peak / ms, peak=flops / (ms_at_peak * 1e-3) / 1e12)
+        flops = sum(it["flops"] for it in its)
+        peak = PEAK_BY_TERMS.get(terms)
+        rows.append(dict(kind=kind, terms=terms, shape=shape, launches=len(its), ms=ms, flops=flops, bytes=sum(it["bytes"] for it in its),
+                         ms_at_peak=(flops / (peak * 1e12) * 1e3) if peak else 0.0))
+
+    def agg(sel):
+        r = [x for x in rows if sel(x)]
+        ms, flops, at_peak = sum(x["ms"] for x in r), sum(x["flops"] for x in r), sum(x["ms_at_peak"] for x in r)
+        n = sum(x["launches"] for x in r if x["terms"] is not None)
+        return dict(launches=n, gflop=flops / 1e9, ms=ms, tflops=flops / (ms * 1e-3) / 1e12 if ms else 0.0,
+                    peak=flops / (at_peak * 1e-3) / 1e12 if at_peak else 0.0, frac=at_peak / ms if ms else 0.0,
+                    alg_bytes=sum(x["bytes"] for x in r))
+
+    total = agg(lambda x: True)
+    by_kind = {"fwd+dgrad": agg(lambda x: x["kind"] in ("fwd", "dgrad")), "wgrad (+ dy split + slab reduce)": agg(lambda x: x["kind"] == "wgrad")}
+    by_terms = {TERMS_NAME[t]: agg(lambda x, t=t: x["terms"] == t) for t in sorted({x["terms"] for x in rows if x["terms"] is not None})}
+    table = []
+    for x in sorted(rows, key=lambda x: -x["ms"]):
+        if x["terms"] is None:
+            table.append(dict(kind="wgrad slab reduce", launches=x["launches"], us_per_launch=round(1e3 * x["ms"] / x["launches"], 1)))
+            continue
+        N_, H_, W_, Ci, Co, KH, KW = x["shape"]
+        table.append(dict(kind=x["kind"], shape=f"N{N_} {H_}x{W_} {Ci}->{Co} {KH}x{KW}", terms=x["terms"], launches=x["launches"],
+                          us_per_launch=round(1e3 * x["ms"] / x["launches"], 1), tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1),
+                          frac=round(x["ms_at_peak"] / x["ms"], 3)))
+    return dict(total=total, by_kind=by_kind, by_terms=by_terms, table=table)
+
+
+def measure_traffic(cfg_key, timeout_s=400):
+    """HBM bytes of one training step from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 passes (--pmc with --kernel-trace only), each scaled by a calibration launch of known byte count taken in the same pass
+    (FETCH_SIZE under-reports wide streaming reads by 2x on gfx950).  tools/pmc_step.sh; None when rocprofv3 is not there or fails."""
+    import shutil
+    import subprocess
+    if not shutil.which("rocprofv3"):
+        return None
+    out = os.path.join("gpurun_out", "bench_pmc")
+    try:
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_step.sh"), out, cfg_key, "4"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=timeout_s, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+        return json.load(open(os.path.join(ROOT, out, "traffic.json")))
+    except Exception as e:   # report, never hide
+        _log(f"traffic measurement failed: {type(e).__name__}: {e}")
+        return None
 
 
 def _log(msg):
@@ -214,13 +265,14 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
-    ap.add_argument("--prec", choices=["f32", "x3", "bf16"], default=None,
+    ap.add_argument("--prec", choices=["f32", "x3", "x3b2", "x2", "bf16"], default=None,
                     help="arithmetic of the MFMA GEMMs (default: TPGSR_CONV_PREC or the library default), see tpgsr_amd/kernels.py")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured hipGraph (default: plain launches on several HIP streams; measured "
                          "faster because ROCm executes the graph's fork/join branches serially)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic (~1 min)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -303,7 +355,7 @@ def main():
             "metric": "training img/s (16x64->32x128, bs=%d/GPU), %s full train step" % (B, "TPGSR-TSRN" if cfg["tl"] else "TSRN"),
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "x3": "f32", "bf16": "bf16"}[K_POLICY], "data": "synthetic",
+            "dtype": {"f32": "f32", "x3": "bf16x3", "x3b2": "bf16x3 fwd / bf16x2 bwd", "x2": "bf16x2", "bf16": "bf16"}[K_POLICY], "arithmetic_policy": K_POLICY, "data": "synthetic",
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
@@ -314,26 +366,37 @@ def main():
         _log(f"timed region done: {ms:.3f} ms/step")
         if not args.no_roofline:
             r = conv_roofline(nets)
-            names = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 3: "fp32-equivalent: split operands, 6 x v_mfma_f32_32x32x16_bf16",
-                     1: "bf16 operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate"}
-            out["roofline"] = {"kernel": "MFMA implicit-GEMM conv (all conv / linear forward + data-gradient launches of the step: "
-                                         "SR net, student and teacher recognisers)",
-                               "bound": "mfma", "achieved": round(r["tflops"], 2), "peak": round(r["peak"], 1),
-                               "unit": "TFLOP/s", "frac": round(r["frac"], 4), "traffic": None,
-                               "peak_note": "time-weighted over the arithmetic classes of the launches: fp32 MFMA 157.3; "
-                                            "split-operand (fp32-equivalent) 2500/6 = 416.7; bf16 operands 2500 (dense)",
-                               "frac_of_fp32_mfma_peak": round(r["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "launches_per_step": r["launches"],
-                               "by_class": {names[t]: {"launches": c["launches"], "gflop": round(c["gflop"], 2), "ms": round(c["ms"], 4),
-                                                       "tflops": round(c["tflops"], 2), "peak": round(c["peak"], 1)}
-                                            for t, c in r["by_class"].items()},
-                               "avg_us_per_launch": round(r["avg_us_per_launch"], 2),
-                               "gflop_per_launch": round(r["flops_per_step"] / r["launches"] / 1e9, 4),
-                               "share_of_step_ms": round(r["ms_per_step"], 4),
+            t = r["total"]
+            traffic = measure_traffic(args.config) if (world == 1 and not args.no_traffic) else None
+            fam = ("conv fwd/dgrad (halo)", "conv fwd/dgrad (tile loop)", "conv wgrad", "dy_split", "wgrad slab reduce")
+            fam_bytes = None
+            if traffic:
+                fam_bytes = sum(traffic[k]["by_class"].get(c, 0) for k in ("fetch", "write") for c in fam)
+
+            def rnd(d):
+                return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
+
+            out["roofline"] = {"kernel": "MFMA implicit-GEMM convolution family: every conv / linear forward, data-gradient AND weight-gradient "
+                                         "launch of the step (SR net, student and teacher recognisers), slab reduces and dy pre-splits charged to the weight gradients",
+                               "bound": "mfma", "achieved": round(t["tflops"], 2), "peak": round(t["peak"], 1), "unit": "TFLOP/s",
+                               "frac": round(t["frac"], 4),
+                               "traffic": round(fam_bytes / t["launches"]) if fam_bytes else None,
+                               "traffic_note": "HBM-side bytes per launch (mean over the family's launches): FETCH_SIZE + WRITE_SIZE of the family's kernels in one "
+                                               "training step, two rocprofv3 --pmc passes, calibrated in-pass (tools/pmc_step.sh); algorithmic_bytes_per_launch beside it",
+                               "algorithmic_bytes_per_launch": round(t["alg_bytes"] / t["launches"]),
+                               "peak_note": "time-weighted over the arithmetic classes of the launches: fp32 MFMA 157.3; x3 2500/6 = 416.7; x2 2500/3 = 833.3; "
+                                            "bf16 operands 2500 (dense bf16 MFMA peak, MI355X_MICROARCH.md)",
+                               "launches_per_step": t["launches"], "gflop_per_step": round(t["gflop"], 2), "ms_per_step_replayed": round(t["ms"], 4),
+                               "avg_us_per_launch": round(1e3 * t["ms"] / t["launches"], 2),
+                               "by_kind": {k: rnd(v) for k, v in r["by_kind"].items()}, "by_class": {k: rnd(v) for k, v in r["by_terms"].items()},
+                               "per_shape": r["table"][:16],
                                "measured_fp32_mfma_only_peak": round(mfma_probe_tflops(), 1)}
             # whole-step view against SURVEY 8d's algorithmic constants (fp32 bytes / FLOPs per image per step)
             out["step_roofline"] = {"hbm_frac": round(value / world * cfg["mb_per_img"] * 1e6 / 8.0e12, 4),
-                                    "fp32_flop_frac": round(value / world * cfg["gflop_per_img"] * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)}
+                                    "fp32_flop_frac": round(value / world * cfg["gflop_per_img"] * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+                                    "hbm_bytes_per_step_pmc": round(traffic["hbm_bytes_per_step"]) if traffic else None,
+                                    "algorithmic_bytes_per_step": round(cfg["mb_per_img"] * 1e6 * B),
+                                    "hbm_traffic_by_class_pmc": ({k: traffic[k]["by_class"] for k in ("fetch", "write")} if traffic else None)}
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args.config)

@@ -36,7 +36,10 @@ DRYRUN = os.environ.get("TPGSR_PLAN_DRYRUN") == "1"
 #   "x2"   : two-term split (3 MFMAs per product block instead of 6, ~16 significand bits per operand: 256x tighter than bf16) in the SR
 #            network and in every backward pass; the FORWARD pass of the text-prior generator stays fp32-equivalent like under
 #            "bf16" (TPGSR_X2_TPG_FWD=2 lowers it as well)
-_TERMS = {"f32": 0, "x3": 3, "bf16": 1, "x2": 2}
+#   "x3b2" : forward passes fp32-equivalent (x3: SR images, text priors and losses are those of "x3" bit for bit), every BACKWARD GEMM
+#            (data and weight gradients) on the two-term split: per product 3 * 2^-18 relative, i.e. the size of the rounding noise an
+#            fp32 GEMM's own accumulation order leaves in a gradient (tests/test_policy_x2_gpu.py measures both against fp64)
+_TERMS = {"f32": 0, "x3": 3, "bf16": 1, "x2": 2, "x3b2": 3}
 _X2_TPG_FWD = int(os.environ.get("TPGSR_X2_TPG_FWD", "3"))
 POLICY = os.environ.get("TPGSR_CONV_PREC", "x3")
 if POLICY not in _TERMS:
@@ -47,7 +50,7 @@ CONV_TERMS = _TERMS[POLICY]
 
 
 def set_conv_prec(name: str):
-    """'f32' | 'x3' | 'x2' | 'bf16' for plans recorded from now on (engines bound earlier keep their recorded plans)"""
+    """'f32' | 'x3' | 'x3b2' | 'x2' | 'bf16' for plans recorded from now on (engines bound earlier keep their recorded plans)"""
     global CONV_TERMS, POLICY
     POLICY, CONV_TERMS = name, _TERMS[name]
 
@@ -58,6 +61,8 @@ def terms_for(net_kind: str, phase: str) -> int:
         return 3 if (net_kind == "tpg" and phase == "fwd") else 1
     if POLICY == "x2":
         return _X2_TPG_FWD if (net_kind == "tpg" and phase == "fwd") else 2
+    if POLICY == "x3b2":
+        return 3 if phase == "fwd" else 2
     return _TERMS[POLICY]
 
 
