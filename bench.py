@@ -266,7 +266,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--prec", choices=["f32", "x3", "x3b2", "x2", "bf16"], default=None,
-                    help="arithmetic of the MFMA GEMMs (default: TPGSR_CONV_PREC or the library default), see tpgsr_amd/kernels.py")
+                    help="arithmetic of the MFMA GEMMs, see tpgsr_amd/kernels.py (default: TPGSR_CONV_PREC if set, else x2 -- BASELINE.json quotes "
+                         "this configuration in bf16; x2 = two bf16 terms per operand holds the north_star gates, tests/test_policy_x2_gpu.py)")
+    ap.add_argument("--alt-prec", default="x3", help="a second policy timed after the headline (same step, same batch) and printed as "
+                                                      "`alt_precision` of the same line; 'none' skips it")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured hipGraph (default: plain launches on several HIP streams; measured "
                          "faster because ROCm executes the graph's fork/join branches serially)")
@@ -303,8 +306,7 @@ def main():
     if os.environ.get("TPGSR_BENCH_MAIN_PRIORITY"):     # experiment switch: the step's main stream at another HIP priority
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["TPGSR_BENCH_MAIN_PRIORITY"])))
     from tpgsr_amd import kernels as K
-    if args.prec:
-        K.set_conv_prec(args.prec)
+    K.set_conv_prec(args.prec or os.environ.get("TPGSR_CONV_PREC") or "x2")
     global K_POLICY
     K_POLICY = K.POLICY
     cfg = CONFIGS[args.config]
@@ -397,6 +399,23 @@ def main():
                                     "hbm_bytes_per_step_pmc": round(traffic["hbm_bytes_per_step"]) if traffic else None,
                                     "algorithmic_bytes_per_step": round(cfg["mb_per_img"] * 1e6 * B),
                                     "hbm_traffic_by_class_pmc": ({k: traffic[k]["by_class"] for k in ("fetch", "write")} if traffic else None)}
+        if world == 1 and args.alt_prec not in ("none", K_POLICY):
+            # the same step under a second arithmetic policy (fresh networks, same weights recipe, same batch), after the headline's
+            # timed region: what the faster headline arithmetic buys against the fp32-equivalent one
+            K.set_conv_prec(args.alt_prec)
+            ts2, _nets2 = build_step(args.config, dev, world, pg)
+            for _ in range(max(3, args.warmup // 2)):
+                ts2.step(lr_img, hr_img)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ts2.step(lr_img, hr_img)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            out["alt_precision"] = {"arithmetic_policy": args.alt_prec, "arithmetic": ARITH[args.alt_prec], "steps": args.steps,
+                                    "ms_per_step": round(1e3 * dt2 / args.steps, 4), "value": round(B * args.steps / dt2, 1), "unit": "img/s"}
+            K.set_conv_prec(K_POLICY)
+            del ts2, _nets2
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args.config)

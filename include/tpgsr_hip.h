@@ -239,6 +239,12 @@ void tpgsr_halo_set_colmajor_min_bytes(long long v);
 /* smallest tap count (KH * KW) the halo forward kernel takes: 2 (default) or 1 (1x1 convolutions with Cin % 32 == 0 as well;
  * TPGSR_XBF_HALO_MINTAPS=1 at load time).  Results do not depend on it beyond fp32 summation order. */
 void tpgsr_halo_set_min_taps(int v);
+/* The row-panel kernel of the 1x1 convolutions with K <= 192 over many pixels (csrc/conv_panel.hip: the GruBlock projections,
+ * model/tsrn.py:491-508, and their data gradients): on / off (TPGSR_XBF_PANEL), and the smallest pixel count it takes (default 32768;
+ * TPGSR_XBF_PANEL_MIN_M).  Placement of a launch on this kernel or on the tile loop only affects speed. */
+void tpgsr_panel_set_enabled(int on);
+void tpgsr_panel_set_min_m(long long m);
+void tpgsr_panel_set_k192(int on);   /* K = 192 -> <= 64 columns on the panel kernel as well (default off: the tile loop is faster in x3; TPGSR_XBF_PANEL_K192) */
 /* host-only: the halo kernels' LDS entry capacity for this geometry = an upper bound of the halo length of any tile of 64
  * consecutive output pixels (reads OH, OW, KH, KW) */
 int tpgsr_halo_capacity(const tpgsr_conv_args* a);
@@ -525,6 +531,12 @@ int tpgsr_plan_add_fork(void* plan);
 int tpgsr_plan_add_join(void* plan);
 int tpgsr_plan_set_arg(void* plan, int op, int arg, const tpgsr_plan_arg* value);   /* patch a per-step pointer / scalar */
 int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream);
+/* A third stream ("leaf"): launches recorded with side == 2 run on it; tpgsr_plan_add_edge(plan, src, dst) orders stream dst (0 main,
+ * 1 side, 2 leaf) after everything recorded so far on stream src.  The SR network's STN-head backward -- a long chain of small
+ * launches nothing but the optimiser waits for (model/stn_head.py, model/tsrn.py:183) -- runs there, next to the text-prior
+ * generator's backward pass on the main stream. */
+int tpgsr_plan_add_edge(void* plan, int src, int dst);
+int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream, void* leaf_stream);
 /* A HIP stream for the side-stream role, optionally confined to the compute units whose bits are set in cu_mask
  * (n_words 32-bit words, bit i of word w = CU 32*w + i; NULL / 0 = all CUs).  Returns NULL on failure. */
 void* tpgsr_stream_create(const unsigned int* cu_mask, int n_words);

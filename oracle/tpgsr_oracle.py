@@ -613,13 +613,17 @@ def tsrn_train_step(p, opt: AdamState, lr_img: Tensor, hr_img: Tensor, *, stn=Tr
 
 def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dict, opt: AdamState,
                      lr_img: Tensor, hr_img: Tensor, *, stu_iter=1, sr_share=True, tpg_share=False, stn=True,
-                     srb_nums=5, gradient=True, explicit_rnn=False, grid_align_corners=False):
+                     srb_nums=5, gradient=True, explicit_rnn=False, grid_align_corners=False, tpg_forward=None):
     """Configs C3-C5: ``tsrn_tl_cascade`` branch, super_resolution.py:295-406 + :419-424.
     teacher(HR).detach -> per stage: student(prev image) -> softmax -> distill loss -> (N,37,1,26)
     -> zero the prior of samples [0, N//4) -> SR net -> image loss; sum; backward;
-    clip each SR net to 0.25 (students are NOT clipped); one Adam over SR nets + students."""
+    clip each SR net to 0.25 (students are NOT clipped); one Adam over SR nets + students.
+    tpg_forward(params, gray, training=...) -> (T, N, C) logits: the text-prior generator, `crnn_forward` (`--tpg CRNN`) unless given
+    (`--tpg OPT`: oracle/opt_oracle.py:opt_forward; super_resolution.py:77-80 selects either for the same loop)."""
+    if tpg_forward is None:
+        tpg_forward = lambda q_, g_, training: crnn_forward(q_, g_, training=training, explicit_rnn=explicit_rnn)
     with torch.no_grad():
-        t_logits = crnn_forward(teacher, parse_crnn_data(hr_img[:, :3]), training=False, explicit_rnn=explicit_rnn)
+        t_logits = tpg_forward(teacher, parse_crnn_data(hr_img[:, :3]), training=False)
         q = F.softmax(t_logits, -1)
     cascade = lr_img
     loss_img = 0.0
@@ -627,7 +631,7 @@ def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dic
     priors = []
     for i in range(stu_iter):
         stu = stu_params[0 if tpg_share else i]
-        logits = crnn_forward(stu, parse_crnn_data(cascade[:, :3]), training=True, explicit_rnn=explicit_rnn)
+        logits = tpg_forward(stu, parse_crnn_data(cascade[:, :3]), training=True)
         pv = F.softmax(logits, -1)                                   # (26, N, 37)
         prior = pv.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)  # (N, 37, 1, 26)
         loss_distill = loss_distill + semantic_loss(pv, q) * 100

@@ -5,7 +5,8 @@ torchvision, cv2 which the reference imports but never uses on these paths).  We
 used by the tests: key order and shapes of the reference's state_dict == ours, which this script asserts), so only inputs and
 expected outputs are stored: forward in train and eval mode, input / prior gradients, per-parameter gradient norms + heads.
 
-    python tests/golden/make_golden_next.py          # rewrites tests/golden/next_*.npz + next_layouts.json"""
+    python tests/golden/make_golden_next.py          # rewrites tests/golden/next_*.npz + next_layouts.json + train_c3_opt.npz
+    python tests/golden/make_golden_next.py --opt-train-only      # only pins the OPT oracle and writes train_c3_opt.npz"""
 import json
 import os
 import sys
@@ -56,6 +57,106 @@ def grad_summary(mod):
         h[:k] = g.reshape(-1)[:k].numpy()
         heads.append(h)
     return np.array(names), np.array(norms), np.stack(heads)
+
+
+def opt_train_fixture():
+    """`--tpg OPT` inside the training loop (interfaces/super_resolution.py:77-80 picks crnn.Model(opt) for teacher AND students of the
+    same loop, :295-424): (1) pins oracle/opt_oracle.py against the genuine reference Model (outputs and every parameter gradient, train
+    and eval mode); (2) composes one C3-shaped step from the reference's own modules -- TSRN_TL + Model(opt) teacher (eval) + Model(opt)
+    student (train), SemanticLoss, ImageLoss(gradient), clip 0.25 on the SR net, Adam -- asserts the oracle's tpgsr_train_step
+    (tpg_forward = opt_forward) reproduces it, and writes tests/golden/train_c3_opt.npz.  Weights: generic_recipe / the oracle recipe."""
+    import torch.nn.functional as F
+    from loss import image_loss as r_image_loss, semantic_loss as r_semantic_loss
+    from model import tsrn as r_tsrn
+    from model.crnn import model as r_opt
+    from oracle import opt_oracle as OO, tpgsr_oracle as O
+
+    class Opt(dict):
+        __getattr__ = dict.get
+
+    cfg = Opt(Transformation="None", FeatureExtraction="ResNet", SequenceModeling="None", Prediction="CTC", num_fiducial=20,
+              input_channel=1, output_channel=512, hidden_size=256, num_class=37)
+    # (1) oracle == reference
+    ref = r_opt.Model(cfg)
+    sd = generic_recipe(ref.state_dict(), 104)
+    gray = torch.rand(3, 1, 32, 100, generator=torch.Generator().manual_seed(1))
+    gy = torch.randn(26, 3, 37, generator=torch.Generator().manual_seed(2))
+    for training in (True, False):
+        ref.load_state_dict(sd)
+        ref.train(training)
+        p = O.as_params(sd, training)
+        y, yo = ref(gray), OO.opt_forward(p, gray, training)
+        assert float((y - yo).abs().max()) <= 1e-6 * float(y.abs().max()), "opt_forward != reference Model"
+        if training:
+            (y * gy).sum().backward()
+            (yo * gy).sum().backward()
+            rp = dict(ref.named_parameters())
+            for k in O.trainable_keys(p):
+                assert float((rp[k].grad - p[k].grad).abs().max()) <= 1e-5 * float(rp[k].grad.abs().max() + 1e-12), k
+    print("oracle opt_forward == reference crnn.Model (train + eval, all gradients)")
+    # (2) one C3-shaped step, reference modules
+    lr, hr = O.synthetic_batch(4, 61)
+    sd_sr = O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 301, tps_hw=(16, 64))
+    sd_t, sd_s = generic_recipe(ref.state_dict(), 312), generic_recipe(ref.state_dict(), 313)
+    net = r_tsrn.TSRN_TL(STN=True, mask=True)
+    net.load_state_dict(sd_sr)
+    net.train()
+    teacher, stu = r_opt.Model(cfg), r_opt.Model(cfg)
+    teacher.load_state_dict(sd_t)
+    teacher.eval()
+    for q in teacher.parameters():
+        q.requires_grad = False
+    stu.load_state_dict(sd_s)
+    stu.train()
+    opt = torch.optim.Adam(list(net.parameters()) + list(stu.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    crit, sem = r_image_loss.ImageLoss(gradient=True, loss_weight=[1, 1e-4]), r_semantic_loss.SemanticLoss()
+    ps, pt, pu = O.as_params(sd_sr), O.as_params(sd_t, False), O.as_params(sd_s)
+    oopt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [pu[k] for k in O.trainable_keys(pu)])
+    traj = {"loss": [], "gnorm": [], "stu_gnorm": []}
+    for step in range(2):
+        hr_prior = F.softmax(teacher(O.parse_crnn_data(hr[:, :3])).detach(), -1)
+        pv = F.softmax(stu(O.parse_crnn_data(lr[:, :3])), -1)
+        pf = pv.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+        l_d = sem(pv, hr_prior) * 100
+        drop = torch.ones(4)
+        drop[:1] = 0
+        sr = net(lr, pf * drop.view(-1, 1, 1, 1))
+        loss = crit(sr, hr).mean() * 100 + l_d
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.25)
+        sgn = float(torch.sqrt(sum(q.grad.double().pow(2).sum() for q in stu.parameters())))
+        opt.step()
+        r = O.tpgsr_train_step([ps], [pu], pt, oopt, lr, hr, stu_iter=1, tpg_forward=OO.opt_forward)
+        tol = (1e-4, 5e-4)[step]
+        assert abs(float(r["loss"]) - loss.item()) <= tol * abs(loss.item()), (step, float(r["loss"]), loss.item())
+        assert abs(float(r["grad_norms"][0]) - float(gn)) <= 10 * tol * float(gn)
+        if step == 0:
+            prior_argmax = pv.detach().argmax(-1).numpy()
+            assert (r["priors"][0].argmax(-1).numpy() == prior_argmax).all()
+            sr0 = sr.detach().numpy()
+        traj["loss"].append(loss.item())
+        traj["gnorm"].append(float(gn))
+        traj["stu_gnorm"].append(sgn)
+        print(f"  C3/OPT step {step}: loss {loss.item():.6f} (distill {l_d.item():.5f}) SR gnorm {float(gn):.5f} student gnorm {sgn:.5f}")
+    np.savez_compressed(os.path.join(HERE, "train_c3_opt.npz"), lr=lr.numpy(), hr=hr.numpy(), loss=np.array(traj["loss"]),
+                        gnorm=np.array(traj["gnorm"]), stu_gnorm=np.array(traj["stu_gnorm"]), prior_argmax_step0=prior_argmax, sr_step0=sr0)
+    print("train_c3_opt.npz written")
+
+
+def _stub_imports():
+    for name in ("IPython", "cv2"):
+        m = types.ModuleType(name)
+        m.embed = lambda *a, **k: None
+        sys.modules.setdefault(name, m)
+    tv = types.ModuleType("torchvision")
+    for sub in ("models", "transforms", "datasets"):
+        m = types.ModuleType("torchvision." + sub)
+        setattr(tv, sub, m)
+        sys.modules["torchvision." + sub] = m
+    sys.modules.setdefault("torchvision", tv)
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
 
 
 def main():
@@ -178,4 +279,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--opt-train-only" in sys.argv:      # just the `--tpg OPT` pinning + train_c3_opt.npz (leaves the other fixtures untouched)
+        import warnings
+        warnings.filterwarnings("ignore")
+        _stub_imports()
+        opt_train_fixture()
+    else:
+        main()
+        opt_train_fixture()

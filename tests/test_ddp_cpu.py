@@ -156,3 +156,81 @@ def test_arena_pool_and_dataparallel_wrapper_cpu():
     keys = list(dp.state_dict().keys())
     assert keys and all(k.startswith("module.") for k in keys)
     assert [k[len("module."):] for k in keys] == list(sr.state_dict().keys())   # save_checkpoint's netG.module.state_dict()
+
+
+def _dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tpgsr_amd.distributed import DataParallel
+    torch.manual_seed(10 + rank)                                   # ranks start DIFFERENT on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Tanh(), torch.nn.Linear(3, 2))
+    dp = DataParallel(net)                                          # no fused engine: per-parameter hooks + rank 0's weights
+    p0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    x = torch.randn(5, 4, generator=torch.Generator().manual_seed(100 + rank))
+    dp(x).pow(2).sum().backward()
+    g = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+
+    # the fused path's hook (what the network's single autograd node calls at the end of its backward pass) on a stand-in engine
+    class _Arena:
+        pass
+
+    class _Eng:
+        FUSED = True
+        arena = _Arena()
+
+        def bind(self, dev):
+            pass
+
+    eng = _Eng()
+    eng.arena.flat = torch.full((6,), float(rank))
+    eng.arena.grad = torch.arange(6, dtype=torch.float32) * (rank + 1)
+
+    class _Fused(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def _engine(self):
+            return eng
+
+    fused = _Fused()
+    dpf = DataParallel(fused)
+    assert fused._grad_sync == dpf._sync
+    fused._grad_sync(eng)
+    q.put((rank, p0, g, eng.arena.flat.clone(), eng.arena.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dataparallel_wrapper_two_ranks_hooked_and_fused_paths():
+    """tpgsr_amd.distributed.DataParallel with world size 2: an operator-by-operator module (no fused engine) gets rank 0's weights
+    and per-parameter gradient averaging; the fused path's _grad_sync averages the engine's flat gradient arena."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+    (_, pa, ga, fa, gfa), (_, pb, gb, fb, gfb) = res
+    assert torch.equal(pa, pb), "broadcast of rank 0's parameters"
+    assert torch.equal(ga, gb), "ranks must hold the same averaged gradient"
+    # single process: mean of the two ranks' gradients with rank 0's weights
+    torch.manual_seed(10)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Tanh(), torch.nn.Linear(3, 2))
+    acc = None
+    for r in range(2):
+        net.zero_grad()
+        x = torch.randn(5, 4, generator=torch.Generator().manual_seed(100 + r))
+        net(x).pow(2).sum().backward()
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        acc = g.clone() if acc is None else acc + g
+    assert (acc / 2 - ga).abs().max() < 1e-6
+    assert torch.equal(fa, torch.zeros(6)) and torch.equal(fb, torch.zeros(6))          # flat parameters: rank 0's
+    assert torch.equal(gfa, gfb) and (gfa - torch.arange(6, dtype=torch.float32) * 1.5).abs().max() < 1e-6

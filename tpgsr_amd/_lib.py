@@ -77,6 +77,8 @@ _SIGS = {
     "tpgsr_plan_add_join": (ci, [vp]),
     "tpgsr_plan_set_arg": (ci, [vp, ci, ci, C.POINTER(PlanArg)]),
     "tpgsr_plan_run": (ci, [vp, vp, vp]),
+    "tpgsr_plan_add_edge": (ci, [vp, ci, ci]),
+    "tpgsr_plan_run3": (ci, [vp, vp, vp, vp]),
     "tpgsr_stream_create": (vp, [C.POINTER(C.c_uint), ci]),
     "tpgsr_stream_destroy": (ci, [vp]),
     "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
@@ -180,6 +182,9 @@ _SIGS = {
     "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_halo_set_colmajor_min_bytes": (None, [C.c_longlong]),
     "tpgsr_halo_set_min_taps": (None, [ci]),
+    "tpgsr_panel_set_enabled": (None, [ci]),
+    "tpgsr_panel_set_min_m": (None, [C.c_longlong]),
+    "tpgsr_panel_set_k192": (None, [ci]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 

@@ -1,0 +1,138 @@
+// Shared device code of the split-operand bf16 MFMA convolution kernels (conv_xbf.hip: tile loop, halo kernels, weight gradients;
+// conv_panel.hip: the row-panel kernel of the 1x1 convolutions): operand splitting, the term-pair MFMA sequence and the forward epilogue.
+#pragma once
+#include "conv_loader.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+#define XW_ROW 192                // bytes per LDS row of the wgrad images (64 bf16 + 64 B pad): 4 consecutive rows -> disjoint 64-B bank windows
+#define XW_PLANE (32 * XW_ROW)
+
+// x = h[0] + h[1] + h[2] exactly (T = 3); h[0] = RNE bf16 (T = 1)
+template <int T>
+__device__ __forceinline__ void split_bf(float x, __bf16 (&h)[T]) {
+  h[0] = (__bf16)x;
+  if (T > 1) {
+    float r = x - (float)h[0];
+    h[1] = (__bf16)r;
+    if (T > 2) h[2] = (__bf16)(r - (float)h[1]);
+  }
+}
+template <int T>
+__device__ __forceinline__ void split4(const float4& v, uint2 (&out)[T]) {
+  __bf16 a[T], b[T], c[T], d[T];
+  split_bf<T>(v.x, a);
+  split_bf<T>(v.y, b);
+  split_bf<T>(v.z, c);
+  split_bf<T>(v.w, d);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    bf16x4 q;
+    q[0] = a[t]; q[1] = b[t]; q[2] = c[t]; q[3] = d[t];
+    out[t] = __builtin_bit_cast(uint2, q);
+  }
+}
+
+// acc += sum over the term pairs (i, j) with i + j <= T + 1 of a[i] * b[j], smallest magnitudes first
+template <int T>
+__device__ __forceinline__ floatx16 mfma_terms(const bf16x8 (&a)[T], const bf16x8 (&b)[T], floatx16 acc) {
+  if (T == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  }
+  if (T == 2) {   // two-term split: a1 b1 + a1 b2 + a2 b1, what is dropped is <= 3 * 2^-18 |a b| per product
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// ---- epilogue shared by the forward kernels (as conv_fwd_kernel): bias, activation, (pixel-shuffled) store, BN partial
+// statistics.  The calling threads are the 256 of the four MFMA waves (tid 0..255); `red` = 4 * 64 WNB floats of LDS nobody
+// reads any more; contains one __syncthreads() when a.bn_partial is set. ----
+// (-DXBF_NT_STORE=1: nontemporal output stores.  Measured: the launch alone 31.1 vs 31.8 us, the C3 step 10.17 vs 9.83 ms -- the next
+//  layer finds less of its input in L2 -- so it stays off)
+#ifndef XBF_NT_STORE
+#define XBF_NT_STORE 0
+#endif
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int wm,
+                                               int wn, int lane, float* red) {
+  constexpr int BNT = 64 * WNB;
+  const int ohw = a.OH * a.OW;
+#pragma unroll
+  for (int j = 0; j < WNB; ++j) {
+    const int cloc = wn * 32 * WNB + 32 * j + (lane & 31);
+    const int n = n0 + cloc;
+    const bool nvalid = n < a.Cout;
+    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int m = m0 + wm * 32 * WMB + 32 * i + row;
+        if (m < M && nvalid) {
+          float raw = acc[i][j][r];
+          s += raw;
+          ss += raw * raw;
+          float v = apply_act(raw + bias, a.out_act);
+          if (!a.out_ps) {
+            if (XBF_NT_STORE) __builtin_nontemporal_store(v, &a.out[(size_t)m * a.out_ld + a.out_coff + n]);
+            else a.out[(size_t)m * a.out_ld + a.out_coff + n] = v;
+          } else {
+            int nn = m / ohw;
+            int rem = m - nn * ohw;
+            int oh = rem / a.OW, ow = rem - oh * a.OW;
+            int cs = n >> 2, pi = (n >> 1) & 1, pj = n & 1;
+            a.out[((size_t)(nn * 2 * a.OH + 2 * oh + pi) * (2 * a.OW) + 2 * ow + pj) * (a.Cout >> 2) + cs] = v;
+          }
+        }
+      }
+    if (a.bn_partial) {
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * BNT + cloc] = s;
+        red[(wm * 2 + 1) * BNT + cloc] = ss;
+      }
+    }
+  }
+}
+// after a barrier: statistics per 64-pixel row block (the layout bn_finalize expects) out of the wave rows' partials
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, int n0, int mblk, int tid, const float* red) {
+  constexpr int BNT = 64 * WNB;
+  // WMB = 1: the two wave rows together are the one 64-pixel block; WMB = 2: each wave row is a block of its own
+  for (int e = tid; e < BNT * WMB; e += 256) {
+    const int blk = e / BNT, c = e - blk * BNT;
+    const long long rb64 = (long long)mblk * WMB + blk;
+    if (n0 + c < a.Cout && rb64 * 64 < M) {
+      float* dst = a.bn_partial + (size_t)rb64 * 2 * a.Cout;
+      if (WMB == 1) {
+        dst[n0 + c] = red[0 * BNT + c] + red[2 * BNT + c];
+        dst[a.Cout + n0 + c] = red[1 * BNT + c] + red[3 * BNT + c];
+      } else {
+        dst[n0 + c] = red[(blk * 2 + 0) * BNT + c];
+        dst[a.Cout + n0 + c] = red[(blk * 2 + 1) * BNT + c];
+      }
+    }
+  }
+}
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_epilogue(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int mblk,
+                                             int wm, int wn, int lane, int tid, float* red) {
+  xbf_store_tile<WMB, WNB>(a, acc, M, m0, n0, wm, wn, lane, red);
+  if (a.bn_partial) {
+    __syncthreads();
+    xbf_bn_flush<WMB, WNB>(a, M, n0, mblk, tid, red);
+  }
+}
+

@@ -72,47 +72,60 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
   __syncthreads();
   const int T = g.T;
   auto pix_of = [&](int step) { return g.base + (long long)(d == 0 ? step : T - 1 - step) * g.stride; };
-  float gr = 0.f, gz = 0.f, gn = 0.f;
-  if (g.active) {
-    const float* p = gi + pix_of(0) * 192 + d * 96 + j;
-    gr = p[0]; gz = p[32]; gn = p[64];
-  }
-  for (int step = 0; step < T; ++step) {
-    const long long pix = pix_of(step);
-    float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-    if (g.active && step + 1 < T) {  // prefetch the next step's input projections
-      const float* p = gi + pix_of(step + 1) * 192 + d * 96 + j;
-      ngr = p[0]; ngz = p[32]; ngn = p[64];
-    }
-    // W_hh h: six independent packed-FMA chains, 8 deep (the recurrence is latency-bound: one wave per SIMD)
-    f2 a0 = mk2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, n0 = a0, n1 = a0;
-    const float4* hp = reinterpret_cast<const float4*>(&hs[step & 1][d * 32]);
+  // The input projections do not depend on the recurrence: they are fetched PF steps ahead through a small register ring.  One
+  // step of look-ahead (a serial step is ~600 cycles) left the wave waiting on memory in EVERY step whenever a load took longer
+  // than that -- i.e. always, next to the other kernels of the training step (the backward kernel below learnt this first).
+  constexpr int PF = 6;
+  struct StepIn {
+    float r, z, n;
+  };
+  auto fetch = [&](int step) {
+    StepIn s = {0.f, 0.f, 0.f};
+    if (!g.active || step >= T) return s;
+    const float* p = gi + pix_of(step) * 192 + d * 96 + j;
+    s.r = p[0]; s.z = p[32]; s.n = p[64];
+    return s;
+  };
+  StepIn ring[PF];
 #pragma unroll
-    for (int k = 0; k < GRU_H / 4; ++k) {
-      const float4 hv = hp[k];
-      a0 = pk_fma(wrz[4 * k], mk2(hv.x, hv.x), a0);
-      a1 = pk_fma(wrz[4 * k + 1], mk2(hv.y, hv.y), a1);
-      a2 = pk_fma(wrz[4 * k + 2], mk2(hv.z, hv.z), a2);
-      a3 = pk_fma(wrz[4 * k + 3], mk2(hv.w, hv.w), a3);
-      n0 = pk_fma(wn2[2 * k], mk2(hv.x, hv.y), n0);
-      n1 = pk_fma(wn2[2 * k + 1], mk2(hv.z, hv.w), n1);
-    }
-    const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
-    const float an = bn + (nn.x + nn.y);
-    const float r = sigmoid_f(gr + (br + rz.x));
-    const float z = sigmoid_f(gz + (bz + rz.y));
-    const float n = tanh_f(gn + r * an);
-    h = (1.f - z) * n + z * h;
-    hs[(step + 1) & 1][lane] = h;
-    if (g.active) {
-      h_out[pix * 64 + d * 32 + j] = h;
-      if (gates) {
-        float* q = gates + pix * 256 + d * 128 + j;
-        q[0] = r; q[32] = z; q[64] = n; q[96] = an;
+  for (int i = 0; i < PF; ++i) ring[i] = fetch(i);
+  for (int base = 0; base < T; base += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int step = base + i;
+      if (step >= T) break;                       // wave-uniform
+      const long long pix = pix_of(step);
+      const StepIn c = ring[i];
+      ring[i] = fetch(step + PF);
+      // W_hh h: six independent packed-FMA chains, 8 deep (the recurrence is latency-bound: one wave per SIMD)
+      f2 a0 = mk2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, n0 = a0, n1 = a0;
+      const float4* hp = reinterpret_cast<const float4*>(&hs[step & 1][d * 32]);
+#pragma unroll
+      for (int k = 0; k < GRU_H / 4; ++k) {
+        const float4 hv = hp[k];
+        a0 = pk_fma(wrz[4 * k], mk2(hv.x, hv.x), a0);
+        a1 = pk_fma(wrz[4 * k + 1], mk2(hv.y, hv.y), a1);
+        a2 = pk_fma(wrz[4 * k + 2], mk2(hv.z, hv.z), a2);
+        a3 = pk_fma(wrz[4 * k + 3], mk2(hv.w, hv.w), a3);
+        n0 = pk_fma(wn2[2 * k], mk2(hv.x, hv.y), n0);
+        n1 = pk_fma(wn2[2 * k + 1], mk2(hv.z, hv.w), n1);
       }
+      const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
+      const float an = bn + (nn.x + nn.y);
+      const float r = sigmoid_f(c.r + (br + rz.x));
+      const float z = sigmoid_f(c.z + (bz + rz.y));
+      const float n = tanh_f(c.n + r * an);
+      h = (1.f - z) * n + z * h;
+      hs[(step + 1) & 1][lane] = h;
+      if (g.active) {
+        h_out[pix * 64 + d * 32 + j] = h;
+        if (gates) {
+          float* q = gates + pix * 256 + d * 128 + j;
+          q[0] = r; q[32] = z; q[64] = n; q[96] = an;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    gr = ngr; gz = ngz; gn = ngn;
   }
 }
 

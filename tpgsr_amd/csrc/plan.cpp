@@ -82,7 +82,7 @@ const std::unordered_map<std::string, Entry>& registry() {
   return r;
 }
 
-enum { OP_LAUNCH = 0, OP_FORK = 1, OP_JOIN = 2 };
+enum { OP_LAUNCH = 0, OP_FORK = 1, OP_JOIN = 2, OP_EDGE = 3 };   // OP_EDGE: stream `src` -> stream `dst` (sid = src, nargs = dst)
 constexpr int MAX_ARGS = 24;
 
 struct Op {
@@ -130,7 +130,7 @@ extern "C" int tpgsr_plan_add_launch(void* plan, const char* symbol, const tpgsr
   Op o;
   memset(&o, 0, sizeof(o));
   o.kind = OP_LAUNCH;
-  o.sid = side ? 1 : 0;
+  o.sid = side < 0 ? 0 : (side > 2 ? 2 : side);    // 0: the caller's stream, 1: side (weight gradients), 2: leaf stream
   o.nargs = nargs;
   o.fn = e.fn;
   o.name = it->first.c_str();
@@ -166,6 +166,19 @@ static int add_edge(void* plan, int kind) {
 }
 extern "C" int tpgsr_plan_add_fork(void* plan) { return add_edge(plan, OP_FORK); }
 extern "C" int tpgsr_plan_add_join(void* plan) { return add_edge(plan, OP_JOIN); }
+extern "C" int tpgsr_plan_add_edge(void* plan, int src, int dst) {
+  if (src < 0 || src > 2 || dst < 0 || dst > 2 || src == dst) {
+    tpgsr_set_error("tpgsr_plan_add_edge: stream ids must be two different values of 0, 1, 2 (got %d -> %d)", src, dst);
+    return -1;
+  }
+  const int i = add_edge(plan, OP_EDGE);
+  if (i >= 0) {
+    Plan* p = static_cast<Plan*>(plan);
+    p->ops[i].sid = src;
+    p->ops[i].nargs = dst;
+  }
+  return i;
+}
 
 extern "C" int tpgsr_plan_set_arg(void* plan, int op, int arg, const tpgsr_plan_arg* value) {
   Plan* p = static_cast<Plan*>(plan);
@@ -178,36 +191,45 @@ extern "C" int tpgsr_plan_set_arg(void* plan, int op, int arg, const tpgsr_plan_
   return 0;
 }
 
-extern "C" int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream) {
+extern "C" int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream, void* leaf_stream) {
   Plan* p = static_cast<Plan*>(plan);
   if (!p) {
     tpgsr_set_error("tpgsr_plan_run: null plan");
     return -1;
   }
-  hipStream_t s[2] = {(hipStream_t)main_stream, (hipStream_t)side_stream};
+  hipStream_t s[3] = {(hipStream_t)main_stream, (hipStream_t)side_stream, (hipStream_t)leaf_stream};
   const int n = (int)p->ops.size();
   for (int i = 0; i < n; ++i) {
     Op& o = p->ops[i];
     if (o.kind == OP_LAUNCH) {
+      if (o.sid && (!s[o.sid] || s[o.sid] == s[0])) {
+        tpgsr_set_error("tpgsr_plan_run: the plan has launches on stream %d but no distinct stream was given for it", o.sid);
+        return -1;
+      }
       int rc = o.fn(o.args, s[o.sid]);
       if (rc) return rc;   // the entry point has set the message
     } else {
-      if (s[1] == s[0] || !s[1]) {
-        tpgsr_set_error("tpgsr_plan_run: the plan has side-stream sections but no distinct side stream was given");
+      const int src = o.kind == OP_FORK ? 0 : o.kind == OP_JOIN ? 1 : o.sid;
+      const int dst = o.kind == OP_FORK ? 1 : o.kind == OP_JOIN ? 0 : o.nargs;
+      if ((src && !s[src]) || (dst && !s[dst]) || s[src] == s[dst]) {      // (the caller's stream may be the null stream)
+        tpgsr_set_error("tpgsr_plan_run: the plan orders stream %d after stream %d but no distinct streams were given for them", dst, src);
         return -1;
       }
       if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) {
         tpgsr_set_error("tpgsr_plan_run: hipEventCreateWithFlags failed");
         return -2;
       }
-      hipStream_t from = o.kind == OP_FORK ? s[0] : s[1], to = o.kind == OP_FORK ? s[1] : s[0];
-      if (hipEventRecord(o.ev, from) != hipSuccess || hipStreamWaitEvent(to, o.ev, 0) != hipSuccess) {
+      if (hipEventRecord(o.ev, s[src]) != hipSuccess || hipStreamWaitEvent(s[dst], o.ev, 0) != hipSuccess) {
         tpgsr_set_error("tpgsr_plan_run: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
         return -2;
       }
     }
   }
   return 0;
+}
+
+extern "C" int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream) {
+  return tpgsr_plan_run3(plan, main_stream, side_stream, nullptr);
 }
 
 // ---- side stream with a compute-unit mask -----------------------------------------------------------------------------

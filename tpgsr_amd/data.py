@@ -48,6 +48,8 @@ class ResizeNormalize:
             raise RuntimeError("tpgsr_amd.data.ResizeNormalize runs on the GPU only (the reference's PIL path is the CPU form)")
         ow, oh = self.size
         N = len(images)
+        if N == 0:                                        # an empty batch is an empty tensor, not a numpy concatenate error
+            return torch.empty(0, 4 if self.mask else 3, oh, ow, dtype=torch.float32, device=self.device)
         descs = (_lib.ImageDesc * N)()
         tabs: List[np.ndarray] = []
         toff, poff, maxH = 0, 0, 1
@@ -102,17 +104,22 @@ class AlignCollate:
 
 class LmdbDatasetReal:
     """`lmdbDataset_real` (dataset/dataset.py:104-149): (HR, LR, label) triples from the reference's LMDB layout, decoded to
-    uint8 arrays for AlignCollate.  Needs the `lmdb` and `PIL` packages like the reference; raises a clear error without them."""
+    uint8 arrays for AlignCollate.  Needs `lmdb` (unless an opened environment is handed in as `env`) and `PIL`, like the reference.
+    As in the reference, a record whose images cannot be decoded is SKIPPED: `self[index]` returns the next sample (:141-146)."""
 
-    def __init__(self, root, voc_type="upper", max_len=100):
-        try:
-            import lmdb
-        except ImportError as e:
-            raise ImportError("LmdbDatasetReal needs the `lmdb` package (as the reference's dataset/dataset.py does)") from e
-        self.env = lmdb.open(root, max_readers=1, readonly=True, lock=False, readahead=False, meminit=False)
+    def __init__(self, root=None, voc_type="upper", max_len=100, test=False, env=None):
+        if env is None:
+            try:
+                import lmdb
+            except ImportError as e:
+                raise ImportError("LmdbDatasetReal needs the `lmdb` package (as the reference's dataset/dataset.py does)") from e
+            env = lmdb.open(root, max_readers=1, readonly=True, lock=False, readahead=False, meminit=False)
+        if not env:
+            raise RuntimeError(f"cannot open lmdb from {root}")
+        self.env = env
         with self.env.begin(write=False) as txn:
             self.nSamples = int(txn.get(NUM_SAMPLES_KEY))
-        self.voc_type, self.max_len = voc_type, max_len
+        self.voc_type, self.max_len, self.test = voc_type, max_len, test
 
     def __len__(self):
         return self.nSamples
@@ -121,9 +128,17 @@ class LmdbDatasetReal:
         import io
         from PIL import Image
         from .utils.metrics import str_filt
-        keys = lmdb_keys(index)
-        with self.env.begin(write=False) as txn:
-            word = txn.get(keys["label"]).decode()
-            hr = np.asarray(Image.open(io.BytesIO(txn.get(keys["image_hr"]))).convert("RGB"))
-            lr = np.asarray(Image.open(io.BytesIO(txn.get(keys["image_lr"]))).convert("RGB"))
-        return hr, lr, str_filt(word, self.voc_type)
+        assert index <= len(self), "index range error"               # (the reference's own guard, dataset.py:131)
+        for probe in range(index, index + len(self) + 1):              # at most one lap: the reference recurses on self[index + 1]
+            keys = lmdb_keys(probe % max(1, len(self)))
+            with self.env.begin(write=False) as txn:
+                word, buf_hr, buf_lr = txn.get(keys["label"]), txn.get(keys["image_hr"]), txn.get(keys["image_lr"])
+            try:
+                if word is None or buf_hr is None or buf_lr is None:
+                    raise IOError(f"missing record {probe}")
+                hr = np.asarray(Image.open(io.BytesIO(buf_hr)).convert("RGB"))
+                lr = np.asarray(Image.open(io.BytesIO(buf_lr)).convert("RGB"))
+            except (IOError, OSError, SyntaxError, ValueError):
+                continue
+            return hr, lr, str_filt(word.decode(), self.voc_type)
+        raise IOError("no decodable record in the LMDB")

@@ -94,7 +94,8 @@ class DataParallel(torch.nn.Module):
         self.module = module
         self.process_group = process_group
         self._inv = None
-        self._fused = callable(getattr(module, "_engine", None))
+        # fused networks (TSRN / TSRN_TL / CRNN: one autograd node per network, which calls _grad_sync) vs operator-by-operator ones
+        self._fused = callable(getattr(module, "_engine", None)) and getattr(module._engine(), "FUSED", True)
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         if self._fused:
             module._grad_sync = self._sync          # called by the module's fused autograd node at the end of its backward pass

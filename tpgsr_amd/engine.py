@@ -255,7 +255,7 @@ class BNLayer:
         """dy = dL/d(pre-BN y) from da (+da2) = dL/d act(BN(y)); accumulates dgamma/dbeta into the arena."""
         eng = self.eng
         nblk = min(1024, max(1, M // 64))
-        part = eng.scratch("bnb_partial", nblk * 2 * self.C)
+        part = eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
         K.bn_bwd_reduce(da, da2, y, M, self.C, self.scale, self.shift, self.save_mean, self.save_rstd, act, part, nblk)
         K.bn_bwd_finalize(part, nblk, self.C, M, self.gamma, self.save_mean, self.save_rstd, eng.G[self.prefix + ".weight"],
                           eng.G[self.prefix + ".bias"], self.coef, accumulate=True)
@@ -385,6 +385,7 @@ class TConvStrip:
 # =================================================================================================================
 class _EngineBase:
     """Arenas, packed-operand table, stream-ordered scratch and plan cache shared by the network engines."""
+    FUSED = True         # one fused autograd node per network (see tpgsr_amd.distributed.DataParallel)
 
     def __init__(self, module: torch.nn.Module):
         self.module = module
@@ -593,6 +594,9 @@ class TSRNEngine(_EngineBase):
         self.overlap_wgrad = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
         # all weight-gradient slab reduces of a backward pass in one launch (each layer then keeps its own slab buffers)
         self.defer_reduce = os.environ.get("TPGSR_DEFER_REDUCE", "1") != "0"
+        # the STN head's backward (a chain of ~60 small launches that only produces parameter gradients) on a third stream, next to
+        # the rest of the step (InfoGen backward -> text-prior generator backward on the caller's stream)
+        self.leaf_stn = os.environ.get("TPGSR_LEAF_STN", "1") != "0"
 
     def _build_layers(self):
         m = self.module
@@ -657,6 +661,7 @@ class TSRNEngine(_EngineBase):
         fwd.final = bwd.final = final
         bwd.overlap = self.overlap_wgrad
         bwd.deferred = [] if self.defer_reduce else None
+        bwd.use_leaf = self.leaf_stn and self.overlap_wgrad and self.defer_reduce
         self._cur_ws, self._wg_idx, self._compose = ws, 0, []
         for bn in self._bn_layers:
             bn.use(ws)
@@ -665,6 +670,7 @@ class TSRNEngine(_EngineBase):
         if training:
             with recording(bwd), K.conv_terms(K.terms_for("sr", "bwd")):
                 self._record_bwd(N, H, W, ws)
+                bwd.leaf_to_side()          # the batched slab reduce reads the leaf stream's slabs too
                 if self.defer_reduce:
                     K.flush_wgrad_reduces()
                 self.flush_compose_bwd()
@@ -879,7 +885,8 @@ class TSRNEngine(_EngineBase):
         xin = t["xr"] if self.stn else t["x_nhwc"]
         self.block1.wgrad(N, H, W, xin, dc1)
         if self.stn:
-            self._record_stn_bwd(N, H, W, dc1, ws)
+            with K.leaf():
+                self._record_stn_bwd(N, H, W, dc1, ws)
         if self.tl:
             self._record_infogen_bwd(N, W, ws)
 

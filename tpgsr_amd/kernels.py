@@ -183,13 +183,15 @@ class Plan:
 
     def __init__(self, name=""):
         self.name = name
-        self.ops = []      # [name, cfunc, [args...], stream id]; cfunc None: "fork" / "join" stream dependencies
+        self.ops = []      # [name, cfunc, [args...], stream id]; cfunc None: "fork" / "join" / "edge" (args = (src, dst)) stream dependencies
         self.keep = []     # tensors / arg structs referenced by raw pointer
         self.dyn = {}      # key -> [(op index, arg index)]
-        self.sid = 0       # stream the next recorded launch goes to: 0 = the caller's stream, 1 = side stream
+        self.sid = 0       # stream the next recorded launch goes to: 0 = the caller's stream, 1 = side stream, 2 = leaf stream
         self.forks = 0
+        self.leaf_pending = False   # launches on the leaf stream nothing has been ordered after yet
         self._native = None  # tpgsr_plan handle, built on first run()
         self._has_side = False
+        self._has_leaf = False
 
     def mark_dynamic(self, key):
         """The NEXT recorded pointer argument equal to the DynPtr placeholder `key` becomes patchable."""
@@ -213,7 +215,21 @@ class Plan:
         kernel reduces in a fixed order and side launches only read buffers the main stream never rewrites."""
         return _SideCtx(self)
 
+    def leaf(self):
+        """``with plan.leaf():`` -- the launches recorded inside go to the LEAF stream (a third stream), ordered after everything
+        recorded so far on the caller's stream; side() sections inside it stay on the leaf stream (in order).  For a chain of
+        launches that only produces parameter gradients (the STN head's backward): it runs next to whatever the caller's stream
+        does afterwards.  leaf_to_side() orders the side stream after it (before the batched slab reduce, which reads its slabs)."""
+        return _LeafCtx(self)
+
+    def leaf_to_side(self):
+        if self.leaf_pending:
+            self.ops.append(["edge", None, (2, 1), 0])
+            self.leaf_pending = False
+            self.forks += 1          # the side stream now carries the leaf stream's work: a join must follow
+
     def join(self):
+        self.leaf_to_side()
         if self.forks:
             self.ops.append(["join", None, None, 0])
             self.forks = 0
@@ -225,7 +241,10 @@ class Plan:
         try:
             for name, fn, args, sid in self.ops:
                 if fn is None:
-                    rc = lib.tpgsr_plan_add_fork(h) if name == "fork" else lib.tpgsr_plan_add_join(h)
+                    if name == "edge":
+                        rc = lib.tpgsr_plan_add_edge(h, args[0], args[1])
+                    else:
+                        rc = lib.tpgsr_plan_add_fork(h) if name == "fork" else lib.tpgsr_plan_add_join(h)
                 else:
                     types = fn.argtypes[:-1]          # the trailing stream is supplied at run time
                     arr = (_lib.PlanArg * max(1, len(types)))()
@@ -247,6 +266,7 @@ class Plan:
         assert lib.tpgsr_plan_size(h) == len(self.ops)
         self._native = h
         self._has_side = any(fn is None for _, fn, _, _ in self.ops)
+        self._has_leaf = any(sid == 2 for _, _, _, sid in self.ops)
 
     def run(self):
         if not self._native:
@@ -255,24 +275,25 @@ class Plan:
             return
         main = torch.cuda.current_stream()
         side = side_stream(main.device).cuda_stream if self._has_side else None
-        rc = _lib.load().tpgsr_plan_run(self._native, main.cuda_stream, side)
+        leaf = aux_stream(main.device).cuda_stream if self._has_leaf else None
+        rc = _lib.load().tpgsr_plan_run3(self._native, main.cuda_stream, side, leaf)
         if rc:
             check(rc, self.name)
 
     def run_interpreted(self):
         """The same replay op by op through ctypes (reference implementation of run(); tests compare the two)."""
         main = torch.cuda.current_stream()
-        streams = (main.cuda_stream, None)
-        side = None
+        side, leaf = side_stream(main.device), aux_stream(main.device)
+        objs = (main, side, leaf)
+        streams = (main.cuda_stream, side.cuda_stream, leaf.cuda_stream)
         for name, fn, args, sid in self.ops:
             if fn is None:
-                if side is None:
-                    side = side_stream(main.device)
-                    streams = (main.cuda_stream, side.cuda_stream)
                 if name == "fork":
                     side.wait_stream(main)
-                else:
+                elif name == "join":
                     main.wait_stream(side)
+                else:
+                    objs[args[1]].wait_stream(objs[args[0]])
                 continue
             rc = fn(*args, streams[sid])
             if rc:
@@ -306,6 +327,22 @@ class _SideCtx:
         return False
 
 
+class _LeafCtx:
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        p = self.plan
+        assert p.sid == 0, "leaf section inside another stream section"
+        p.ops.append(["edge", None, (0, 2), 0])
+        p.sid = 2
+        p.leaf_pending = True
+
+    def __exit__(self, *exc):
+        self.plan.sid = 0
+        return False
+
+
 class _NoSide:
     def __enter__(self):
         return None
@@ -315,8 +352,19 @@ class _NoSide:
 
 
 def side():
-    """Side-stream section of the plan being recorded (no-op when launching eagerly outside a plan)."""
-    return _REC.side() if _REC is not None and getattr(_REC, "overlap", False) else _NoSide()
+    """Side-stream section of the plan being recorded (no-op when launching eagerly outside a plan, and inside a leaf section:
+    the leaf stream runs its own weight gradients in order)."""
+    return _REC.side() if _REC is not None and getattr(_REC, "overlap", False) and _REC.sid != 2 else _NoSide()
+
+
+def leaf():
+    """Leaf-stream section of the plan being recorded (Plan.leaf); no-op unless the plan opted in (`use_leaf`)."""
+    return _REC.leaf() if _REC is not None and getattr(_REC, "overlap", False) and getattr(_REC, "use_leaf", False) else _NoSide()
+
+
+def stream_tag() -> str:
+    """suffix for stream-ordered scratch buffers: launches recorded on the leaf stream must not share them with the main stream's"""
+    return "_leaf" if (_REC is not None and _REC.sid == 2) else ""
 
 
 class DynPtr:
@@ -478,7 +526,7 @@ _DY_SCRATCH = {}
 
 
 def _dy_scratch(nbytes: int, device) -> torch.Tensor:
-    key = (str(device), current_stream().cuda_stream)
+    key = (str(device), current_stream().cuda_stream, stream_tag())     # (the leaf stream's launches get their own)
     bufs = _DY_SCRATCH.setdefault(key, [])
     if not bufs or bufs[-1].numel() < nbytes:
         bufs.append(torch.empty(nbytes, dtype=torch.uint8, device=device))

@@ -23,6 +23,16 @@ class Model(nn.Module):
         self.SequenceModeling_output = self.FeatureExtraction_output
         self.Prediction = LinearParams(self.SequenceModeling_output, g("num_class"))
 
+    def _engine(self):
+        """engine adapter (tpgsr_amd/engine_functional.py): lets TPGSRTrainStep / FusedAdam / ArenaPool drive this recogniser as a
+        student or teacher of the fused train step (`--tpg OPT`, interfaces/super_resolution.py:77-80)"""
+        eng = self.__dict__.get("_eng")
+        if eng is None:
+            from ...engine_functional import FunctionalEngine
+            eng = FunctionalEngine(self)
+            self.__dict__["_eng"] = eng
+        return eng
+
     def forward(self, input, text=None, is_train=True):
         feat = self.FeatureExtraction(Fh.to_nhwc(input))          # (N, h, 26, 512) NHWC
         seq = Fh.mean_over_height(feat)                           # (N, 26, 512) == the reference's permute + pool + squeeze

@@ -34,8 +34,10 @@ def gaussian(window_size, sigma):
 
 
 def create_window(window_size, channel=1):
+    """utils/ssim_psnr.py:23-27: (channel, 1, window_size, window_size), the same Gaussian taps for every channel"""
     w1 = gaussian(window_size, 1.5).unsqueeze(1)
-    return w1.mm(w1.t()).float().contiguous()          # the same (window_size, window_size) taps for every channel
+    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous()
 
 
 class SSIM(torch.nn.Module):
@@ -45,7 +47,7 @@ class SSIM(torch.nn.Module):
             raise NotImplementedError("the TPGSR evaluation path uses size_average=True (interfaces/super_resolution.py)")
         self.window_size = window_size
         self.size_average = size_average
-        self.register_buffer("window", create_window(window_size), persistent=False)
+        self.register_buffer("window", create_window(window_size, 1)[0, 0].contiguous(), persistent=False)   # the kernel takes the 2-D taps
 
     def forward(self, img1, img2):
         from .. import kernels as K
