@@ -326,6 +326,8 @@ int tpgsr_bigru_fwd(const float* gi, const float* w_hh /* [2][96][32] */, const 
  * as plain GEMMs / column sums (tpgsr_conv_wgrad against the input resp. the one-step-shifted states). */
 int tpgsr_bigru_bwd(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
                     const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dgh, void* stream);
+/* look-ahead, in time steps, of the operand prefetch rings of tpgsr_bigru_fwd / _bwd: 4, 8 (default) or 12 (TPGSR_GRU_PF); speed only */
+void tpgsr_gru_set_prefetch(int steps);
 
 /* ------------------------------------------------------------------------------------------------
  * STN / TPS rectification -- model/tps_spatial_transformer.py:97-112, grid_sample :10-18
@@ -404,12 +406,23 @@ int tpgsr_lstm_stepx_fwd(float* G, const void* wfr, const float* bhh, float* Cst
 int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hx, unsigned* sync, int N, int T,
                        int Hh, void* stream);
 long long tpgsr_lstm_seq_hx_bytes(void);
+/* The same forward recurrence with a DATA-TAGGED hand-off (8-byte {three bf16 terms of h, tag} granules, no counter, no wait for the
+ * stores; csrc/lstm_seq.hip).  hg: tpgsr_lstm_seq_hg_bytes() bytes and sync: 8 x u32, both ZEROED ONCE by the caller and then owned by
+ * these launches (the launch epoch lives in sync[4..5]); T <= 31.  sync[2] != 0: a hand-off timed out. */
+int tpgsr_lstm_seq_fwdg(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hg, unsigned* sync, int N, int T,
+                        int Hh, void* stream);
+long long tpgsr_lstm_seq_hg_bytes(void);
 /* BiLSTM backward recurrence (BPTT of nn.LSTM, model/crnn/crnn.py:10) as ONE persistent launch (replaces the T x (tpgsr_lstm_rec_gemm +
  * tpgsr_lstm_step_bwd) loop): G activated gates in, gate gradients out; dout [N][T][2Hh] = dL/dh; w0 / w1 = weight_hh_l0 / _reverse
  * [4Hh][Hh] as stored; px: exchange buffer of tpgsr_lstm_seq_px_bytes() bytes (no initialisation); sync as above. */
 int tpgsr_lstm_seq_bwd(float* G, const float* Cst, const float* dout, const float* w0, const float* w1, void* px, unsigned* sync, int N,
                        int T, int Hh, void* stream);
 long long tpgsr_lstm_seq_px_bytes(void);
+/* The backward recurrence with the data-tagged hand-off (8-byte {fp32 partial sum, tag} granules): pg of tpgsr_lstm_seq_pg_bytes() bytes and
+ * sync (8 x u32) ZEROED ONCE by the caller, then owned by these launches; T <= 255. */
+int tpgsr_lstm_seq_bwdg(float* G, const float* Cst, const float* dout, const float* w0, const float* w1, void* pg, unsigned* sync, int N,
+                        int T, int Hh, void* stream);
+long long tpgsr_lstm_seq_pg_bytes(void);
 int tpgsr_lstm_step_bwd(float* G, const float* Cst, const float* dout, const float* dhc, int nsplit, float* dcc, int N, int T,
                         int Hh, int step, void* stream);
 /* p = softmax(logits [N][T][C]); prior (N,C,1,T) = p with samples [0, drop_n) zeroed (prior dropout); with q: partial

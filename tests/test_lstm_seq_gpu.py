@@ -155,3 +155,57 @@ def test_lstm_seq_under_load_from_another_stream():
         assert int(sync[2].item()) == 0 and int(syncb[2].item()) == 0
         for a, b_ in zip(quiet, loaded):
             assert torch.equal(a, b_)
+
+
+def test_lstm_seq_granule_handoff_equals_counter_handoff():
+    """the data-tagged forward kernel (8-byte {h terms, tag} granules, no counter) runs the same arithmetic in the same order as the
+    counter kernel: bitwise equal outputs -- over repeated launches on ONE exchange buffer (the launch epoch must keep stale tags
+    from matching), with the batch size changing between launches, and next to a stream of memory-bound kernels"""
+    from tpgsr_amd import kernels as K
+    dev = torch.device(DEV)
+    hx, sync = K.lstm_seq_buffers(dev)
+    hg, gsync = K.lstm_seq_granule_buffers(dev)
+    px, bsync = K.lstm_seq_bwd_buffers(dev)
+    pg, bgsync = K.lstm_seq_bwd_granule_buffers(dev)
+    noise_a, noise_b = torch.randn(32 << 20, device=DEV), torch.empty(32 << 20, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for rep, (N, T) in enumerate([(48, 26), (48, 26), (5, 3), (64, 31), (48, 26), (33, 1), (48, 26)]):
+        g = torch.Generator().manual_seed(1000 + rep)
+        Gin = torch.randn(N, T, 2, 4 * Hh, generator=g).to(DEV)
+        WT = (torch.randn(2, Hh, 4 * Hh, generator=g) / Hh ** 0.5).to(DEV)
+        b = torch.randn(2, 4 * Hh, generator=g).to(DEV)
+        res = []
+        for gran in (False, True):
+            G = Gin.clone()
+            Cst = torch.full((N, T, 2, Hh), float("nan"), device=DEV)
+            out = torch.full((N, T, 2 * Hh), float("nan"), device=DEV)
+            if rep >= 4:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        K.copy(noise_a, noise_b, noise_a.numel())
+            if gran:
+                K.lstm_seq_fwdg(G, WT, b, Cst, out, hg, gsync, N, T, Hh)
+            else:
+                K.lstm_seq_fwd(G, WT, b, Cst, out, hx, sync, N, T, Hh)
+            torch.cuda.synchronize()
+            res.append((G, Cst, out))
+        assert int(sync[2].item()) == 0 and int(gsync[2].item()) == 0, "a hand-off timed out"
+        assert int(gsync[4].item()) == rep + 1 and int(gsync[5].item()) == rep + 1          # one epoch per launch and direction
+        for a, b_ in zip(res[0], res[1]):
+            assert torch.equal(a, b_), (rep, N, T)
+        # backward recurrence: granule hand-off == counter hand-off, bit for bit
+        G, Cst, _ = res[0]
+        dout = torch.randn(N, T, 2 * Hh, generator=g).to(DEV)
+        w = [WT[d].t().contiguous() for d in range(2)]
+        Ga, Gb = G.clone(), G.clone()
+        if rep >= 4:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    K.copy(noise_a, noise_b, noise_a.numel())
+        K.lstm_seq_bwd(Ga, Cst, dout, w[0], w[1], px, bsync, N, T, Hh)
+        K.lstm_seq_bwdg(Gb, Cst, dout, w[0], w[1], pg, bgsync, N, T, Hh)
+        torch.cuda.synchronize()
+        assert int(bsync[2].item()) == 0 and int(bgsync[2].item()) == 0, "a backward hand-off timed out"
+        assert int(bgsync[4].item()) == rep + 1 and int(bgsync[5].item()) == rep + 1
+        assert torch.equal(Ga, Gb), (rep, N, T)

@@ -130,8 +130,12 @@ _SIGS = {
     "tpgsr_lstm_step_fwd": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_hx_bytes": (C.c_longlong, []),
+    "tpgsr_lstm_seq_fwdg": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "tpgsr_lstm_seq_hg_bytes": (C.c_longlong, []),
     "tpgsr_lstm_seq_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_px_bytes": (C.c_longlong, []),
+    "tpgsr_lstm_seq_bwdg": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "tpgsr_lstm_seq_pg_bytes": (C.c_longlong, []),
     "tpgsr_lstm_wfrag_bytes": (C.c_longlong, []),
     "tpgsr_lstm_wfrag": (ci, [vp, vp, ci, vp]),
     "tpgsr_lstm_stepx_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
@@ -185,6 +189,7 @@ _SIGS = {
     "tpgsr_panel_set_enabled": (None, [ci]),
     "tpgsr_panel_set_min_m": (None, [C.c_longlong]),
     "tpgsr_panel_set_k192": (None, [ci]),
+    "tpgsr_gru_set_prefetch": (None, [ci]),
     "tpgsr_mfma_bf16_probe": (ci, [vp, vp, vp, vp, ci, vp]),
 }
 

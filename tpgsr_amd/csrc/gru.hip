@@ -10,6 +10,7 @@
 // Gate math == nn.GRU:  r = s(gi_r + W_hr h + b_hr), z likewise, n = tanh(gi_n + r*(W_hn h + b_hn)),
 // h' = (1-z)*n + z*h, gi = W_i x + b_i precomputed by the MFMA GEMM (tpgsr_conv_fwd).
 #include "common.h"
+#include <stdlib.h>
 
 #define GRU_H 32
 // one wavefront per workgroup: the per-step barrier degenerates to wave-local ordering
@@ -48,6 +49,7 @@ __device__ __forceinline__ f2 mk2(float x, float y) {
   return v;
 }
 
+template <int PF>
 __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                         const float* __restrict__ b_hh, int N, int H, int W, int axis,
                                                         float* __restrict__ h_out, float* __restrict__ gates) {
@@ -75,7 +77,6 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
   // The input projections do not depend on the recurrence: they are fetched PF steps ahead through a small register ring.  One
   // step of look-ahead (a serial step is ~600 cycles) left the wave waiting on memory in EVERY step whenever a load took longer
   // than that -- i.e. always, next to the other kernels of the training step (the backward kernel below learnt this first).
-  constexpr int PF = 6;
   struct StepIn {
     float r, z, n;
   };
@@ -129,13 +130,21 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
   }
 }
 
+// look-ahead (in time steps) of the operand prefetch rings of both kernels: TPGSR_GRU_PF = 4 | 8 (default) | 12.  Loads and stores
+// retire in order on one counter per wave, so a ring slot is only as far ahead as the stores issued before it allow.
+static int g_gru_pf = [] { const char* e = getenv("TPGSR_GRU_PF"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 12) ? v : 8; }();
+extern "C" void tpgsr_gru_set_prefetch(int steps) { g_gru_pf = (steps == 4 || steps == 12) ? steps : 8; }
+
 extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* b_hh, int N, int H, int W, int axis,
                                float* h_out, float* gates, void* stream) {
   TPGSR_CHECK_ARG(gi && w_hh && b_hh && h_out, "tpgsr_bigru_fwd: null pointer");
   TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "tpgsr_bigru_fwd: bad geometry");
   int nseq = axis == 0 ? N * H : N * W;
-  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out,
-                     gates);
+  switch (g_gru_pf) {
+    case 4: hipLaunchKernelGGL(bigru_fwd_kernel<4>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); break;
+    case 12: hipLaunchKernelGGL(bigru_fwd_kernel<12>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); break;
+    default: hipLaunchKernelGGL(bigru_fwd_kernel<8>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); break;
+  }
   TPGSR_LAUNCH_CHECK("tpgsr_bigru_fwd");
 }
 
@@ -145,6 +154,7 @@ extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* 
 //   outputs: dgi [P][192]  = (dr_pre, dz_pre, dn_pre)   -> dW_ih, db_ih, d(input) by GEMM
 //            dgh [P][192]  = (dr_pre, dz_pre, dn_pre*r) -> dW_hh, db_hh by GEMM against the shifted states
 // ------------------------------------------------------------------------------------------------------
+template <int PF>
 __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ h_out,
                                                         const float* __restrict__ dh_out, const float* __restrict__ dh_out2,
                                                         const float* __restrict__ w_hh, int N, int H, int W, int axis,
@@ -184,7 +194,6 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
   // The operands do not depend on the recurrence, so they are fetched PF steps ahead through a small register ring: next
   // to the weight-gradient GEMMs of the side stream a load takes several times its idle latency, and one step of
   // look-ahead (the whole serial step is ~550 cycles) left the wave waiting on memory every step (75 us vs 35 us alone).
-  constexpr int PF = 4;
   StepIn ring[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) ring[i] = fetch(T - 1 - i);
@@ -236,7 +245,10 @@ extern "C" int tpgsr_bigru_bwd(const float* gates, const float* h_out, const flo
   TPGSR_CHECK_ARG(gates && h_out && dh_out && w_hh && dgi && dgh, "tpgsr_bigru_bwd: null pointer");
   TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "tpgsr_bigru_bwd: bad geometry");
   int nseq = axis == 0 ? N * H : N * W;
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N,
-                     H, W, axis, dgi, dgh);
+  switch (g_gru_pf) {
+    case 4: hipLaunchKernelGGL(bigru_bwd_kernel<4>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+    case 12: hipLaunchKernelGGL(bigru_bwd_kernel<12>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+    default: hipLaunchKernelGGL(bigru_bwd_kernel<8>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+  }
   TPGSR_LAUNCH_CHECK("tpgsr_bigru_bwd");
 }

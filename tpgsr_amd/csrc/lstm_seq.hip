@@ -57,12 +57,12 @@ __device__ __forceinline__ floatx16 ls_mfma6(const ls_bf16x8 (&a)[3], const ls_b
 }
 
 // one lane: wait until `target` workgroups have arrived on *cnt (relaxed agent-scope polls; a sleeping poller costs the memory
-// system next to nothing).  ~seconds without progress: set the timeout flag and give up rather than hang the GPU.
+// system next to nothing).  ~0.1 s without progress: set the timeout flag and give up rather than hang the GPU.
 __device__ __forceinline__ void ls_wait(unsigned* cnt, unsigned target, unsigned* flag) {
   int spins = 0;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 22)) {
+    if (++spins > (1 << 17)) {
       __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
@@ -213,6 +213,177 @@ extern "C" int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh,
   hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(2 * LS_NW), dim3(256), 0, (hipStream_t)stream, G, whhT, bhh, Cst, out, (unsigned short*)hx,
                      sync, N, T);
   TPGSR_LAUNCH_CHECK("tpgsr_lstm_seq_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward, DATA-TAGGED hand-off ("granules", MI355X_MICROARCH.md price list: handoff-1to1 / allgather rows): no counter, no flag, no wait
+// for the stores at all.  Every published value is one naturally aligned 8-byte granule {h1, h2, h3 (the three bf16 terms), tag}
+// written by ONE sc1 store (two granules per 16-byte store; each 8-byte half lands untorn); tag = (launch epoch, step).  A consumer
+// loads the granules it needs with sc1 loads and simply re-loads until every tag is this step's: the data is its own flag, so
+// the per-step chain is  store -> (memory) -> load  instead of  store -> wait for the write-through ack -> barrier -> atomic ->
+// poll -> barrier -> load.  Stale tags cannot match: the epoch (sync[4 + d], bumped by workgroup (d, 0) when it finishes -- which
+// implies every workgroup of direction d has read it) changes with every launch, the step with every use of a parity buffer.
+//   hg   [2 parity][2 dir][2 row blocks][16 k-blocks][4 quads][64 lanes][2] granules of 8 B (512 KB), zeroed ONCE by the caller:
+//        fragment lane l of k-block kb needs the 8 granules k = 16 kb + 8 (l >> 5) + j of row (l & 31); quad q holds j = 2q, 2q + 1,
+//        so one load instruction of a wave is 1 KB contiguous
+//   sync [8] u32: [2] timeout flag, [4 + d] launch epoch of direction d; zeroed ONCE by the caller (not per launch)
+// Needs T <= 31 (5 tag bits for the step).  LDS: W fragments 48 KB | partial sums, double-buffered by step parity, 2 x 16 KB |
+// cell state 2 KB | b_hh.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ G, const float* __restrict__ whhT,
+                                                            const float* __restrict__ bhh, float* __restrict__ Cst,
+                                                            float* __restrict__ out, unsigned* __restrict__ hg,
+                                                            unsigned* __restrict__ sync, int N, int T) {
+  constexpr int Hh = 256, G4 = 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char lsm[48 * 1024 + 32 * 1024 + 2 * 1024 + 128];
+  unsigned short* wfr = reinterpret_cast<unsigned short*>(lsm);
+  float* red0 = reinterpret_cast<float*>(lsm + 48 * 1024);
+  float* cst = reinterpret_cast<float*>(lsm + 80 * 1024);
+  float* bsm = reinterpret_cast<float*>(lsm + 82 * 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.x / LS_NW, u = blockIdx.x % LS_NW, u0 = u * 8;
+  const float* W = whhT + (size_t)d * Hh * G4;
+  for (int idx = tid; idx < 16 * 64; idx += 256) {
+    const int kb = idx >> 6, l = idx & 63, c = l & 31;
+    const int col = (c >> 3) * Hh + u0 + (c & 7);
+    unsigned short hv[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ls_split3(W[(size_t)(kb * 16 + (l >> 5) * 8 + j) * G4 + col], hv[j]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      unsigned short* dst = wfr + ((size_t)(t * 16 + kb) * 64 + l) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = hv[j][t];
+    }
+  }
+  for (int i = tid; i < 64 * 8; i += 256) cst[i] = 0.f;
+  if (tid < 32) bsm[tid] = bhh ? bhh[(size_t)d * G4 + (tid >> 3) * Hh + u0 + (tid & 7)] : 0.f;
+  const unsigned ep = sync[4 + d] & 0x7ffu;         // written by the previous launch on this stream (kernel boundary: visible)
+  __syncthreads();
+  const int rb = wave & 1, kh = wave >> 1;
+  const unsigned dir_bytes = 2u * 16 * 4 * 64 * 16, par_bytes = 2 * dir_bytes;
+  const __amdgpu_buffer_rsrc_t rs = ls_rsrc(hg, 2 * (size_t)par_bytes);
+  const int ul = tid & 7;
+  const bool row_live = rb * 32 + (lane & 31) < N;   // rows past the batch are never published: their tags are not checked
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? s : T - 1 - s;
+    float pre[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int n = (tid >> 3) + 32 * it;
+      if (n < N) {
+        const float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + u0 + ul;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre[it][q] = g[q * Hh];
+      }
+    }
+    float* red = red0 + (s & 1) * 4096;
+    if (s > 0) {
+      const unsigned want = ((ep << 5) | (unsigned)s) << 16;                       // tag of step s - 1's data = (epoch, (s - 1) + 1)
+      const unsigned base = (unsigned)(((s - 1) & 1) * par_bytes + d * dir_bytes) + ((unsigned)(rb * 16 + kh * 8) * 4 * 64 + lane) * 16u;
+      ls_u32x4 raw[8][4];
+      int tries = 0;
+      while (true) {
+        // (the compiler treats buffer loads as ordinary reads: without this barrier it hoists all 32 of them OUT of the retry loop
+        //  and the loop only sleeps -- seen in the ISA of the first version, which timed out on every hand-off)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            raw[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(base + (unsigned)((i * 4 + q) * 64) * 16u), 0, LS_SC1);
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bad |= (raw[i][q].y ^ want) | (raw[i][q].w ^ want);
+        const bool ok = !row_live || (bad >> 16) == 0;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++tries > (1 << 14)) {          // tens of ms without progress: flag it and go on with what is there rather than hang the GPU
+          if (lane == 0) __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      floatx16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ls_u32x4 av[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // granule pair (x, y), (z, w): x / z = h1 | h2 << 16, y / w = h3 | tag << 16
+          av[0][q] = __builtin_amdgcn_perm(raw[i][q].z, raw[i][q].x, 0x05040100u);
+          av[1][q] = __builtin_amdgcn_perm(raw[i][q].z, raw[i][q].x, 0x07060302u);
+          av[2][q] = __builtin_amdgcn_perm(raw[i][q].w, raw[i][q].y, 0x05040100u);
+        }
+        ls_bf16x8 a[3], b[3];
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          a[tt] = __builtin_bit_cast(ls_bf16x8, av[tt]);
+          b[tt] = *reinterpret_cast<const ls_bf16x8*>(wfr + ((size_t)(tt * 16 + kh * 8 + i) * 64 + lane) * 8);
+        }
+        acc = ls_mfma6(a, b, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[(kh * 64 + row) * 32 + (lane & 31)] = acc[r];
+      }
+      __syncthreads();      // the only barrier of a step (red is double-buffered by step parity)
+    }
+    const unsigned tagw = ((ep << 5) | (unsigned)(s + 1)) << 16;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int n = (tid >> 3) + 32 * it;
+      unsigned glo = 0, ghi = 0;
+      if (n < N) {
+        const int item = n * 8 + ul, unit = u0 + ul;
+        float p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          p[q] = pre[it][q] + bsm[q * 8 + ul];
+          if (s > 0) p[q] += red[n * 32 + q * 8 + ul] + red[(64 + n) * 32 + q * 8 + ul];
+        }
+        const float ig = sigmoid_f(p[0]), fg = sigmoid_f(p[1]), gg = tanh_f(p[2]), og = sigmoid_f(p[3]);
+        const float c = fg * cst[item] + ig * gg;
+        const float h = og * tanh_f(c);
+        cst[item] = c;
+        unsigned short hv[3];
+        ls_split3(h, hv);
+        glo = (unsigned)hv[0] | ((unsigned)hv[1] << 16);
+        ghi = (unsigned)hv[2] | tagw;
+        float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + unit;
+        g[0] = ig;
+        g[Hh] = fg;
+        g[2 * Hh] = gg;
+        g[3 * Hh] = og;
+        Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = c;
+        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = h;
+      }
+      if (s + 1 < T) {      // publish: the even unit of a pair stores both granules (16 bytes, write-through), nothing waits for it
+        const unsigned nlo = __shfl_xor(glo, 1), nhi = __shfl_xor(ghi, 1);
+        if (n < N && !(ul & 1)) {
+          ls_u32x4 v;
+          v.x = glo; v.y = ghi; v.z = nlo; v.w = nhi;
+          const unsigned off = (unsigned)((s & 1) * par_bytes + d * dir_bytes) +
+                               ((((unsigned)((n >> 5) * 16 + (u >> 1)) * 4 + (ul >> 1)) * 64) + (u & 1) * 32 + (n & 31)) * 16u;
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, LS_SC1);
+        }
+      }
+    }
+  }
+  if (u == 0 && tid == 0) sync[4 + d] = ep + 1;     // this workgroup is done => everybody of direction d has read the epoch long ago
+}
+
+extern "C" long long tpgsr_lstm_seq_hg_bytes(void) { return 2ll * 2 * 2 * 16 * 4 * 64 * 16; }
+
+extern "C" int tpgsr_lstm_seq_fwdg(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hg, unsigned* sync, int N,
+                                   int T, int Hh, void* stream) {
+  TPGSR_CHECK_ARG(G && whhT && Cst && out && hg && sync && N > 0 && N <= 64 && T > 0 && T <= 31 && Hh == 256,
+                  "tpgsr_lstm_seq_fwdg: needs Hh == 256, 1 <= N <= 64, 1 <= T <= 31 and non-null buffers (got Hh %d, N %d, T %d)", Hh, N, T);
+  hipLaunchKernelGGL(lstm_seq_fwdg_kernel, dim3(2 * LS_NW), dim3(256), 0, (hipStream_t)stream, G, whhT, bhh, Cst, out, (unsigned*)hg, sync, N, T);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_seq_fwdg");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -389,6 +560,231 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
       if (tid == 0) __hip_atomic_fetch_add(sync + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward with the DATA-TAGGED hand-off (as lstm_seq_fwdg_kernel): every partial sum travels as an 8-byte granule {fp32 value, tag =
+// (launch epoch, step)}; a consumer re-loads its 96 KB until every tag is this step's.  Twice the bytes of the counter form, but no
+// wait for the write-through acknowledgement, no arrival counter and no poll on the per-step chain.
+//   pg   [2 parity][2 dir][32 consumers][32 producers][8 units][64 rows] granules (16 MB), zeroed ONCE by the caller;
+//   sync [8] u32 as for the forward kernel (epoch in sync[4 + d]), zeroed ONCE by the caller.   T < 256.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_seq_bwdg_kernel(float* __restrict__ G, const float* __restrict__ Cst,
+                                                           const float* __restrict__ dout, const float* __restrict__ w0,
+                                                           const float* __restrict__ w1, unsigned* __restrict__ pg,
+                                                           unsigned* __restrict__ sync, int N, int T) {
+  constexpr int Hh = 256, G4 = 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsb[];
+  unsigned short* wfr = reinterpret_cast<unsigned short*>(lsb);
+  float* pst = reinterpret_cast<float*>(lsb + 48 * 1024);
+  unsigned short* afr = reinterpret_cast<unsigned short*>(lsb + 48 * 1024 + 256 * LSB_PLD * 4);
+  float* rsum = reinterpret_cast<float*>(lsb + 48 * 1024 + 256 * LSB_PLD * 4 + 12 * 1024);
+  float* dcc = reinterpret_cast<float*>(lsb + 48 * 1024 + 256 * LSB_PLD * 4 + 16 * 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.x / LS_NW, u = blockIdx.x % LS_NW, u0 = u * 8;
+  const float* W = d == 0 ? w0 : w1;
+  // B operand of (n-block nb, k-block kb): lane l holds unit nb 32 + (l & 31), k = 16 kb + 8 (l >> 5) + j <-> gate column (k >> 3) Hh + u0 + (k & 7)
+  for (int idx = tid; idx < 8 * 2 * 64; idx += 256) {
+    const int nb = idx >> 7, kb = (idx >> 6) & 1, l = idx & 63;
+    const int unit = nb * 32 + (l & 31);
+    unsigned short hv[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kb * 16 + (l >> 5) * 8 + j;
+      ls_split3(W[(size_t)((k >> 3) * Hh + u0 + (k & 7)) * Hh + unit], hv[j]);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      unsigned short* dst = wfr + ((size_t)((t * 8 + nb) * 2 + kb) * 64 + l) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = hv[j][t];
+    }
+  }
+  for (int i = tid; i < 3 * 2 * 2 * 64 * 8 / 2; i += 256) reinterpret_cast<unsigned*>(afr)[i] = 0u;   // rows >= N stay zero
+  for (int i = tid; i < 64 * 8; i += 256) dcc[i] = 0.f;
+  __syncthreads();
+  const int rb = wave & 1, nbh = wave >> 1;
+  const size_t dir_f = (size_t)32 * 32 * 8 * 64, par_f = 2 * dir_f;    // granules of 8 bytes {partial sum, tag}
+  const __amdgpu_buffer_rsrc_t rs_px = ls_rsrc(pg, 2 * par_f * 8);
+  const unsigned ep = sync[4 + d] & 0xffffffu;
+  const int ul = tid & 7;
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    const int tp = d == 0 ? t - 1 : t + 1;           // previous state in this direction's forward order
+    const bool has_prev = d == 0 ? t > 0 : t < T - 1;
+    // everything of this step that does not depend on the exchange
+    float gt[2][4], cc[2], cp[2], dh[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int n = (tid >> 3) + 32 * it;
+      if (n < N) {
+        const float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + u0 + ul;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gt[it][q] = g[q * Hh];
+        cc[it] = Cst[(((size_t)n * T + t) * 2 + d) * Hh + u0 + ul];
+        cp[it] = has_prev ? Cst[(((size_t)n * T + tp) * 2 + d) * Hh + u0 + ul] : 0.f;
+        dh[it] = dout[((size_t)n * T + t) * 2 * Hh + d * Hh + u0 + ul];
+      }
+    }
+    if (s > 0) {
+      // gather: my region [32 producers][8 units][64 rows] of granules; thread = (producer group g of 16, unit gu, row quad rq).
+      // The data is its own flag: re-load until every granule carries (epoch, step s - 1)'s tag.
+      const int g = tid >> 7, gu = (tid >> 4) & 7, rq = tid & 15;
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool live = rq * 4 < N;
+      const unsigned want = (ep << 8) | (unsigned)s;
+      const unsigned base = (unsigned)((((s - 1) & 1) * par_f + d * dir_f + (size_t)u * 32 * 8 * 64) * 8);
+      ls_u32x4 v[16][2];
+      int tries = 0;
+      while (true) {
+        asm volatile("" ::: "memory");      // keeps the loads inside the retry loop (see lstm_seq_fwdg_kernel)
+        if (live) {
+#pragma unroll
+          for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+              v[p][hh] = __builtin_amdgcn_raw_buffer_load_b128(
+                  rs_px, (int)(base + ((((unsigned)(g * 16 + p) * 8 + gu) * 64 + rq * 4 + hh * 2) * 8)), 0, LS_SC1);
+        }
+        unsigned bad = 0;
+        if (live) {
+#pragma unroll
+          for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) bad |= (v[p][hh].y ^ want) | (v[p][hh].w ^ want);
+        }
+        if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++tries > (1 << 14)) {
+          if (lane == 0) __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {     // producer order: deterministic
+          sum.x += __uint_as_float(v[p][0].x);
+          sum.y += __uint_as_float(v[p][0].z);
+          sum.z += __uint_as_float(v[p][1].x);
+          sum.w += __uint_as_float(v[p][1].z);
+        }
+      }
+      *reinterpret_cast<float4*>(rsum + ((g * 8 + gu) * 64 + rq * 4)) = sum;
+      __syncthreads();
+    }
+    // cell backward: item = (sequence n, local unit ul); the gate gradients go to G and, split, into the A fragments of the next step
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int n = (tid >> 3) + 32 * it;
+      if (n < N) {
+        const int item = n * 8 + ul;
+        const float ig = gt[it][0], fg = gt[it][1], gg = gt[it][2], og = gt[it][3];
+        float dhh = dh[it], dc = 0.f;
+        if (s > 0) {
+          dhh += rsum[ul * 64 + n] + rsum[(8 + ul) * 64 + n];
+          dc = dcc[item];
+        }
+        const float tc = tanh_f(cc[it]);
+        const float dog = dhh * tc * og * (1.f - og);
+        dc += dhh * og * (1.f - tc * tc);
+        const float dig = dc * gg * ig * (1.f - ig);
+        const float dfg = dc * cp[it] * fg * (1.f - fg);
+        const float dgg = dc * ig * (1.f - gg * gg);
+        dcc[item] = dc * fg;
+        float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + u0 + ul;
+        g[0] = dig;
+        g[Hh] = dfg;
+        g[2 * Hh] = dgg;
+        g[3 * Hh] = dog;
+        const float dq[4] = {dig, dfg, dgg, dog};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // k = 8 q + ul: k-block q >> 1, fragment lane (q & 1) 32 + (n & 31), element ul
+          unsigned short hv[3];
+          ls_split3(dq[q], hv);
+#pragma unroll
+          for (int tt = 0; tt < 3; ++tt)
+            afr[((size_t)((tt * 2 + (n >> 5)) * 2 + (q >> 1)) * 64 + (q & 1) * 32 + (n & 31)) * 8 + ul] = hv[tt];
+        }
+      }
+    }
+    if (s + 1 < T) {
+      __syncthreads();
+      // P_u[n][256] = dG_u[n][32] W_hh[cols_u][256]: wave (row block rb, n-blocks 4 nbh .. 4 nbh + 3)
+      ls_bf16x8 a[2][3];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) a[kb][tt] = *reinterpret_cast<const ls_bf16x8*>(afr + ((size_t)((tt * 2 + rb) * 2 + kb) * 64 + lane) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nb = nbh * 4 + i;
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          ls_bf16x8 b[3];
+#pragma unroll
+          for (int tt = 0; tt < 3; ++tt) b[tt] = *reinterpret_cast<const ls_bf16x8*>(wfr + ((size_t)((tt * 8 + nb) * 2 + kb) * 64 + lane) * 8);
+          acc = ls_mfma6(a[kb], b, acc);
+        }
+        // staging image [unit][row]: a lane holds 4 consecutive rows of one unit per register quad
+        const int unit = nb * 32 + (lane & 31);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = rb * 32 + 8 * rg + 4 * (lane >> 5);
+          *reinterpret_cast<float4*>(pst + unit * LSB_PLD + row) = make_float4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+        }
+      }
+      __syncthreads();
+      // publish, coalesced: piece o = (unit, row quad) = four tagged granules = two 16-byte write-through stores; nothing waits for them
+      const unsigned wbase = (unsigned)(((s & 1) * par_f + d * dir_f) * 8);
+      const unsigned tagv = (ep << 8) | (unsigned)(s + 1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = tid + 256 * i, unit = o >> 4, rq = o & 15;
+        if (rq * 4 < N) {
+          const ls_u32x4 v = *reinterpret_cast<const ls_u32x4*>(pst + unit * LSB_PLD + rq * 4);
+          const unsigned off = wbase + (((((unsigned)(unit >> 3) * 32 + u) * 8 + (unit & 7)) * 64 + rq * 4) * 8);
+          ls_u32x4 lo, hi;
+          lo.x = v.x; lo.y = tagv; lo.z = v.y; lo.w = tagv;
+          hi.x = v.z; hi.y = tagv; hi.z = v.w; hi.w = tagv;
+          __builtin_amdgcn_raw_buffer_store_b128(lo, rs_px, (int)off, 0, LS_SC1);
+          __builtin_amdgcn_raw_buffer_store_b128(hi, rs_px, (int)(off + 16), 0, LS_SC1);
+        }
+      }
+    }
+  }
+  if (u == 0 && tid == 0) sync[4 + d] = ep + 1;     // see lstm_seq_fwdg_kernel
+}
+
+
+extern "C" long long tpgsr_lstm_seq_pg_bytes(void) { return 2ll * 2 * 32 * 32 * 8 * 64 * 8; }
+
+extern "C" int tpgsr_lstm_seq_bwdg(float* G, const float* Cst, const float* dout, const float* w0, const float* w1, void* pg,
+                                   unsigned* sync, int N, int T, int Hh, void* stream) {
+  TPGSR_CHECK_ARG(G && Cst && dout && w0 && w1 && pg && sync && N > 0 && N <= 64 && T > 0 && T < 256 && Hh == 256,
+                  "tpgsr_lstm_seq_bwdg: needs Hh == 256, 1 <= N <= 64, 1 <= T <= 255 and non-null buffers (got Hh %d, N %d, T %d)", Hh, N, T);
+  {   // opt in to > 64 KB of dynamic LDS, once per device
+    static std::mutex mu;
+    static unsigned long long done = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      tpgsr_set_error("tpgsr_lstm_seq_bwdg: hipGetDevice failed");
+      return TPGSR_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!(done >> dev & 1ull)) {
+      if (hipFuncSetAttribute((const void*)lstm_seq_bwdg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSB_LDS) != hipSuccess) {
+        tpgsr_set_error("tpgsr_lstm_seq_bwdg: LDS opt-in (%d bytes) failed", LSB_LDS);
+        return TPGSR_ERR_LAUNCH;
+      }
+      done |= 1ull << dev;
+    }
+  }
+  hipLaunchKernelGGL(lstm_seq_bwdg_kernel, dim3(2 * LS_NW), dim3(256), LSB_LDS, (hipStream_t)stream, G, Cst, dout, w0, w1, (unsigned*)pg, sync, N,
+                     T);
+  TPGSR_LAUNCH_CHECK("tpgsr_lstm_seq_bwdg");
 }
 
 extern "C" long long tpgsr_lstm_seq_px_bytes(void) { return 2ll * 2 * 32 * 32 * 8 * 64 * 4; }

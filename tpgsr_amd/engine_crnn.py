@@ -116,11 +116,12 @@ class LstmLayer:
         if K.LSTM_SEQ and Hh == 256 and N <= 64:             # the whole recurrence as one persistent launch
             if not hasattr(self, "_seq"):
                 self._seq = {}
-            key = K.current_stream().cuda_stream               # one exchange buffer per stream (the teacher runs on its own)
+            gran = K.LSTM_GRANULE and T <= 31
+            key = (K.current_stream().cuda_stream, gran)       # one exchange buffer per stream (the teacher runs on its own)
             if key not in self._seq:
-                self._seq[key] = K.lstm_seq_buffers(self.eng.device)
+                self._seq[key] = K.lstm_seq_granule_buffers(self.eng.device) if gran else K.lstm_seq_buffers(self.eng.device)
             hx, sync = self._seq[key]
-            K.lstm_seq_fwd(G, self.whh_f, self.bhh, Cst, out, hx, sync, N, T, Hh)
+            (K.lstm_seq_fwdg if gran else K.lstm_seq_fwd)(G, self.whh_f, self.bhh, Cst, out, hx, sync, N, T, Hh)
             self.emb.fwd(N, 1, T, out, e)
             return
         if K.LSTM_STEPX and Hh == 256 and N <= 64:           # one fused launch per time step
@@ -154,11 +155,12 @@ class LstmLayer:
         if seq:                                              # the whole BPTT recurrence as one persistent launch
             if not hasattr(self, "_seqb"):
                 self._seqb = {}
-            key = K.current_stream().cuda_stream
+            gran = K.LSTM_GRANULE_BWD and T <= 255
+            key = (K.current_stream().cuda_stream, gran)
             if key not in self._seqb:
-                self._seqb[key] = K.lstm_seq_bwd_buffers(self.eng.device)
+                self._seqb[key] = K.lstm_seq_bwd_granule_buffers(self.eng.device) if gran else K.lstm_seq_bwd_buffers(self.eng.device)
             px, sync = self._seqb[key]
-            K.lstm_seq_bwd(G, Cst, dout, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], px, sync, N, T, Hh)
+            (K.lstm_seq_bwdg if gran else K.lstm_seq_bwd)(G, Cst, dout, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], px, sync, N, T, Hh)
         for s in range(0 if seq else T):
             if s > 0:     # dh_prev = dG[t_next] W_hh (operand [K=4Hh][Hh] is the PyTorch weight itself), split over K
                 a = [G.data_ptr() + 4 * (((T - s if d == 0 else s - 1) * 2 + d) * G4) for d in range(2)]

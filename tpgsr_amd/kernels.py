@@ -805,8 +805,33 @@ def lstm_seq_buffers(device):
     return hx, torch.zeros(4, dtype=torch.int32, device=device)
 
 
+# data-tagged hand-off for the persistent forward kernel (8-byte {h terms, tag} granules, no arrival counter): TPGSR_LSTM_GRANULE=0 -> counter form
+LSTM_GRANULE = os.environ.get("TPGSR_LSTM_GRANULE", "1") == "1"
+LSTM_GRANULE_BWD = os.environ.get("TPGSR_LSTM_GRANULE_BWD", "0") == "1"
+
+
+def lstm_seq_fwdg(G, whhT, bhh, Cst, out, hg, sync, N, T, Hh):
+    _launch("tpgsr_lstm_seq_fwdg", _p(G), _p(whhT), _p(bhh), _p(Cst), _p(out), _p(hg), _p(sync), N, T, Hh)
+
+
+def lstm_seq_granule_buffers(device):
+    """(hg, sync) for lstm_seq_fwdg: both zeroed ONCE here, then owned by the launches (tags / launch epoch)"""
+    return (torch.zeros(_lib.load().tpgsr_lstm_seq_hg_bytes(), dtype=torch.uint8, device=device),
+            torch.zeros(8, dtype=torch.int32, device=device))
+
+
 def lstm_seq_bwd(G, Cst, dout, w0, w1, px, sync, N, T, Hh):
     _launch("tpgsr_lstm_seq_bwd", _p(G), _p(Cst), _p(dout), _p(w0), _p(w1), _p(px), _p(sync), N, T, Hh)
+
+
+def lstm_seq_bwdg(G, Cst, dout, w0, w1, pg, sync, N, T, Hh):
+    _launch("tpgsr_lstm_seq_bwdg", _p(G), _p(Cst), _p(dout), _p(w0), _p(w1), _p(pg), _p(sync), N, T, Hh)
+
+
+def lstm_seq_bwd_granule_buffers(device):
+    """(pg, sync) for lstm_seq_bwdg: zeroed ONCE here, then owned by the launches"""
+    return (torch.zeros(_lib.load().tpgsr_lstm_seq_pg_bytes(), dtype=torch.uint8, device=device),
+            torch.zeros(8, dtype=torch.int32, device=device))
 
 
 def lstm_seq_bwd_buffers(device):
