@@ -657,16 +657,21 @@ class TSRNEngine(_EngineBase):
                               lambda ws, final: self._record(N, H, W, training, ws, final, bool(defer_join)))
 
     def _record(self, N, H, W, training, ws, final, defer_join=False):
-        fwd, bwd = Plan("tsrn_fwd"), Plan("tsrn_bwd")
-        fwd.final = bwd.final = final
+        pre, fwd, bwd = Plan("tsrn_fwd_pre"), Plan("tsrn_fwd"), Plan("tsrn_bwd")
+        pre.final = fwd.final = bwd.final = final
         bwd.overlap = self.overlap_wgrad
         bwd.deferred = [] if self.defer_reduce else None
         bwd.use_leaf = self.leaf_stn and self.overlap_wgrad and self.defer_reduce
         self._cur_ws, self._wg_idx, self._compose = ws, 0, []
         for bn in self._bn_layers:
             bn.use(ws)
+        # the forward pass in two plans: everything that does not depend on the text prior (operand packing, the STN head + TPS
+        # rectification, block1) -- a train step launches it on another stream next to the text-prior generator's forward pass
+        # (forward_pre) -- and the rest
+        with recording(pre), K.conv_terms(K.terms_for("sr", "fwd")):
+            b1 = self._record_fwd_pre(N, H, W, training, ws)
         with recording(fwd), K.conv_terms(K.terms_for("sr", "fwd")):
-            self._record_fwd(N, H, W, training, ws)
+            self._record_fwd(N, H, W, training, ws, b1)
         if training:
             with recording(bwd), K.conv_terms(K.terms_for("sr", "bwd")):
                 self._record_bwd(N, H, W, ws)
@@ -676,10 +681,11 @@ class TSRNEngine(_EngineBase):
                 self.flush_compose_bwd()
                 if not defer_join:
                     bwd.join()
-        return dict(fwd=fwd, bwd=bwd, ws=ws)
+        return dict(pre=pre, fwd=fwd, bwd=bwd, ws=ws)
 
     # ---- forward -------------------------------------------------------------------------------------------------
-    def _record_fwd(self, N, H, W, training, ws):
+    def _record_fwd_pre(self, N, H, W, training, ws):
+        """model/tsrn.py:183-186 (STN, training only) and block1: independent of the text prior"""
         Cc, Ci = self.C, self.in_planes
         P1 = N * H * W
         self.pack_all()
@@ -692,6 +698,11 @@ class TSRNEngine(_EngineBase):
         b1 = ws("b1", P1, Cc)
         self.block1.fwd(N, H, W, xin, c1)
         K.prelu_fwd(c1, self.P["block1.1.weight"], P1 * Cc, b1)
+        return b1
+
+    def _record_fwd(self, N, H, W, training, ws, b1):
+        Cc, Ci = self.C, self.in_planes
+        P1 = N * H * W
         temb = self._record_infogen_fwd(N, W, training, ws) if self.tl else None
         cur = b1
         for i, L in enumerate(self.rrb):
@@ -930,8 +941,23 @@ class TSRNEngine(_EngineBase):
                 conv.dgrad(N, h, w, ds, dact)
 
     # ---- execution -----------------------------------------------------------------------------------------------
+    def forward_pre(self, x: torch.Tensor, training: bool, slot: int = 0, defer_join: bool = False):
+        """the prior-independent part of the forward pass (operand packing, STN head + rectification, block1) on the CURRENT stream;
+        the caller then runs forward(..., pre_done=True) on a stream ordered after it.  `x` must stay alive until then."""
+        if x.dim() != 4 or x.shape[1] != self.module.in_planes:
+            raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
+        if not x.is_cuda and not K.DRYRUN:
+            raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
+        self.bind(x.device)
+        N, _, H, W = x.shape
+        pl = self.plans(N, H, W, training, slot, defer_join and training)
+        if x.dtype != F32 or not x.is_contiguous():
+            raise ValueError("forward_pre needs a contiguous fp32 input (it is read asynchronously)")
+        pl["pre"].set_ptr("x", x.data_ptr())
+        pl["pre"].run()
+
     def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None, slot: int = 0,
-                defer_join: bool = False) -> torch.Tensor:
+                defer_join: bool = False, pre_done: bool = False) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.module.in_planes:
             raise ValueError(f"expected (N, {self.module.in_planes}, H, W) input, got {tuple(x.shape)}")
         if not x.is_cuda and not K.DRYRUN:
@@ -941,8 +967,10 @@ class TSRNEngine(_EngineBase):
         pl = self.plans(N, H, W, training, slot, defer_join and training)
         x = x.contiguous().float()
         sr = torch.empty(N, self.in_planes, 2 * H, 2 * W, dtype=F32, device=x.device)
+        if not pre_done:
+            pl["pre"].set_ptr("x", x.data_ptr())
+            pl["pre"].run()
         fwd = pl["fwd"]
-        fwd.set_ptr("x", x.data_ptr())
         fwd.set_ptr("sr", sr.data_ptr())
         if self.tl:
             if prior is None or tuple(prior.shape) != (N, self.emb_cls, 1, 26) or not (prior.is_cuda or K.DRYRUN):

@@ -188,6 +188,7 @@ class TPGSRTrainStep:
         # weight-gradient stream at its end (the student's backward pass starts right away); _join_side() orders the main stream after
         # it before clip + Adam.  With a gradient exchange the bucket launch right after the SR backward needs them: the plan joins.
         self._defer_join = (not self.collective) and os.environ.get("TPGSR_DEFER_JOIN", "1") != "0"
+        self._sr_pre_side = os.environ.get("TPGSR_SR_PRE_SIDE", "1") != "0"
 
     def _buffers(self, lr_img):
         dev, N = lr_img.device, lr_img.shape[0]
@@ -213,7 +214,7 @@ class TPGSRTrainStep:
         N, C, H, W = lr_img.shape
         H2, W2 = 2 * H, 2 * W
         hr = hr_img.contiguous()
-        lr_img = lr_img.contiguous()
+        lr_img = lr_img.contiguous().float()
         if self.collective:
             self._exchanger().begin()
         self.opt.zero_grad()
@@ -227,16 +228,26 @@ class TPGSRTrainStep:
             K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
         cascade, ch, cw = lr_img, H, W
         srs, logits_keep = [], []
+        # the SR network's prior-independent prologue (operand packing, STN head, rectification, block1: ~0.3 ms of small launches) runs
+        # on the weight-gradient stream -- idle during the forward pass -- next to the text-prior generator's forward pass
+        pre_side = self._sr_pre_side and not K.DRYRUN
+        side = K.side_stream(lr_img.device) if pre_side else None
         for i in range(self.stu_iter):
             stu = self.stu[0 if self.tpg_share else i]
             srm = self.sr[0 if self.sr_share else i]
+            if pre_side:
+                side.wait_stream(main)
+                with K.stream_ctx(side):
+                    srm._engine().forward_pre(lr_img, True, slot=i, defer_join=self._defer_join)
             K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
             logits = stu._engine().forward(st["gray"][i], True, slot=i)
             if i == 0:
                 main.wait_stream(aux)           # the teacher's distribution q is needed from here on
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
             K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
-            sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join)
+            if pre_side:
+                main.wait_stream(side)
+            sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join, pre_done=pre_side)
             K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
             n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
             K.image_loss_finalize(st["part_img"][i], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
