@@ -239,6 +239,7 @@ void tpgsr_halo_set_colmajor_min_bytes(long long v);
 /* smallest tap count (KH * KW) the halo forward kernel takes: 2 (default) or 1 (1x1 convolutions with Cin % 32 == 0 as well;
  * TPGSR_XBF_HALO_MINTAPS=1 at load time).  Results do not depend on it beyond fp32 summation order. */
 void tpgsr_halo_set_min_taps(int v);
+void tpgsr_halo_set_ne9(int on);   /* halos of 225..288 entries on the halo forward kernel as well (default off: slower than the tile loop; TPGSR_XBF_HALO_NE9) */
 /* The row-panel kernel of the 1x1 convolutions with K <= 192 over many pixels (csrc/conv_panel.hip: the GruBlock projections,
  * model/tsrn.py:491-508, and their data gradients): on / off (TPGSR_XBF_PANEL), and the smallest pixel count it takes (default 32768;
  * TPGSR_XBF_PANEL_MIN_M).  Placement of a launch on this kernel or on the tile loop only affects speed. */

@@ -594,6 +594,9 @@ extern "C" void tpgsr_halo_set_colmajor_min_bytes(long long v) { g_nmajor_min_by
 
 /* smallest tap count the halo kernel takes (default 2; 1 sends 1x1 convolutions with Cin % 32 == 0 through it as well --
  * TPGSR_XBF_HALO_MINTAPS, experiment switch) */
+static int g_halo_force_ne9 = 0;
+/* tests: let the halo forward kernel take halos of 225..288 entries (its 9-entries-per-thread variant) */
+extern "C" void tpgsr_halo_set_ne9(int on) { g_halo_force_ne9 = on ? 1 : 0; }
 static int g_halo_min_taps = [] { const char* e = getenv("TPGSR_XBF_HALO_MINTAPS"); return e && e[0] == '1' ? 1 : 2; }();
 extern "C" void tpgsr_halo_set_min_taps(int v) { g_halo_min_taps = v < 1 ? 1 : v; }
 
@@ -612,6 +615,11 @@ static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, h
   // conv, 278 halo entries = 107 KB in x3 mode, measured 54 us here against 47 us on the tile loop)
   if (Lcap > 32 * 9 || lds > 80 * 1024) return 0;
   const bool small = Lcap <= 32 * 7;
+  // the 9-entries-per-thread variant (halos of 225..288 entries: the recognizer's 16 x 50 maps).  In x3 arithmetic its two 107 KB
+  // buffers never fit (rejected above); in x2 / bf16 they do (73 KB) and the launch was measured at 203 us against ~45 us on the tile
+  // loop (128 -> 64 data gradient at batch 48, profiles/r03j_kernel_stats_c3_x2.md) -- off unless TPGSR_XBF_HALO_NE9=1
+  static const bool ne9 = [] { const char* e = getenv("TPGSR_XBF_HALO_NE9"); return e && e[0] == '1'; }();
+  if (!small && !ne9 && !g_halo_force_ne9) return 0;
   const void* fn = nullptr;
 #define XBF_HALO_CASE(B)                                                                                                      \
   case B:                                                                                                                     \

@@ -11,6 +11,7 @@ Module layout / parameter names stay the reference's (tpgsr_amd/model/tsrn.py), 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -597,6 +598,11 @@ class TSRNEngine(_EngineBase):
         # the STN head's backward (a chain of ~60 small launches that only produces parameter gradients) on a third stream, next to
         # the rest of the step (InfoGen backward -> text-prior generator backward on the caller's stream)
         self.leaf_stn = os.environ.get("TPGSR_LEAF_STN", "1") != "0"
+        # ... and with it everything after the last use of the caller's stream's data in the trunk: block 0's convolution gradients,
+        # block1 (TPGSR_LEAF_EARLY=0: only the STN head)
+        # (measured on MI355X: 7.60 vs 7.55 ms per C3 step -- the longer leaf chain, whose weight gradients run in order with it, lands
+        #  on the step's tail -- so it is opt-in: TPGSR_LEAF_EARLY=1)
+        self.leaf_early = os.environ.get("TPGSR_LEAF_EARLY", "0") == "1"
 
     def _build_layers(self):
         m = self.module
@@ -855,6 +861,7 @@ class TSRNEngine(_EngineBase):
         self.conv7.dgrad(N, H, W, dy, gA)
         have_B = False
         da = ws("da", P1, Cc)
+        leaf = contextlib.ExitStack()
         for i in range(self.srb - 1, -1, -1):
             L = self.rrb[i]
             p = f"r{i}_"
@@ -875,6 +882,11 @@ class TSRNEngine(_EngineBase):
                 K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
                 L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, da, **L["bn2"].loader)
+            if i == 0 and self.leaf_early:
+                # Everything below only feeds parameter gradients (block 0's convolutions, block1, the STN head): the text-strip gradient
+                # dtemb is final here, so the caller's stream goes straight on to the InfoGen backward and the text-prior generator's
+                # backward pass while this tail runs on the leaf stream
+                leaf.enter_context(K.leaf())
             dy = buf("dy", p + "c2_", Cc)
             L["bn2"].backward(da, None, y2, P1, "none", dy)
             L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
@@ -884,20 +896,23 @@ class TSRNEngine(_EngineBase):
             L["conv1"].wgrad(N, H, W, X, dy)
             L["conv1"].dgrad(N, H, W, dy, gB)                              # second gradient path into X
             have_B = True
+        early = bool(self.srb and self.leaf_early)      # the leaf section is already open
         # b1 receives d_s (long skip) + gA (+ gB)
         if have_B:
             K.add(gA, gB, P1 * Cc, gA)
         dc1 = ws("dc1", P1, Cc)
         nb = 256
-        dap = self.scratch("prelu_dap", nb)
+        dap = self.scratch("prelu_dap" + K.stream_tag(), nb)
         K.prelu_bwd(t["c1"], self.P["block1.1.weight"], gA, d_s, P1 * Cc, dc1, dap, nb)
         with K.side():
             K.reduce_partials(dap, nb, 1, self.G["block1.1.weight"], accumulate=True)
         xin = t["xr"] if self.stn else t["x_nhwc"]
         self.block1.wgrad(N, H, W, xin, dc1)
         if self.stn:
-            with K.leaf():
-                self._record_stn_bwd(N, H, W, dc1, ws)
+            if not early:
+                leaf.enter_context(K.leaf())
+            self._record_stn_bwd(N, H, W, dc1, ws)
+        leaf.close()
         if self.tl:
             self._record_infogen_bwd(N, W, ws)
 

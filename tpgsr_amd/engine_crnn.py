@@ -222,7 +222,7 @@ class CRNNEngine(_EngineBase):
         return dims
 
     def plans(self, N, training, slot=0):
-        return self._two_pass((N, bool(training), slot), lambda ws, final: self._record(N, training, ws, final))
+        return self._two_pass((N, bool(training), slot, getattr(self, "role", "tpg")), lambda ws, final: self._record(N, training, ws, final))
 
     def _record(self, N, training, ws, final):
         fwd, bwd, dgp = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_dgray")
@@ -235,7 +235,7 @@ class CRNNEngine(_EngineBase):
         self._cur_ws, self._wg_idx = ws, 0
         for bn in self._bn_layers:
             bn.use(ws)
-        with recording(fwd), K.conv_terms(K.terms_for("tpg", "fwd")):
+        with recording(fwd), K.conv_terms(K.terms_for(getattr(self, "role", "tpg"), "fwd")):
             self._record_fwd(N, training, ws)
         if training:
             with recording(bwd), K.conv_terms(K.terms_for("tpg", "bwd")):

@@ -172,6 +172,8 @@ class TPGSRTrainStep:
         self.sr = list(sr_models) if isinstance(sr_models, (list, tuple)) else [sr_models]
         self.stu = list(students) if isinstance(students, (list, tuple)) else [students]
         self.teacher = teacher
+        if hasattr(teacher, "_engine") and all(teacher is not m for m in self.stu):
+            teacher._engine().role = "teacher"      # arithmetic policy: its output is a soft target only (kernels.terms_for)
         self.stu_iter, self.sr_share, self.tpg_share = stu_iter, sr_share, tpg_share
         self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
         mods = self.sr + self.stu
@@ -189,6 +191,14 @@ class TPGSRTrainStep:
         # it before clip + Adam.  With a gradient exchange the bucket launch right after the SR backward needs them: the plan joins.
         self._defer_join = (not self.collective) and os.environ.get("TPGSR_DEFER_JOIN", "1") != "0"
         self._sr_pre_side = os.environ.get("TPGSR_SR_PRE_SIDE", "1") != "0"
+
+    def _mark(self, name):
+        """diagnostics (tools/lab/step_phases.py): with `self._marks = []` set, an event on the caller's stream at every phase boundary"""
+        m = getattr(self, "_marks", None)
+        if m is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            m.append((name, ev))
 
     def _buffers(self, lr_img):
         dev, N = lr_img.device, lr_img.shape[0]
@@ -217,6 +227,7 @@ class TPGSRTrainStep:
         lr_img = lr_img.contiguous().float()
         if self.collective:
             self._exchanger().begin()
+        self._mark("start")
         self.opt.zero_grad()
         # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
         # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
@@ -241,17 +252,21 @@ class TPGSRTrainStep:
                     srm._engine().forward_pre(lr_img, True, slot=i, defer_join=self._defer_join)
             K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
             logits = stu._engine().forward(st["gray"][i], True, slot=i)
+            self._mark(f"student{i} fwd")
             if i == 0:
                 main.wait_stream(aux)           # the teacher's distribution q is needed from here on
+                self._mark("wait teacher")
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
             K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
             if pre_side:
                 main.wait_stream(side)
+                self._mark(f"wait SR prologue{i}")
             sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join, pre_done=pre_side)
             K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
             n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
             K.image_loss_finalize(st["part_img"][i], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
             srs.append(sr)
+            self._mark(f"SR{i} fwd + loss")
             cascade, ch, cw = sr, H2, W2
         # total loss (device scalar) = sum of the 2*stu_iter scalars
         K.copy(st["l_img"][0], st["loss"], 1)
@@ -270,6 +285,7 @@ class TPGSRTrainStep:
             if i == 0 and self.collective and self._overlap_exchange:
                 # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
                 self._exchanger().launch(0)
+            self._mark(f"SR{i} bwd")
             K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
             if getattr(self, "_debug", False):
                 self._dbg.setdefault("dprior", {})[i] = dprior.clone()
@@ -278,7 +294,9 @@ class TPGSRTrainStep:
             if i > 0:
                 self._dbg_dgray = dgray
                 K.bicubic_gray_bwd(dgray, N, C, H2, W2, 32, 100, st["dcas"])
+        self._mark("student bwd")
         self._join_side(lr_img.device)
+        self._mark("join side")
         self.last_sr, self.last_p = srs[-1], st["p"][self.stu_iter - 1]
         return st["loss"]
 
@@ -321,6 +339,7 @@ class TPGSRTrainStep:
         loss = self._phase_a(lr_img, hr_img)
         self._exchange()
         self._phase_b()
+        self._mark("optimiser")
         return loss
 
     def capture(self, lr_img, hr_img, warmup=2):

@@ -56,10 +56,14 @@ def set_conv_prec(name: str):
 
 
 def terms_for(net_kind: str, phase: str) -> int:
-    """what an engine records under the current policy; net_kind 'sr' | 'tpg' (text-prior generator), phase 'fwd' | 'bwd'"""
+    """what an engine records under the current policy; net_kind 'sr' | 'tpg' (text-prior generator) | 'teacher', phase 'fwd' | 'bwd'"""
+    if net_kind == "teacher" and POLICY != "x2":
+        net_kind = "tpg"
     if POLICY == "bf16":
         return 3 if (net_kind == "tpg" and phase == "fwd") else 1
     if POLICY == "x2":
+        # "teacher": the frozen recogniser whose softmax output is only the distillation TARGET q (interfaces/super_resolution.py:372-382):
+        # nothing thresholds it, so it runs two-term like the rest; "tpg" = a student, whose arg-max prior must match the fp32 oracle's
         return _X2_TPG_FWD if (net_kind == "tpg" and phase == "fwd") else 2
     if POLICY == "x3b2":
         return 3 if phase == "fwd" else 2
