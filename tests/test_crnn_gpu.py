@@ -66,11 +66,12 @@ def test_semantic_loss_module_on_probabilities(golden_dir):
         assert (pd.grad.cpu() / 3.0 - pr.grad).abs().max() < 1e-5 * pr.grad.abs().max()
 
 
+@pytest.mark.parametrize("hw", [(4, 9), (6, 10)])      # (6, 10): even sizes -> the non-overlapping 2x2 backward fast path
 @pytest.mark.parametrize("cfg", [((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))])
-def test_pool2d(cfg):
+def test_pool2d(cfg, hw):
     from tpgsr_amd import kernels as K
     k, s, pd = cfg
-    N, H, W, C = 2, 4, 9, 32
+    N, (H, W), C = 2, hw, 32
     g = torch.Generator().manual_seed(3)
     x = torch.randn(N, C, H, W, generator=g)
     sc = torch.rand(C, generator=g) + 0.5

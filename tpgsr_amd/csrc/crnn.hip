@@ -5,6 +5,7 @@
 //   * softmax over the 37 classes + SemanticLoss (loss/semantic_loss.py:21-39) + the (N,37,1,26) prior with the
 //     deterministic prior dropout of interfaces/super_resolution.py:376-382
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------------------------
@@ -337,6 +338,54 @@ __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const float* __restrict
   }
 }
 
+// 2 x 2 windows, stride 2, no padding, even H and W (pooling0 / pooling1 of the recogniser, crnn.py:56-59: its two largest maps): the
+// windows do not overlap, so one thread owns one WINDOW x 4 channels -- every input is read once and every gradient written once
+// (the gather form above re-reads each window from all four of its positions: 73 / 55 us per launch at batch 48).  First arg-max in
+// row-major scan order, as the gather form and ATen.
+__global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, int N, int H,
+                                                          int W, int C, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act, float* __restrict__ dz) {
+  const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+  const long long total = (long long)N * OH * OW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long p = i / C4;
+    const int ow = (int)(p % OW);
+    p /= OW;
+    const int oh = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const size_t base = ((size_t)(n * H + 2 * oh) * W + 2 * ow) * C + c;
+    const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    float4 xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const float4*>(x + base + offs[k]);
+    const float4 g = *reinterpret_cast<const float4*>(dout + ((size_t)(n * OH + oh) * OW + ow) * C + c);
+    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 out[4];
+    auto one = [&](float x0, float x1, float x2, float x3, float s, float t, float gg, float& o0, float& o1, float& o2, float& o3)
+                   __attribute__((always_inline)) {
+      const float p0 = x0 * s + t, p1 = x1 * s + t, p2 = x2 * s + t, p3 = x3 * s + t;
+      const float v0 = apply_act(p0, act), v1 = apply_act(p1, act), v2 = apply_act(p2, act), v3 = apply_act(p3, act);
+      int k = 0;
+      float best = v0;
+      if (v1 > best) { best = v1; k = 1; }
+      if (v2 > best) { best = v2; k = 2; }
+      if (v3 > best) { best = v3; k = 3; }
+      o0 = k == 0 ? gg * act_grad(p0, act) : 0.f;
+      o1 = k == 1 ? gg * act_grad(p1, act) : 0.f;
+      o2 = k == 2 ? gg * act_grad(p2, act) : 0.f;
+      o3 = k == 3 ? gg * act_grad(p3, act) : 0.f;
+    };
+    one(xv[0].x, xv[1].x, xv[2].x, xv[3].x, sc.x, sh.x, g.x, out[0].x, out[1].x, out[2].x, out[3].x);
+    one(xv[0].y, xv[1].y, xv[2].y, xv[3].y, sc.y, sh.y, g.y, out[0].y, out[1].y, out[2].y, out[3].y);
+    one(xv[0].z, xv[1].z, xv[2].z, xv[3].z, sc.z, sh.z, g.z, out[0].z, out[1].z, out[2].z, out[3].z);
+    one(xv[0].w, xv[1].w, xv[2].w, xv[3].w, sc.w, sh.w, g.w, out[0].w, out[1].w, out[2].w, out[3].w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(dz + base + offs[k]) = out[k];
+  }
+}
+
 extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale, const float* shift,
                                 int act, int KH, int KW, int SH, int SW, int PH, int PW, float* dz, void* stream) {
   TPGSR_CHECK_ARG(x && dout && dz && KH > 0 && KW > 0 && SH > 0 && SW > 0, "tpgsr_pool2d_bwd: bad arguments");
@@ -344,6 +393,14 @@ extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H,
   const bool vec = (C & 3) == 0 && ((((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dz) & 15) == 0);
   long long total = (long long)N * H * W * (vec ? C / 4 : C);
   int grid = (int)min((long long)16384, (total + 255) / 256);
+  static const bool fast2x2 = [] { const char* e = getenv("TPGSR_POOL2X2_FAST"); return !(e && e[0] == '0'); }();
+  if (fast2x2 && vec && KH == 2 && KW == 2 && SH == 2 && SW == 2 && PH == 0 && PW == 0 && !(H & 1) && !(W & 1) &&
+      (!scale || !(((uintptr_t)scale | (uintptr_t)shift) & 15))) {
+    const long long tw = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(pool2x2_bwd_kernel, dim3((int)min((long long)16384, (tw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dout, N, H, W,
+                       C, scale, shift, act, dz);
+    TPGSR_LAUNCH_CHECK("tpgsr_pool2d_bwd");
+  }
   if (vec)
     hipLaunchKernelGGL(pool2d_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dout, N, H, W, C, scale, shift, act, KH, KW,
                        SH, SW, PH, PW, OH, OW, dz);
