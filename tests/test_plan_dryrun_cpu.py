@@ -69,6 +69,21 @@ x = lr.clone()
 y = sr5(x, torch.zeros(N, 37, 1, 26))
 y.sum().backward()
 out["live_after_bwd"] = len(sr5._engine()._live)
+# a training-mode forward whose graph is dropped without a backward pass gives its workspace slot back
+import gc
+for _ in range(3):
+    y = sr5(x, torch.zeros(N, 37, 1, 26))
+    del y
+gc.collect()
+out["live_after_dropped_graphs"] = len(sr5._engine()._live)
+# a module handed to a SECOND pool is re-pointed there; the first pool notices on its next bind instead of using a stale buffer
+from tpgsr_amd.engine import ArenaPool
+p1 = ts5.pool
+p2 = ArenaPool([sr5])
+p2.bind(torch.device("cpu"))
+out["repointed"] = sr5._engine().arena.flat.data_ptr() == p2.flat.data_ptr()
+p1.bind(torch.device("cpu"))
+out["first_pool_rebuilt"] = sr5._engine().arena.flat.data_ptr() == p1.flat.data_ptr() + 4 * p1.ranges[id(sr5)][0]
 print("RESULT " + json.dumps(out))
 '''
 
@@ -89,6 +104,8 @@ def test_record_all_plans_without_gpu():
     assert res["c3"][2].get("tpgsr_pad_channels", 0) >= 2          # prior 37 -> 40, dlogits 37 -> 40
     assert res["pool"][0] >= res["pool"][1] and res["views"] and res["sr_first"]
     assert res["live_after_bwd"] == 0
+    assert res["live_after_dropped_graphs"] == 0
+    assert res["repointed"] and res["first_pool_rebuilt"]
 
 
 FSCRIPT = r'''

@@ -119,9 +119,15 @@ class ArenaPool:
         sizes = [m._engine().arena.layout()[1] for m in self.modules]
         if self.flat is not None and self.flat.device == device and [self.ranges[id(m)][1] - self.ranges[id(m)][0]
                                                                       for m in self.modules] == sizes:
-            for m in self.modules:
-                m._engine().bind(device)
-            return
+            # fast path only while every module's arena still points into THIS pool (a module handed to a second pool -- two train
+            # steps sharing a network -- was re-pointed there: rebuild rather than exchange / optimise a stale buffer)
+            lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+            mine = all(m._engine().arena.external is not None and lo <= m._engine().arena.external[0].data_ptr() < hi
+                       and m._engine().arena.external[0].data_ptr() == lo + 4 * self.ranges[id(m)][0] for m in self.modules)
+            if mine:
+                for m in self.modules:
+                    m._engine().bind(device)
+                return
         off, self.ranges = 0, {}
         for m, n in zip(self.modules, sizes):
             self.ranges[id(m)] = (off, off + n)

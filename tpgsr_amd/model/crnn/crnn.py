@@ -5,6 +5,8 @@ plan in tpgsr_amd/engine_crnn.py.
     crnn = CRNN(32, 1, 37, 256).cuda()
     logits = crnn(gray)            # gray (N, 1, 32, 100) -> (T=26, N, 37), seq-first like the reference
 """
+import weakref
+
 import torch
 from torch import nn
 
@@ -24,6 +26,10 @@ class _CRNNFunction(torch.autograd.Function):
         eng = net._engine()
         eng.bind(gray.device)
         ctx.slot, ctx.gen = eng.acquire_slot() if net.training else (0, 0)
+        if net.training:
+            # a graph that is dropped without a backward pass (a logged loss, an exception) must not keep its workspace slot:
+            # release it when autograd destroys this node (release_slot is a no-op once backward has released it)
+            weakref.finalize(ctx, eng.release_slot, ctx.slot, ctx.gen)
         logits = eng.forward(gray, net.training, slot=ctx.slot)
         ctx.net, ctx.mode, ctx.N = net, net.training, gray.shape[0]
         ctx.save_for_backward(gray.contiguous().float())

@@ -13,6 +13,8 @@ of interfaces/super_resolution.py).
 """
 import math
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -141,6 +143,10 @@ class _TSRNFunction(torch.autograd.Function):
         eng = net._engine()
         eng.bind(x.device)
         ctx.slot, ctx.gen = eng.acquire_slot() if net.training else (0, 0)
+        if net.training:
+            # a graph that is dropped without a backward pass (a logged loss, an exception) must not keep its workspace slot:
+            # release it when autograd destroys this node (release_slot is a no-op once backward has released it)
+            weakref.finalize(ctx, eng.release_slot, ctx.slot, ctx.gen)
         sr = eng.forward(x, net.training, prior, slot=ctx.slot)
         ctx.net, ctx.x_shape, ctx.mode = net, tuple(x.shape), net.training
         ctx.save_for_backward(sr)
