@@ -416,6 +416,11 @@ def main():
             dt2 = time.perf_counter() - t1
             out["alt_precision"] = {"arithmetic_policy": args.alt_prec, "arithmetic": ARITH[args.alt_prec], "steps": args.steps,
                                     "ms_per_step": round(1e3 * dt2 / args.steps, 4), "value": round(B * args.steps / dt2, 1), "unit": "img/s"}
+            if not args.no_roofline:      # the same convolution-family replay under this policy (its launches, its class peaks)
+                t2 = conv_roofline(_nets2)["total"]
+                out["alt_precision"]["roofline"] = {"bound": "mfma", "achieved": round(t2["tflops"], 2), "peak": round(t2["peak"], 1),
+                                                    "unit": "TFLOP/s", "frac": round(t2["frac"], 4), "launches_per_step": t2["launches"],
+                                                    "ms_per_step_replayed": round(t2["ms"], 4)}
             K.set_conv_prec(K_POLICY)
             del ts2, _nets2
         if world == 1 and not args.no_cpu_baseline:

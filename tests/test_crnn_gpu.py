@@ -282,6 +282,24 @@ def test_train_c3_step_vs_golden(golden_dir):
     assert abs(l1 - t["loss"][1]) < 2e-2 * t["loss"][1]
 
 
+def test_train_c3_hipgraph_replay_equals_eager(golden_dir):
+    """the whole TPGSR step -- three streams (SR prologue on the side stream, teacher + STN-head backward on the leaf stream), the
+    persistent BiLSTM kernels with their in-kernel hand-offs, deferred join -- captured into ONE hipGraph and replayed: bitwise the
+    eager step sequence (same kernels, same order, deterministic reductions)"""
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    t = np.load(os.path.join(golden_dir, "train_c3.npz"))
+    lr, hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+    (sa, ua, ta_, *_), (sb, ub, tb_, *_) = _c3_models(), _c3_models()
+    ea, eb = TPGSRTrainStep(sa, ua, ta_, stu_iter=1), TPGSRTrainStep(sb, ub, tb_, stu_iter=1)
+    eb.capture(lr, hr, warmup=1)          # one eager warm-up step has been applied; the capture itself executes nothing
+    la = [ea.step(lr, hr).item() for _ in range(3)]
+    lb = [eb.replay().item() for _ in range(2)]
+    torch.cuda.synchronize()
+    print(la, lb)
+    assert lb[0] == la[1] and lb[1] == la[2]
+    assert torch.equal(ea.pool.flat, eb.pool.flat)
+
+
 def test_cascade_two_stages_vs_oracle():
     """stu_iter 2, sr_share, two students, no STN: every gradient (SR net accumulated over both stages, both students,
     incl. the path through parse_crnn_data of stage 2) against oracle autograd, via one fused step's Adam-free grads.
