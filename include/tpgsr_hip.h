@@ -86,6 +86,20 @@ typedef struct {
                              k' = ((ci / 32) * KH*KW + tap) * 32 + ci % 32  (tpgsr_split_desc.cin), which is what lets KH x KW
                              convolutions run on the halo kernel */
   int reserved0;
+  /* --- BatchNorm-backward statistics in the epilogue of the convolution that PRODUCES the incoming gradient (split-bf16 kernels only;
+   *     the fp32 kernel refuses it).  With bnb_y set, `out` = da is stored as usual and bn_partial receives, per 64-pixel row block,
+   *     [0][c] = sum dz, [1][c] = sum dz * (y - mean[c]) * rstd[c],  dz = da * act'(y * bnb_scale[c] + bnb_shift[c])
+   *     -- the first pass of tpgsr_bn_bwd_reduce (autograd's batch_norm_backward reduction, model/tsrn.py:376,380) without its launch and
+   *     its re-read of da.  y is dense [M][Cout]. --- */
+  const float* bnb_y;     /* optional: the BatchNorm's input (the pre-normalisation map of the forward pass) */
+  const float* bnb_mean;  /* [Cout] batch mean / reciprocal standard deviation saved by tpgsr_bn_finalize */
+  const float* bnb_rstd;
+  const float* bnb_scale; /* [Cout] folded scale / shift (needed when bnb_act != NONE) */
+  const float* bnb_shift;
+  int bnb_act;            /* activation that followed the BatchNorm in the forward pass: NONE / RELU / MISH */
+  int bnb_store_dz;       /* 1: `out` receives dz instead of da.  With bn_partial NULL this is a plain activation backward on the
+                             way out -- out = da * act'(y * scale + shift), scale / shift optional (1 / 0) -- which is how the mish
+                             in front of the tail convolution (model/tsrn.py:39,159) is differentiated without a launch of its own */
 } tpgsr_conv_args;
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);

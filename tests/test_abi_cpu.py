@@ -146,3 +146,37 @@ def test_plan_recording_sections_on_cpu():
             K._launch("tpgsr_zero", 0x1000, 16)
         plain.join()
     assert [(op[0], op[3]) for op in plain.ops] == [("tpgsr_zero", 0)]
+
+
+def test_plan_side_batch_on_cpu():
+    """side_batch_begin / _end: the side sections in between are held and go out behind ONE fork at the end of the batch, in order,
+    DynPtr slots pointing at their final op index; the caller's launches keep their order"""
+    from tpgsr_amd import kernels as K
+    plan = K.Plan("b")
+    plan.overlap = True
+    with K.recording(plan):
+        K._launch("tpgsr_zero", 0x1000, 16)
+        sb = K.side_batch_begin()
+        assert sb
+        with K.side():
+            K._launch("tpgsr_zero", 0x2000, 16)
+        K._launch("tpgsr_zero", K.DynPtr("m"), 16)
+        with K.side():
+            K._launch("tpgsr_zero", K.DynPtr("s"), 16)
+        K._launch("tpgsr_zero", 0x5000, 16)
+        K.side_batch_end(sb)
+        with K.side():                                  # outside a batch: its own fork, as before
+            K._launch("tpgsr_zero", 0x6000, 16)
+        plan.join()
+    kinds = [(op[0], op[3], op[2][0] if op[1] else None) for op in plan.ops]
+    assert kinds == [("tpgsr_zero", 0, 0x1000), ("tpgsr_zero", 0, None), ("tpgsr_zero", 0, 0x5000), ("fork", 0, None),
+                     ("tpgsr_zero", 1, 0x2000), ("tpgsr_zero", 1, None), ("fork", 0, None), ("tpgsr_zero", 1, 0x6000), ("join", 0, None)]
+    assert plan.dyn == {"m": [(1, 0)], "s": [(5, 0)]}
+    empty = K.Plan("e")                                 # a batch without side sections leaves nothing behind
+    empty.overlap = True
+    with K.recording(empty):
+        sb = K.side_batch_begin()
+        K._launch("tpgsr_zero", 0x1000, 16)
+        K.side_batch_end(sb)
+        empty.join()
+    assert [(op[0], op[3]) for op in empty.ops] == [("tpgsr_zero", 0)]

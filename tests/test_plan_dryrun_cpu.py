@@ -34,6 +34,8 @@ def conv_stats(nets):
                         a = args[0]._obj
                         c = a.c if name == "tpgsr_conv_wgrad" else a
                         n += 1
+                        if name == "tpgsr_conv_fwd" and c.bnb_y:
+                            names["conv_fwd+bnb"] = names.get("conv_fwd+bnb", 0) + 1
                         wld = c.wt_ld if c.wt_ld > 0 else c.Cout
                         if c.Cin %% 4 != 0 or (name == "tpgsr_conv_fwd" and wld %% 4 != 0) or \
                            (name == "tpgsr_conv_wgrad" and not a.dy_ps and a.dy_ld %% 4 != 0):
@@ -102,6 +104,13 @@ def test_record_all_plans_without_gpu():
         assert scalar == [], (cfg, scalar)
     assert res["c3"][2].get("tpgsr_im2col3x3_c1", 0) == 2          # student + teacher conv0
     assert res["c3"][2].get("tpgsr_pad_channels", 0) >= 2          # prior 37 -> 40, dlogits 37 -> 40
+    # BatchNorm-backward sums ride on the producing data-gradient convolutions: 11 in the SR network (5 blocks x 2 + block 7), 3 in the
+    # student (conv2 / conv4 / bn6), 3 in InfoGen; what is left as its own launch: InfoGen's last BatchNorm and the STN head
+    # ... + the tail's mish backward (an epilogue without sums) + InfoGen bn0..bn2 + bn6 (BiLSTM projection's data gradient)
+    assert res["c3"][2].get("conv_fwd+bnb", 0) == 11 + 1 + 3 + 3, res["c3"][2]
+    assert res["c2"][2].get("conv_fwd+bnb", 0) == 11 + 1
+    assert res["c3"][2].get("tpgsr_bn_bwd_reduce", 0) == res["c3"][2]["tpgsr_bn_bwd_finalize"] - 17
+    assert res["c3"][2].get("tpgsr_act_bwd", 0) == 0
     assert res["pool"][0] >= res["pool"][1] and res["views"] and res["sr_first"]
     assert res["live_after_bwd"] == 0
     assert res["live_after_dropped_graphs"] == 0

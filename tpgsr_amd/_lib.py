@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
                 ("Cout", ci), ("KH", ci), ("KW", ci), ("pad_h", ci), ("pad_w", ci), ("OH", ci), ("OW", ci),
                 ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci),
                 ("in_b", vp), ("cin_a", ci), ("in_b_ld", ci), ("in_dil_w", ci), ("wt_ld", ci), ("wt_coff", ci), ("stride_w", ci),
-                ("terms", ci), ("kp", ci), ("wt_bf", vp), ("wt_bf_cin", ci), ("reserved0", ci)]
+                ("terms", ci), ("kp", ci), ("wt_bf", vp), ("wt_bf_cin", ci), ("reserved0", ci),
+                ("bnb_y", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_act", ci), ("bnb_store_dz", ci)]
 
 
 class WgradArgs(C.Structure):

@@ -366,12 +366,24 @@ extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
   int vecB = ((wld_ & 3) == 0 && ((uintptr_t)a->wt & 15) == 0) ? 1 : 0;   // rows padded to a multiple of 4 floats
   hipStream_t st = (hipStream_t)stream;
   const int ld = loader_bits(a);
+  if (a->bnb_y) {   // BatchNorm-backward statistics / activation backward in the epilogue
+    TPGSR_CHECK_ARG(!a->out_ps && !a->bias && a->out_act == TPGSR_ACT_NONE,
+                    "tpgsr_conv_fwd: bnb_y goes with a plain dense data-gradient store (no bias, no output activation, no pixel shuffle)");
+    TPGSR_CHECK_ARG(a->bnb_act == TPGSR_ACT_NONE || a->bnb_act == TPGSR_ACT_RELU || a->bnb_act == TPGSR_ACT_MISH, "tpgsr_conv_fwd: bnb_act %d", a->bnb_act);
+    TPGSR_CHECK_ARG((a->bnb_scale == nullptr) == (a->bnb_shift == nullptr), "tpgsr_conv_fwd: bnb_scale / bnb_shift must come together");
+    if (a->bn_partial)
+      TPGSR_CHECK_ARG(a->bnb_mean && a->bnb_rstd && (a->bnb_act == TPGSR_ACT_NONE || a->bnb_scale),
+                      "tpgsr_conv_fwd: BatchNorm-backward sums need bnb_mean, bnb_rstd (and bnb_scale / bnb_shift under an activation)");
+    else
+      TPGSR_CHECK_ARG(a->bnb_store_dz, "tpgsr_conv_fwd: bnb_y without bn_partial and without bnb_store_dz does nothing");
+  }
   // bf16 matrix cores with split operands (conv_xbf.hip): vector loader + pre-split weights required
   if (a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) {
     TPGSR_CHECK_ARG(a->terms >= 1 && a->terms <= 3, "tpgsr_conv_fwd: terms must be 0, 1, 2 or 3");
     TPGSR_CHECK_ARG(a->kp >= K && (a->kp & 31) == 0 && ((uintptr_t)a->wt_bf & 15) == 0, "tpgsr_conv_fwd: bad split operand (kp %d, K %d)", a->kp, K);
     return tpgsr_conv_fwd_xbf_launch(a, M, K, ld, st);
   }
+  TPGSR_CHECK_ARG(!a->bnb_y, "tpgsr_conv_fwd: the BatchNorm-backward epilogue (bnb_y) exists in the split-bf16 kernels only (terms > 0, wt_bf, Cin %% 4 == 0)");
   // the 64-channel 3x3 trunk convs on 64-wide maps: weights-stationary kernel (TPGSR_CONV_WSTAT=0 falls back to the tile loop)
   static const bool wstat_on = [] { const char* e = getenv("TPGSR_CONV_WSTAT"); return !(e && e[0] == '0'); }();
   if (wstat_on && ld == 0 && a->KH == 3 && a->KW == 3 && a->pad_h == 1 && a->pad_w == 1 && a->Cin == 64 && a->Cout == 64 &&

@@ -73,16 +73,45 @@ __device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx1
     const bool nvalid = n < a.Cout;
     const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
     float s = 0.f, ss = 0.f;
+    // BatchNorm-backward statistics of the gradient this launch produces (tpgsr_conv_args.bnb_y): s = sum dz, ss = sum dz * xhat;
+    // bnb_store_dz: the activation backward on the way out
+    const bool bnb = a.bnb_y != nullptr;
+    float b_mu = 0.f, b_rs = 0.f, b_sc = 1.f, b_sh = 0.f;
+    if (bnb && nvalid) {
+      if (a.bn_partial) {
+        b_mu = a.bnb_mean[n];
+        b_rs = a.bnb_rstd[n];
+      }
+      if (a.bnb_act && a.bnb_scale) {
+        b_sc = a.bnb_scale[n];
+        b_sh = a.bnb_shift[n];
+      }
+    }
 #pragma unroll
-    for (int i = 0; i < WMB; ++i)
+    for (int i = 0; i < WMB; ++i) {
+      float yv[16];
+      if (bnb) {   // all sixteen loads of the BatchNorm input in flight before the first store (the stores may alias for the compiler)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 * WMB + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          yv[r] = (m < M && nvalid) ? a.bnb_y[(size_t)m * a.Cout + n] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         int m = m0 + wm * 32 * WMB + 32 * i + row;
         if (m < M && nvalid) {
           float raw = acc[i][j][r];
-          s += raw;
-          ss += raw * raw;
+          if (bnb) {
+            const float dz = a.bnb_act ? raw * act_grad(yv[r] * b_sc + b_sh, a.bnb_act) : raw;
+            s += dz;
+            ss += dz * (yv[r] - b_mu) * b_rs;
+            if (a.bnb_store_dz) raw = dz;
+          } else {
+            s += raw;
+            ss += raw * raw;
+          }
           float v = apply_act(raw + bias, a.out_act);
           if (!a.out_ps) {
             if (XBF_NT_STORE) __builtin_nontemporal_store(v, &a.out[(size_t)m * a.out_ld + a.out_coff + n]);
@@ -96,6 +125,7 @@ __device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx1
           }
         }
       }
+    }
     if (a.bn_partial) {
       s += __shfl_xor(s, 32);
       ss += __shfl_xor(ss, 32);

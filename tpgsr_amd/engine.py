@@ -258,12 +258,27 @@ class BNLayer:
     def loader(self):
         return dict(in_scale=self.scale, in_shift=self.shift)
 
-    def backward(self, da, da2, y, M, act, dy):
-        """dy = dL/d(pre-BN y) from da (+da2) = dL/d act(BN(y)); accumulates dgamma/dbeta into the arena."""
+    def fuse_stats(self, y, M, act, cin):
+        """kwargs (`bnb=`) for the convolution over `cin` channels that PRODUCES this BatchNorm's incoming gradient: its epilogue then
+        leaves the reduction sums of the backward pass behind and backward(..., fused=True) skips the statistics launch.  None when
+        the launch would not run on a kernel that has the epilogue (fp32 policy, switch off)."""
+        if not K.bnb_fusable(cin):
+            return None
+        nblk = (M + 63) // 64
+        part = self.eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
+        return dict(y=y, mean=self.save_mean, rstd=self.save_rstd, scale=self.scale, shift=self.shift, act=act, partial=part)
+
+    def backward(self, da, da2, y, M, act, dy, fused=None):
+        """dy = dL/d(pre-BN y) from da (+da2) = dL/d act(BN(y)); accumulates dgamma/dbeta into the arena.
+        fused: what fuse_stats(...) returned for the producer of `da` (same stream, no other BatchNorm backward in between)."""
         eng = self.eng
-        nblk = min(1024, max(1, M // 64))
-        part = eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
-        K.bn_bwd_reduce(da, da2, y, M, self.C, self.scale, self.shift, self.save_mean, self.save_rstd, act, part, nblk)
+        if fused is not None:
+            assert da2 is None and fused["y"] is y and fused["act"] == act
+            nblk, part = (M + 63) // 64, fused["partial"]
+        else:
+            nblk = min(1024, max(1, M // 64))
+            part = eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
+            K.bn_bwd_reduce(da, da2, y, M, self.C, self.scale, self.shift, self.save_mean, self.save_rstd, act, part, nblk)
         K.bn_bwd_finalize(part, nblk, self.C, M, self.gamma, self.save_mean, self.save_rstd, eng.G[self.prefix + ".weight"],
                           eng.G[self.prefix + ".bias"], self.coef, accumulate=True)
         K.bn_bwd_apply(da, da2, y, M, self.C, self.scale, self.shift, act, self.coef, dy)
@@ -312,8 +327,9 @@ class GruLayer:
         K.conv_fwd(K.make_conv_args(g, x, self.wc_f, gi, bias=self.bc, **loader))
         K.bigru_fwd(gi, self.whh, self.bhh, N, H, W, self.axis, h, gates)
 
-    def bwd(self, N, H, W, x, gates, h, dh, dh2, dgi, dgh, dx, **loader):
-        """all parameter gradients of the block + dx = dL/d loader(x) (dx None: the caller takes it from dgi / wc_d)"""
+    def bwd(self, N, H, W, x, gates, h, dh, dh2, dgi, dgh, dx, dx_bnb=None, **loader):
+        """all parameter gradients of the block + dx = dL/d loader(x) (dx None: the caller takes it from dgi / wc_d);
+        dx_bnb: BNLayer.fuse_stats(...) of the BatchNorm dx is the incoming gradient of"""
         eng, G, gp = self.eng, self.eng.G, self.gp
         K.bigru_bwd(gates, h, dh, dh2, self.whh, N, H, W, self.axis, dgi, dgh)
         with K.side():
@@ -336,7 +352,7 @@ class GruLayer:
             K.wgrad_reduce(part, dbp, Z, gc, dWc, dbc, accumulate=False)
             eng._compose.append((self, dWc, dbc))
         if dx is not None:
-            K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cin), dgi, self.wc_d, dx))
+            K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cin), dgi, self.wc_d, dx, bnb=dx_bnb))
 
 
 class TConvStrip:
@@ -381,10 +397,10 @@ class TConvStrip:
             K.wgrad_reduce(part, None, Z, g, eng.G[self.wname], None, layout=3, accumulate=True,
                            real=(self.Cin, 1, 3, self.Cp) if self.Cp != self.Cin else None)
 
-    def dgrad(self, N, Win, dy, dx):
+    def dgrad(self, N, Win, dy, dx, bnb=None):
         """dx[N][1][Win][Cin] = strided conv of dy[N][1][OW][Cout] with the un-flipped taps"""
         g = ConvGeom(N, 1, self.out_w(Win), self.Cout, self.Cin, 1, 3, 0, self.pw, 1, Win)
-        K.conv_fwd(K.make_conv_args(g, dy, self.wt_d, dx, stride_w=self.sw, wt_ld=self.Cp))
+        K.conv_fwd(K.make_conv_args(g, dy, self.wt_d, dx, stride_w=self.sw, wt_ld=self.Cp, bnb=bnb))
 
 
 # =================================================================================================================
@@ -781,18 +797,19 @@ class TSRNEngine(_EngineBase):
         widths = self._ig_widths(Wp)
         dz = ws("ig_dz3", N * widths[4], self.Ct)
         K.strip_resample_bwd(t["ig_t3"], self.ig_bn[3].scale, self.ig_bn[3].shift, "relu", t["dtemb"], N, widths[4], W, self.Ct, dz)
-        da, act = dz, "none"
+        da, act, fz = dz, "none", None
         for i in range(3, -1, -1):
             tc, bn = self.ig[i], self.ig_bn[i]
             M = N * widths[i + 1]
             dy = ws(f"ig_dy{i}", M, tc.Cout)
-            bn.backward(da, None, t[f"ig_t{i}"], M, act, dy)
+            bn.backward(da, None, t[f"ig_t{i}"], M, act, dy, fused=fz)
             xin = t[f"ig_t{i - 1}"] if i > 0 else t.get("prior_p", t["prior_nhwc"])
             loader = dict(in_act="relu", **self.ig_bn[i - 1].loader) if i > 0 else {}
             tc.wgrad(N, widths[i], xin, dy, loader=loader)
             da = ws(f"ig_da{i}", N * widths[i], tc.Cin)
-            tc.dgrad(N, widths[i], dy, da)
             act = "relu"
+            fz = self.ig_bn[i - 1].fuse_stats(t[f"ig_t{i - 1}"], N * widths[i], act, tc.Cout) if i > 0 else None
+            tc.dgrad(N, widths[i], dy, da, bnb=fz)
         K.nhwc_to_nchw(da, N, self.emb_cls, 1, Wp, K.DynPtr("dprior"))
 
     def _stn_dims(self, H, W):
@@ -840,6 +857,7 @@ class TSRNEngine(_EngineBase):
         t = ws.t
         tl = self.tail
         # tail: dP, bias grad, weight grad, d mish(ups)
+        sb = K.side_batch_begin()      # the tail's / upsample block's / block 7's weight gradients behind one fork
         nblk = K.tail_bwd_blocks(N, H2, W2, tl.Co, tl.KS)
         dPt = ws("dPt", P4, tl.Cout)
         dbp = self.scratch("tail_dbp", nblk * tl.Co)
@@ -848,19 +866,23 @@ class TSRNEngine(_EngineBase):
             K.reduce_partials(dbp, nblk, tl.Co, self.G[tl.wname.replace(".weight", ".bias")], accumulate=True)
         tl.wgrad(N, H2, W2, t["mups"], dPt)
         dm = ws("d_ups", P4, Cc)
-        tl.dgrad(N, H2, W2, dPt, dm)
-        K.act_bwd(t["ups"], dm, P4 * Cc, "mish", dm)                      # in place: d(ups), pixel-shuffled layout
+        if K.bnb_fusable(tl.Cout):     # d(ups) = mish'(ups) * (data gradient), the factor applied in the convolution's epilogue
+            tl.dgrad(N, H2, W2, dPt, dm, bnb=dict(y=t["ups"], act="mish", store_dz=True))
+        else:
+            tl.dgrad(N, H2, W2, dPt, dm)
+            K.act_bwd(t["ups"], dm, P4 * Cc, "mish", dm)                  # in place: d(ups), pixel-shuffled layout
         # upsample conv: input was bn7(y7) + b1
         self.up.wgrad(N, H, W, t["y7"], dm, loader=dict(in2=t["b1"], **self.bn7.loader), dy_kw=dict(dy_ps=True))
         d_s = ws("d_s", P1, Cc)                                           # = d(bn7 out) = one of b1's gradients
-        self.up.dgrad(N, H, W, dm, d_s, in_ps=True)
+        fz7 = self.bn7.fuse_stats(t["y7"], P1, "none", self.up.Cout)
+        self.up.dgrad(N, H, W, dm, d_s, in_ps=True, bnb=fz7)
         uniq = self.overlap_wgrad
 
         def buf(name, tag, C_):    # one buffer per use when a side-stream wgrad reads it, else one recycled buffer
             return ws(tag + name if uniq else name, P1, C_)
 
         dy = buf("dy", "b7_", Cc)
-        self.bn7.backward(d_s, None, t["y7"], P1, "none", dy)
+        self.bn7.backward(d_s, None, t["y7"], P1, "none", dy, fused=fz7)
         gA, gB = ws("gA", P1, Cc), ws("gB", P1, Cc)
         last_out = t[f"r{self.srb - 1}_out"] if self.srb else t["b1"]
         self.conv7.wgrad(N, H, W, last_out, dy)
@@ -868,8 +890,13 @@ class TSRNEngine(_EngineBase):
         have_B = False
         da = ws("da", P1, Cc)
         leaf = contextlib.ExitStack()
+        K.side_batch_end(sb)
+        nbb = max(1, int(os.environ.get("TPGSR_SIDE_BATCH_BLOCKS", "2")))     # blocks per side batch (measured: 1 -> 7.11, 2 -> 7.085, 5 -> 7.40 ms)
+        sb = False
         for i in range(self.srb - 1, -1, -1):
             L = self.rrb[i]
+            if (self.srb - 1 - i) % nbb == 0 and not (i == 0 and self.leaf_early):
+                sb = K.side_batch_begin()   # one fork per block (or per nbb blocks) instead of four
             p = f"r{i}_"
             dgi, dgh = buf("dgi", p + "g2_", 192), buf("dgh", p + "g2_", 192)
             X = t[f"r{i - 1}_out"] if i > 0 else t["b1"]
@@ -882,27 +909,36 @@ class TSRNEngine(_EngineBase):
                 g1 = L["gru1"]
                 g1.bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, None, in_b=t["temb"], cin_a=Cc, **L["bn2"].loader)
                 # data gradient of the composed 96->192 projection in two column blocks: image features and text strip
-                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, Cc), dgi, g1.wc_d, da, wt_ld=g1.Cin, wt_coff=0))
+                # (leaf_early: block 0's BatchNorm backward runs on the leaf stream, its producer here -- no shared scratch across streams)
+                fz2 = None if (i == 0 and self.leaf_early) else L["bn2"].fuse_stats(y2, P1, "none", 192)
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, Cc), dgi, g1.wc_d, da, wt_ld=g1.Cin, wt_coff=0, bnb=fz2))
                 dtb = ws("d_tb", P1, self.Ct)
                 K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Ct), dgi, g1.wc_d, dtb, wt_ld=g1.Cin, wt_coff=Cc))
                 K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
-                L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, da, **L["bn2"].loader)
+                fz2 = None if (i == 0 and self.leaf_early) else L["bn2"].fuse_stats(y2, P1, "none", 192)
+                L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, da, dx_bnb=fz2, **L["bn2"].loader)
             if i == 0 and self.leaf_early:
                 # Everything below only feeds parameter gradients (block 0's convolutions, block1, the STN head): the text-strip gradient
                 # dtemb is final here, so the caller's stream goes straight on to the InfoGen backward and the text-prior generator's
                 # backward pass while this tail runs on the leaf stream
                 leaf.enter_context(K.leaf())
             dy = buf("dy", p + "c2_", Cc)
-            L["bn2"].backward(da, None, y2, P1, "none", dy)
+            L["bn2"].backward(da, None, y2, P1, "none", dy, fused=fz2)
             L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
-            L["conv2"].dgrad(N, H, W, dy, da)                              # d mish(bn1(y1))
+            fz1 = L["bn1"].fuse_stats(y1, P1, "mish", L["conv2"].Cout)
+            L["conv2"].dgrad(N, H, W, dy, da, bnb=fz1)                     # d mish(bn1(y1))
             dy = buf("dy", p + "c1_", Cc)
-            L["bn1"].backward(da, None, y1, P1, "mish", dy)
+            L["bn1"].backward(da, None, y1, P1, "mish", dy, fused=fz1)
             L["conv1"].wgrad(N, H, W, X, dy)
             L["conv1"].dgrad(N, H, W, dy, gB)                              # second gradient path into X
             have_B = True
+            if (self.srb - 1 - i) % nbb == nbb - 1 or i == 0 or (i == 1 and self.leaf_early):
+                K.side_batch_end(sb)
+                sb = False
         early = bool(self.srb and self.leaf_early)      # the leaf section is already open
+        # block1's and InfoGen's weight gradients (+ the PReLU slope's reduce) behind one fork at the end of the plan
+        sb = K.side_batch_begin() if (os.environ.get("TPGSR_SIDE_BATCH_TAIL", "1") != "0" and not early) else False
         # b1 receives d_s (long skip) + gA (+ gB)
         if have_B:
             K.add(gA, gB, P1 * Cc, gA)
@@ -921,6 +957,7 @@ class TSRNEngine(_EngineBase):
         leaf.close()
         if self.tl:
             self._record_infogen_bwd(N, W, ws)
+        K.side_batch_end(sb)
 
     def _record_stn_bwd(self, N, H, W, dc1, ws):
         t = ws.t

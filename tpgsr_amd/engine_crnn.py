@@ -144,8 +144,9 @@ class LstmLayer:
             K.lstm_step_fwd(G, gh if s > 0 else None, S, self.bhh, Cst, out, N, T, Hh, s)
         self.emb.fwd(N, 1, T, out, e)
 
-    def bwd(self, N, T, x, G, Cst, out, de, dout, dhc, dcc, dx, **loader):
-        """de = dL/d e  ->  all parameter gradients, dx = dL/d loader(x) (if dx is not None)"""
+    def bwd(self, N, T, x, G, Cst, out, de, dout, dhc, dcc, dx, dx_bnb=None, **loader):
+        """de = dL/d e  ->  all parameter gradients, dx = dL/d loader(x) (if dx is not None); dx_bnb: BNLayer.fuse_stats(...) of the
+        BatchNorm dx is the incoming gradient of"""
         eng, P, Gd, r = self.eng, self.eng.P, self.eng.G, self.r
         Hh, G4 = self.Hh, 4 * self.Hh
         self.emb.wgrad(N, 1, T, out, de)
@@ -183,7 +184,7 @@ class LstmLayer:
                 K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gi_, x, **loader), G, part, dbp, dy_ld=2 * G4, dy_coff=d * G4))
                 K.wgrad_reduce(part, dbp, Z, gi_, Gd[r + "weight_ih_l0" + suf], Gd[r + "bias_ih_l0" + suf], accumulate=True)
         if dx is not None:
-            K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, 2 * G4, self.Cin), G, self.wih_d, dx))
+            K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, 2 * G4, self.Cin), G, self.wih_d, dx, bnb=dx_bnb))
 
 
 class CRNNEngine(_EngineBase):
@@ -291,6 +292,11 @@ class CRNNEngine(_EngineBase):
         de = ws("dlogits", N * T, cp)                 # zero-padded to a multiple of 4 classes (PaddedLinear)
         K.pad_channels(K.DynPtr("dlogits"), N * T, self.nclass, cp, de)
         cnn_loader = dict(in_act="relu", **self.bns[6].loader)
+        fz = None                                 # BatchNorm-backward sums already left behind by the producer of `da`
+        # side batches (K.side_batch_begin): 1 = both BiLSTMs' weight gradients behind one fork and conv6..conv3's (+ the early slab
+        # reduce) behind another; 2 = conv2 / conv1 as well; conv0's stays on its own (it is the tail of the pass)
+        sbl = int(os.environ.get("TPGSR_SIDE_BATCH_CRNN", "1"))
+        sb = K.side_batch_begin() if sbl >= 1 else False
         for j in (1, 0):
             L = self.lstm[j]
             G4 = 4 * L.Hh
@@ -299,11 +305,17 @@ class CRNNEngine(_EngineBase):
             dcc = ws(f"l{j}_dcc", N, 2 * L.Hh)
             x = t[f"l{j - 1}_e"] if j == 1 else t["s6"]
             dx = ws(f"l{j}_dx", N * T, L.Cin)
-            L.bwd(N, T, x, t[f"l{j}_G"], t[f"l{j}_C"], t[f"l{j}_out"], de, dout, dhc, dcc, dx, **({} if j == 1 else cnn_loader))
+            if j == 0:    # the first BiLSTM's input is relu(bn6(s6)): bn6's backward sums ride on the projection's data gradient
+                fz = self.bns[6].fuse_stats(t["s6"], N * T, "relu", 2 * G4)
+            L.bwd(N, T, x, t[f"l{j}_G"], t[f"l{j}_C"], t[f"l{j}_out"], de, dout, dhc, dcc, dx, dx_bnb=fz, **({} if j == 1 else cnn_loader))
             de = dx
         da = de                                   # d relu(bn6(s6))
+        K.side_batch_end(sb)
+        sb = False
         for i in range(6, -1, -1):
             conv, bn = self.convs[i], self.bns.get(i)
+            if not sb and (sbl >= 1 and i == 6 or sbl >= 2 and i == 2):
+                sb = K.side_batch_begin()
             (h, w), (oh, ow), (ph, pw) = dims[i]
             M = N * oh * ow
             s = t[f"s{i}"]
@@ -316,11 +328,12 @@ class CRNNEngine(_EngineBase):
                     ds = ws(f"ds{i}b", M, conv.Cout)
                     bn.backward(dz, None, s, M, "none", ds)
             elif bn:
-                bn.backward(da, None, s, M, "relu", ds)
+                bn.backward(da, None, s, M, "relu", ds, fused=fz)
             else:
                 K.act_bwd(s, da, M * conv.Cout, "relu", ds)
             # the conv's own input and the loader it was read through
             if i == 0:
+                K.side_batch_end(sb)
                 conv.wgrad(N, h, w, t["col0"], ds)
                 continue
             else:
@@ -335,8 +348,12 @@ class CRNNEngine(_EngineBase):
                 # overlaps with the rest of this backward pass; the reduce at the end of the plan -- on the step's critical tail,
                 # nothing is left to hide it -- then only covers conv2..conv0
                 K.flush_wgrad_reduces()
+                K.side_batch_end(sb)
+                sb = False
             da = ws(f"da{i - 1}", N * h * w, conv.Cin)
-            conv.dgrad(N, h, w, ds, da)
+            # conv2 / conv4 are followed by BatchNorm + ReLU and no pooling: the sums of that BatchNorm's backward pass ride on this launch
+            fz = pbn.fuse_stats(t[f"s{pi}"], N * h * w, "relu", conv.Cout) if (pbn and pi not in self.POOLS) else None
+            conv.dgrad(N, h, w, ds, da, **(dict(bnb=fz) if fz else {}))
 
     def _record_dgray(self, N, ws):
         h, w = self.IMG_HW

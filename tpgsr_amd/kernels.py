@@ -193,6 +193,7 @@ class Plan:
         self.sid = 0       # stream the next recorded launch goes to: 0 = the caller's stream, 1 = side stream, 2 = leaf stream
         self.forks = 0
         self.leaf_pending = False   # launches on the leaf stream nothing has been ordered after yet
+        self.hold = None            # side_batch(): side-stream launches held back until the batch closes [(op, [(key, arg index)])]
         self._native = None  # tpgsr_plan handle, built on first run()
         self._has_side = False
         self._has_leaf = False
@@ -232,7 +233,26 @@ class Plan:
             self.leaf_pending = False
             self.forks += 1          # the side stream now carries the leaf stream's work: a join must follow
 
+    def side_batch_begin(self):
+        """Side-stream sections opened from here on are HELD and go out behind ONE fork when side_batch_end() is called, instead of one
+        fork each: an event record on the caller's stream costs it ~5 us of queue time (the 64->64 trunk's backward pass has four
+        side sections per block).  The held launches start later, never earlier: they only read buffers the caller's stream does
+        not rewrite before the join (the rule side() already lives by), so the result is the same."""
+        assert self.sid == 0 and self.hold is None
+        self.hold = []
+
+    def side_batch_end(self):
+        held, self.hold = self.hold, None
+        if held:
+            self.ops.append(["fork", None, None, 0])
+            self.forks += 1
+            for op, dyns in held:
+                for key, ai in dyns:
+                    self.dyn.setdefault(key, []).append((len(self.ops), ai))
+                self.ops.append(op)
+
     def join(self):
+        assert self.hold is None, "join inside a side batch"
         self.leaf_to_side()
         if self.forks:
             self.ops.append(["join", None, None, 0])
@@ -322,8 +342,9 @@ class _SideCtx:
     def __enter__(self):
         p = self.plan
         assert p.sid == 0, "nested side-stream sections"
-        p.ops.append(["fork", None, None, 0])
-        p.forks += 1
+        if p.hold is None:
+            p.ops.append(["fork", None, None, 0])
+            p.forks += 1
         p.sid = 1
 
     def __exit__(self, *exc):
@@ -359,6 +380,22 @@ def side():
     """Side-stream section of the plan being recorded (no-op when launching eagerly outside a plan, and inside a leaf section:
     the leaf stream runs its own weight gradients in order)."""
     return _REC.side() if _REC is not None and getattr(_REC, "overlap", False) and _REC.sid != 2 else _NoSide()
+
+
+SIDE_BATCH = os.environ.get("TPGSR_SIDE_BATCH", "1") != "0"
+
+
+def side_batch_begin():
+    """see Plan.side_batch_begin (no-op outside a recording with side streams, and with TPGSR_SIDE_BATCH=0)"""
+    if SIDE_BATCH and _REC is not None and getattr(_REC, "overlap", False) and _REC.sid == 0 and _REC.hold is None:
+        _REC.side_batch_begin()
+        return True
+    return False
+
+
+def side_batch_end(opened: bool):
+    if opened:
+        _REC.side_batch_end()
 
 
 def leaf():
@@ -399,6 +436,10 @@ def _launch(name, *args):
     fn = getattr(_lib.load(), name)
     if _REC is not None:
         args = list(args)
+        if _REC.hold is not None and _REC.sid == 1:      # side-stream launch inside a side batch: recorded when the batch closes
+            dyns = [(a.key, ai) for ai, a in enumerate(args) if isinstance(a, DynPtr)]
+            _REC.hold.append(([name, fn, [None if isinstance(a, DynPtr) else a for a in args], 1], dyns))
+            return
         oi = len(_REC.ops)
         for ai, a in enumerate(args):
             if isinstance(a, DynPtr):
@@ -462,7 +503,9 @@ class ConvGeom:
 
 def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, in_scale=None, in_shift=None, in_act=None,
                    in_ps=False, in_ld=None, in_coff=0, in2_ld=None, out_act=None, out_ps=False, out_ld=None, out_coff=0,
-                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1) -> ConvArgs:
+                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1, bnb=None) -> ConvArgs:
+    """`bnb` (a dict from engine.BNLayer.fuse_stats): this convolution produces the gradient that enters a BatchNorm's backward pass --
+    its epilogue also writes that BatchNorm's two reduction sums per 64-pixel row block (tpgsr_conv_args.bnb_y)"""
     a = ConvArgs()
     a.in_, a.in2, a.in_scale, a.in_shift = _p(inp), _p(in2), _p(in_scale), _p(in_shift)
     a.wt, a.bias, a.out, a.bn_partial = _p(wt), _p(bias), _p(out), _p(bn_partial)
@@ -494,7 +537,23 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
                 assert tw[2] in (0, g.Cin), f"operand split for Cin {tw[2]}, used by a convolution over {g.Cin} channels"
                 if _REC is not None:
                     _REC.keep.append(tw[0])
+    if bnb is not None:
+        if not (a.terms and a.wt_bf and wt_coff % 32 == 0):
+            raise RuntimeError("BatchNorm-backward statistics ride on the split-bf16 convolution kernels only (check bnb_fusable first)")
+        a.bn_partial = _p(bnb.get("partial"))
+        a.bnb_y, a.bnb_mean, a.bnb_rstd = _p(bnb["y"]), _p(bnb.get("mean")), _p(bnb.get("rstd"))
+        a.bnb_scale, a.bnb_shift, a.bnb_act = _p(bnb.get("scale")), _p(bnb.get("shift")), act_code(bnb["act"])
+        a.bnb_store_dz = int(bool(bnb.get("store_dz", False)))   # without "partial": a plain activation backward on the way out
     return a
+
+
+# BatchNorm-backward reduction fused into the producing data-gradient convolution (TPGSR_BNB_FUSE=0: its own launch, as before)
+BNB_FUSE = os.environ.get("TPGSR_BNB_FUSE", "1") != "0"
+
+
+def bnb_fusable(cin: int) -> bool:
+    """can a convolution over `cin` input channels carry a BatchNorm's backward statistics under the current arithmetic policy?"""
+    return bool(BNB_FUSE and CONV_TERMS and cin % 4 == 0)
 
 
 def conv_fwd(args: ConvArgs):
