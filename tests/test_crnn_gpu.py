@@ -66,7 +66,7 @@ def test_semantic_loss_module_on_probabilities(golden_dir):
         assert (pd.grad.cpu() / 3.0 - pr.grad).abs().max() < 1e-5 * pr.grad.abs().max()
 
 
-@pytest.mark.parametrize("hw", [(4, 9), (6, 10)])      # (6, 10): even sizes -> the non-overlapping 2x2 backward fast path
+@pytest.mark.parametrize("hw", [(4, 9), (6, 10), (5, 9)])      # even H (and W): the 2x2 backward fast paths; (5, 9): the gather form
 @pytest.mark.parametrize("cfg", [((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))])
 def test_pool2d(cfg, hw):
     from tpgsr_amd import kernels as K
@@ -297,6 +297,22 @@ def test_train_c3_hipgraph_replay_equals_eager(golden_dir):
     torch.cuda.synchronize()
     print(la, lb)
     assert lb[0] == la[1] and lb[1] == la[2]
+    assert torch.equal(ea.pool.flat, eb.pool.flat)
+
+
+def test_train_c3_teacher_late_equals_default(golden_dir):
+    """TPGSR_TEACHER_LATE: the teacher's forward pass launched after the student's (its soft target only enters the semantic loss and
+    the student's backward pass) -- the same kernels on the same data in another order: bitwise the default step"""
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    t = np.load(os.path.join(golden_dir, "train_c3.npz"))
+    lr, hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+    (sa, ua, ta_, *_), (sb, ub, tb_, *_) = _c3_models(), _c3_models()
+    ea, eb = TPGSRTrainStep(sa, ua, ta_, stu_iter=1), TPGSRTrainStep(sb, ub, tb_, stu_iter=1)
+    eb._teacher_late = True
+    la = [ea.step(lr, hr).item() for _ in range(3)]
+    lb = [eb.step(lr, hr).item() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert la == lb, (la, lb)
     assert torch.equal(ea.pool.flat, eb.pool.flat)
 
 

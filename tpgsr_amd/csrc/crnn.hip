@@ -386,6 +386,70 @@ __global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const float* __restric
   }
 }
 
+// 2 x 2 windows, stride (2, 1), padding (0, 1), even H (pooling2 / pooling3 of the recogniser, crnn.py:60-66): the windows overlap along
+// W only -- input column w sits in window ow = w (columns w-1, w) and in window ow = w+1 (columns w, w+1) of its row pair.  One thread
+// owns the two inputs (2 oh, w), (2 oh + 1, w) x 4 channels: six independent input loads + two gradient loads, no loop (the gather
+// form above walks windows and positions with dependent loads: 40 / 60 us per launch at batch 48 for 10 / 20 MB of traffic).
+__global__ __launch_bounds__(256) void pool2x2s21_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, int N, int H,
+                                                             int W, int C, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, float* __restrict__ dz) {
+  const int C4 = C >> 2, OH = H >> 1, OW = W + 1;
+  const long long total = (long long)N * OH * W * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long p = i / C4;
+    const int w = (int)(p % W);
+    p /= W;
+    const int oh = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const size_t r0 = ((size_t)(n * H + 2 * oh) * W + w) * C + c, r1 = r0 + (size_t)W * C;
+    const bool hasl = w > 0, hasr = w + 1 < W;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xv[2][3];     // [row][left, mine, right]
+    xv[0][1] = *reinterpret_cast<const float4*>(x + r0);
+    xv[1][1] = *reinterpret_cast<const float4*>(x + r1);
+    xv[0][0] = hasl ? *reinterpret_cast<const float4*>(x + r0 - C) : zero;
+    xv[1][0] = hasl ? *reinterpret_cast<const float4*>(x + r1 - C) : zero;
+    xv[0][2] = hasr ? *reinterpret_cast<const float4*>(x + r0 + C) : zero;
+    xv[1][2] = hasr ? *reinterpret_cast<const float4*>(x + r1 + C) : zero;
+    const size_t od = ((size_t)(n * OH + oh) * OW + w) * C + c;
+    const float4 ga = *reinterpret_cast<const float4*>(dout + od);         // window ow = w
+    const float4 gb = *reinterpret_cast<const float4*>(dout + od + C);     // window ow = w + 1
+    const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : zero;
+    auto one = [&](float l0, float m0, float q0, float l1, float m1, float q1, float s, float t, float gA, float gB, float& o0, float& o1)
+                   __attribute__((always_inline)) {
+      const float pm0 = m0 * s + t, pm1 = m1 * s + t;
+      const float vm0 = apply_act(pm0, act), vm1 = apply_act(pm1, act);
+      const float vl0 = hasl ? apply_act(l0 * s + t, act) : -INFINITY, vl1 = hasl ? apply_act(l1 * s + t, act) : -INFINITY;
+      const float vr0 = hasr ? apply_act(q0 * s + t, act) : -INFINITY, vr1 = hasr ? apply_act(q1 * s + t, act) : -INFINITY;
+      // window A (columns w-1, w), scan order (r0, w-1), (r0, w), (r1, w-1), (r1, w): first arg-max
+      int ka = 0;
+      float best = vl0;
+      if (vm0 > best) { best = vm0; ka = 1; }
+      if (vl1 > best) { best = vl1; ka = 2; }
+      if (vm1 > best) { best = vm1; ka = 3; }
+      // window B (columns w, w+1): (r0, w), (r0, w+1), (r1, w), (r1, w+1)
+      int kb = 0;
+      best = vm0;
+      if (vr0 > best) { best = vr0; kb = 1; }
+      if (vm1 > best) { best = vm1; kb = 2; }
+      if (vr1 > best) { best = vr1; kb = 3; }
+      const float g0 = (ka == 1 ? gA : 0.f) + (kb == 0 ? gB : 0.f);
+      const float g1 = (ka == 3 ? gA : 0.f) + (kb == 2 ? gB : 0.f);
+      o0 = g0 * act_grad(pm0, act);
+      o1 = g1 * act_grad(pm1, act);
+    };
+    float4 o0, o1;
+    one(xv[0][0].x, xv[0][1].x, xv[0][2].x, xv[1][0].x, xv[1][1].x, xv[1][2].x, sc.x, sh.x, ga.x, gb.x, o0.x, o1.x);
+    one(xv[0][0].y, xv[0][1].y, xv[0][2].y, xv[1][0].y, xv[1][1].y, xv[1][2].y, sc.y, sh.y, ga.y, gb.y, o0.y, o1.y);
+    one(xv[0][0].z, xv[0][1].z, xv[0][2].z, xv[1][0].z, xv[1][1].z, xv[1][2].z, sc.z, sh.z, ga.z, gb.z, o0.z, o1.z);
+    one(xv[0][0].w, xv[0][1].w, xv[0][2].w, xv[1][0].w, xv[1][1].w, xv[1][2].w, sc.w, sh.w, ga.w, gb.w, o0.w, o1.w);
+    *reinterpret_cast<float4*>(dz + r0) = o0;
+    *reinterpret_cast<float4*>(dz + r1) = o1;
+  }
+}
+
 extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, const float* scale, const float* shift,
                                 int act, int KH, int KW, int SH, int SW, int PH, int PW, float* dz, void* stream) {
   TPGSR_CHECK_ARG(x && dout && dz && KH > 0 && KW > 0 && SH > 0 && SW > 0, "tpgsr_pool2d_bwd: bad arguments");
@@ -399,6 +463,13 @@ extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H,
     const long long tw = (long long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(pool2x2_bwd_kernel, dim3((int)min((long long)16384, (tw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dout, N, H, W,
                        C, scale, shift, act, dz);
+    TPGSR_LAUNCH_CHECK("tpgsr_pool2d_bwd");
+  }
+  if (fast2x2 && vec && KH == 2 && KW == 2 && SH == 2 && SW == 1 && PH == 0 && PW == 1 && !(H & 1) &&
+      (!scale || !(((uintptr_t)scale | (uintptr_t)shift) & 15))) {
+    const long long tw = (long long)N * (H / 2) * W * (C / 4);
+    hipLaunchKernelGGL(pool2x2s21_bwd_kernel, dim3((int)min((long long)16384, (tw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dout, N, H,
+                       W, C, scale, shift, act, dz);
     TPGSR_LAUNCH_CHECK("tpgsr_pool2d_bwd");
   }
   if (vec)

@@ -903,6 +903,10 @@ class TSRNEngine(_EngineBase):
             y1, y2, gt1, h1, gt2, out = (t[p + n] for n in ("y1", "y2", "gt1", "h1", "gt2", "out"))
             # gru2 (input X + h1): parameter grads + d(X + h1) -> gA (incoming gA/gB are dead after the scan)
             L["gru2"].bwd(N, H, W, X, gt2, out, gA, gB if have_B else None, dgi, dgh, gA, in2=h1)
+            if sb and os.environ.get("TPGSR_SIDE_BATCH_SPLIT", "0") == "1":
+                # experiment: what is held so far (+ gru2's weight gradients) goes out here, next to gru1's BiGRU backward kernel
+                K.side_batch_end(sb)
+                sb = K.side_batch_begin()
             # gru1 (input bn2(y2) [+ text strip]): dh = gA
             dgi, dgh = buf("dgi", p + "g1_", 192), buf("dgh", p + "g1_", 192)
             if self.tl:
