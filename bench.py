@@ -27,7 +27,13 @@ import os
 import sys
 import time
 
-import torch
+# The step runs on three HIP streams; a gradient exchange adds RCCL's.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4): with a fifth stream two of them share a queue and an event wait of one blocks the other -- measured at world size 1 with
+# the collectives forced: 8.02 ms per step on four queues, 7.17 on eight (plain step 7.08 either way; profiles/r03z_collective_path_ab.md).
+# Read when the HIP runtime initialises, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -66,7 +72,7 @@ def synthetic_batch(n, seed, device):
     return lr.to(device), hr.to(device)
 
 
-def build_step(cfg_key, dev, world=1, pg=None):
+def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False):
     """networks (weights by recipe: no pretrained files exist) + the train-step driver of the chosen configuration.
     Product code only: the CPU oracle is not needed to build or run the benchmarked step."""
     from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep, TSRNTrainStep
@@ -78,14 +84,14 @@ def build_step(cfg_key, dev, world=1, pg=None):
         net = init_by_recipe(tsrn.TSRN(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 1234)
         net = net.to(dev).train()
         ts = TSRNTrainStep(net, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
-                           process_group=pg, world_size=world)
+                           process_group=pg, world_size=world, force_collectives=force_collectives)
         return ts, [net]
     sr = init_by_recipe(tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 11)
     teacher = init_by_recipe(crnn.CRNN(32, 1, 37, 256), 12)
     students = [init_by_recipe(crnn.CRNN(32, 1, 37, 256), 13 + k).to(dev).train() for k in range(cfg["stu_iter"])]
     ts = TPGSRTrainStep([sr.to(dev).train()], students, teacher.to(dev).eval(), stu_iter=cfg["stu_iter"], sr_share=True,
                         tpg_share=False, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
-                        process_group=pg, world_size=world)
+                        process_group=pg, world_size=world, force_collectives=force_collectives)
     return ts, [sr] + students + [teacher]
 
 
@@ -270,6 +276,7 @@ def main():
     ap.add_argument("--prec", choices=["f32", "x3", "x3b2", "x2", "bf16"], default=None,
                     help="arithmetic of the MFMA GEMMs, see tpgsr_amd/kernels.py (default: TPGSR_CONV_PREC if set, else x2 -- BASELINE.json quotes "
                          "this configuration in bf16; x2 = two bf16 terms per operand holds the north_star gates, tests/test_policy_x2_gpu.py)")
+    ap.add_argument("--force-collectives", action="store_true", help="world size 1 with the RCCL gradient exchange forced on (diagnostic)")
     ap.add_argument("--alt-prec", default="x3", help="a second policy timed after the headline (same step, same batch) and printed as "
                                                       "`alt_precision` of the same line; 'none' skips it")
     ap.add_argument("--graph", action="store_true",
@@ -304,6 +311,12 @@ def main():
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    elif args.force_collectives:
+        # ONE rank with the gradient exchange forced on: RCCL's all-reduce (the identity here) launched from inside the backward pass,
+        # wait, average -- what the collective code path itself costs a step, measurable on a one-GPU box
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     if os.environ.get("TPGSR_BENCH_MAIN_PRIORITY"):     # experiment switch: the step's main stream at another HIP priority
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["TPGSR_BENCH_MAIN_PRIORITY"])))
@@ -314,7 +327,7 @@ def main():
     cfg = CONFIGS[args.config]
     B = cfg["batch"]
     torch.manual_seed(0)
-    ts, nets = build_step(args.config, dev, world, pg)
+    ts, nets = build_step(args.config, dev, world, pg, force_collectives=args.force_collectives)
     ts.broadcast_parameters(0)
     lr_img, hr_img = synthetic_batch(B, 1234 + rank, dev)
 
@@ -364,7 +377,7 @@ def main():
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
                        "kernel_launches_per_step": n_launch, "arithmetic": ARITH[K_POLICY],
-                       "gradient_exchange": None if world == 1 else "one flat fp32 buffer, 2 RCCL all-reduce buckets (SR net overlapped with the student backward)"},
+                       "gradient_exchange": ("forced at world size 1 (RCCL all-reduce = identity)" if args.force_collectives else None) if world == 1 else "one flat fp32 buffer, 2 RCCL all-reduce buckets (SR net overlapped with the student backward)"},
             "final_loss": round(final_loss, 5),
         }
         _log(f"timed region done: {ms:.3f} ms/step")
@@ -429,6 +442,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

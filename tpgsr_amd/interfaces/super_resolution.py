@@ -186,10 +186,12 @@ class TPGSRTrainStep:
         self._dbg = {}
         self._exch = None
         self._overlap_exchange = True      # False while capturing hipGraphs (the all-reduce stays between the graphs)
-        # world size 1: nothing reads the SR network's parameter gradients before the optimiser, so its backward plan does not join the
-        # weight-gradient stream at its end (the student's backward pass starts right away); _join_side() orders the main stream after
-        # it before clip + Adam.  With a gradient exchange the bucket launch right after the SR backward needs them: the plan joins.
-        self._defer_join = (not self.collective) and os.environ.get("TPGSR_DEFER_JOIN", "1") != "0"
+        # The SR network's backward plan does not join the weight-gradient stream at its end (the student's backward pass starts right
+        # away); _join_side() orders the main stream after it before clip + Adam.  With a gradient exchange the SR bucket is launched
+        # FROM the weight-gradient stream (its tail is ordered after every gradient of the SR network: the weight gradients and their
+        # reduces run there, the leaf stream is ordered into it, and it is made to wait for the main stream's BatchNorm / PReLU
+        # gradients), so the collective starts when the gradients are final and the main stream still does not wait.
+        self._defer_join = os.environ.get("TPGSR_DEFER_JOIN", "1") != "0"
         self._sr_pre_side = os.environ.get("TPGSR_SR_PRE_SIDE", "1") != "0"
         # teacher forward started AFTER the first student forward instead of next to it: its soft target q only enters the semantic
         # loss and the student's backward pass (the prior itself does not need it), so it can fill the SR network's BiGRU kernels
@@ -301,7 +303,13 @@ class TPGSRTrainStep:
             dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i, defer_join=self._defer_join)
             if i == 0 and self.collective and self._overlap_exchange:
                 # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
-                self._exchanger().launch(0)
+                if self._defer_join and not K.DRYRUN:
+                    side = K.side_stream(lr_img.device)
+                    side.wait_stream(K.current_stream())      # BatchNorm / PReLU-slope gradients are written on the main stream
+                    with K.stream_ctx(side):
+                        self._exchanger().launch(0)
+                else:
+                    self._exchanger().launch(0)
             self._mark(f"SR{i} bwd")
             if late and i == self.stu_iter - 1:
                 # q is needed from here on: the semantic losses of all stages (the softmax is recomputed into a scratch: 6 us each)
