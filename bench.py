@@ -95,6 +95,16 @@ def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False):
     return ts, [sr] + students + [teacher]
 
 
+def _exchange_note(ts, world, forced):
+    if world == 1 and not forced:
+        return None
+    nb = len(ts._exchanger().bounds)
+    note = ("one flat fp32 buffer, %d RCCL all-reduce buckets launched from the weight-gradient stream as their gradients become final "
+            "(SR net under the text-prior generator's backward%s)" % (nb, "; the generator from conv3 on, 95.6 %, under the rest of its backward; "
+                                                                      "1.5 MB at the end" if nb == 3 else ""))
+    return note + ("; forced at world size 1 (the all-reduce is the identity)" if world == 1 else "")
+
+
 PEAK_BY_TERMS = {0: FP32_MFMA_PEAK_TFLOPS,          # v_mfma_f32_32x32x2_f32
                  3: BF16_MFMA_PEAK_TFLOPS / 6.0,    # fp32-equivalent: six v_mfma_f32_32x32x16_bf16 per product block
                  2: BF16_MFMA_PEAK_TFLOPS / 3.0,    # two-term split: three MFMAs per product block
@@ -110,7 +120,7 @@ def conv_family(nets):
     items = []
     for net in nets:
         for pl in net._engine()._plans.values():
-            for pname in ("pre", "fwd", "bwd"):
+            for pname in ("pre", "fwd", "bwd", "bwd_b"):
                 if pname not in pl:
                     continue
                 for name, fn, args, _sid in pl[pname].ops:
@@ -268,6 +278,11 @@ def cpu_baseline(cfg_key, seconds_budget=25.0, max_steps=6):
 
 
 def main():
+    # ONE JSON line on stdout and nothing else: libraries write there too (RCCL prints a version banner when the process exits, gloo its
+    # connection messages), so the descriptor the line goes to is kept aside and fd 1 is pointed at stderr for everybody else
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -288,7 +303,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.config)), flush=True)
+        print(json.dumps(cpu_baseline(args.config)), file=line_out, flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -367,7 +382,7 @@ def main():
     if rank == 0:
         ms = 1e3 * dt / args.steps
         value = B * world * args.steps / dt
-        n_launch = sum(len(pl[k]) for m in nets for pl in m._engine()._plans.values() for k in ("pre", "fwd", "bwd") if k in pl)
+        n_launch = sum(len(pl[k]) for m in nets for pl in m._engine()._plans.values() for k in ("pre", "fwd", "bwd", "bwd_b") if k in pl)
         out = {
             "metric": "training img/s (16x64->32x128, bs=%d/GPU), %s full train step" % (B, "TPGSR-TSRN" if cfg["tl"] else "TSRN"),
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -377,7 +392,7 @@ def main():
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
                        "kernel_launches_per_step": n_launch, "arithmetic": ARITH[K_POLICY],
-                       "gradient_exchange": ("forced at world size 1 (RCCL all-reduce = identity)" if args.force_collectives else None) if world == 1 else "one flat fp32 buffer, 2 RCCL all-reduce buckets (SR net overlapped with the student backward)"},
+                       "gradient_exchange": _exchange_note(ts, world, args.force_collectives)},
             "final_loss": round(final_loss, 5),
         }
         _log(f"timed region done: {ms:.3f} ms/step")
@@ -439,7 +454,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args.config)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
     if world > 1:
         torch.distributed.barrier()
     if torch.distributed.is_initialized():

@@ -47,7 +47,9 @@ for force in (False, True):
     torch.cuda.synchronize()
     if force:
         ex = ts._exchanger()
-        assert ex.active and ex.world == 1 and len(ex.bounds) == 2
+        # SR networks | the text-prior generator from conv3 on (final between its two backward plans) | its first three conv layers
+        assert ex.active and ex.world == 1 and len(ex.bounds) == 3
+        assert ex.bounds[2] == (ex.bounds[0][1], ex.bounds[1][0]) and not ex._work
     res.append((losses, ts.pool.flat.clone(), ts.pool.grad.clone()))
 (l0, p0, g0), (l1, p1, g1) = res
 assert l0 == l1, (l0, l1)

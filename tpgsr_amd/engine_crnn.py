@@ -226,13 +226,13 @@ class CRNNEngine(_EngineBase):
         return self._two_pass((N, bool(training), slot, getattr(self, "role", "tpg")), lambda ws, final: self._record(N, training, ws, final))
 
     def _record(self, N, training, ws, final):
-        fwd, bwd, dgp = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_dgray")
-        fwd.final = bwd.final = dgp.final = final
+        fwd, bwd, bwd_b, dgp = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_bwd_b"), Plan("crnn_dgray")
+        fwd.final = bwd.final = bwd_b.final = dgp.final = final
         # weight gradients on the side stream + one batched slab reduce, as in TSRNEngine (every buffer a weight-gradient
         # launch reads -- ds{i}, saved activations, the LSTM gate gradients after the time loop -- is written once per pass)
-        bwd.overlap = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
+        bwd.overlap = bwd_b.overlap = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
         defer = os.environ.get("TPGSR_DEFER_REDUCE", "1") != "0"
-        bwd.deferred = [] if defer else None
+        bwd.deferred, bwd_b.deferred = ([] if defer else None), ([] if defer else None)
         self._cur_ws, self._wg_idx = ws, 0
         for bn in self._bn_layers:
             bn.use(ws)
@@ -240,13 +240,19 @@ class CRNNEngine(_EngineBase):
             self._record_fwd(N, training, ws)
         if training:
             with recording(bwd), K.conv_terms(K.terms_for("tpg", "bwd")):
-                self._record_bwd(N, ws)
+                # the pass is recorded as TWO plans, cut behind the early slab reduce: every gradient from conv3 to the end of the
+                # parameter arena (both BiLSTMs, conv6..conv3, bn6 / bn4: 95.6 % of it) is final there, and a data-parallel train step
+                # launches that bucket's all-reduce between the two (backward(..., after_early=...)) under the rest of the pass
+                self._record_bwd(N, ws, cut_to=bwd_b if os.environ.get("TPGSR_CRNN_BWD_SPLIT", "1") != "0" else None)
                 if defer:
                     K.flush_wgrad_reduces()
-                bwd.join()
+                K._REC.join()
             with recording(dgp), K.conv_terms(K.terms_for("tpg", "bwd")):   # d gray: only later cascade stages ask for it
                 self._record_dgray(N, ws)
-        return dict(fwd=fwd, bwd=bwd, dgray=dgp, ws=ws)
+        out = dict(fwd=fwd, bwd=bwd, dgray=dgp, ws=ws)
+        if len(bwd_b):
+            out["bwd_b"] = bwd_b
+        return out
 
     def _record_fwd(self, N, training, ws):
         self.pack_all()
@@ -284,7 +290,7 @@ class CRNNEngine(_EngineBase):
             x = e
         K.copy(x, K.DynPtr("logits"), N * T * self.nclass)
 
-    def _record_bwd(self, N, ws):
+    def _record_bwd(self, N, ws, cut_to=None):
         t = ws.t
         dims = self._dims()
         T = self.T
@@ -350,6 +356,8 @@ class CRNNEngine(_EngineBase):
                 K.flush_wgrad_reduces()
                 K.side_batch_end(sb)
                 sb = False
+                if cut_to is not None:
+                    K.continue_in(cut_to)
             da = ws(f"da{i - 1}", N * h * w, conv.Cin)
             # conv2 / conv4 are followed by BatchNorm + ReLU and no pooling: the sums of that BatchNorm's backward pass ride on this launch
             fz = pbn.fuse_stats(t[f"s{pi}"], N * h * w, "relu", conv.Cout) if (pbn and pi not in self.POOLS) else None
@@ -381,13 +389,31 @@ class CRNNEngine(_EngineBase):
         self._last_gray = gray
         return logits
 
-    def backward(self, N, gray: torch.Tensor, dlogits: torch.Tensor, need_dgray: bool = False, slot: int = 0) -> Optional[torch.Tensor]:
+    #: first parameter (arena order) whose gradient is NOT final when the first backward plan has run: everything from here to the
+    #: end of the arena is (both BiLSTMs, conv6..conv3 and their BatchNorms)
+    EARLY_FINAL_FROM = "cnn.conv3.weight"
+
+    def early_final_offset(self) -> Optional[int]:
+        """offset (floats, in this network's gradient arena) from which on the gradients are final after the FIRST backward plan --
+        None when the pass is recorded as one plan (TPGSR_CRNN_EARLY_REDUCE=0 / no deferred reduces)"""
+        if "0" in (os.environ.get("TPGSR_CRNN_EARLY_REDUCE", "1"), os.environ.get("TPGSR_DEFER_REDUCE", "1"), os.environ.get("TPGSR_CRNN_BWD_SPLIT", "1")):
+            return None
+        return self.arena.layout()[0][self.EARLY_FINAL_FROM]
+
+    def backward(self, N, gray: torch.Tensor, dlogits: torch.Tensor, need_dgray: bool = False, slot: int = 0,
+                 after_early=None) -> Optional[torch.Tensor]:
+        """after_early(): called between the two backward plans, when every gradient from early_final_offset() on is final (on the
+        weight-gradient stream + this stream) -- a data-parallel step launches that bucket's all-reduce there"""
         pl = self.plans(N, True, slot)
         self.arena.attach_grads()
         bwd = pl["bwd"]
         dlogits = dlogits.contiguous().float()
         bwd.set_ptr("dlogits", dlogits.data_ptr())
         bwd.run()
+        if "bwd_b" in pl:
+            if after_early is not None:
+                after_early()
+            pl["bwd_b"].run()
         if not need_dgray:
             return None
         dgray = torch.empty_like(gray)

@@ -185,6 +185,7 @@ class TPGSRTrainStep:
         self._graph = None
         self._dbg = {}
         self._exch = None
+        self._early_bucket = None          # index of the text-prior generator's early gradient bucket (see _exchanger)
         self._overlap_exchange = True      # False while capturing hipGraphs (the all-reduce stays between the graphs)
         # The SR network's backward plan does not join the weight-gradient stream at its end (the student's backward pass starts right
         # away); _join_side() orders the main stream after it before clip + Adam.  With a gradient exchange the SR bucket is launched
@@ -303,13 +304,7 @@ class TPGSRTrainStep:
             dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i, defer_join=self._defer_join)
             if i == 0 and self.collective and self._overlap_exchange:
                 # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
-                if self._defer_join and not K.DRYRUN:
-                    side = K.side_stream(lr_img.device)
-                    side.wait_stream(K.current_stream())      # BatchNorm / PReLU-slope gradients are written on the main stream
-                    with K.stream_ctx(side):
-                        self._exchanger().launch(0)
-                else:
-                    self._exchanger().launch(0)
+                self._launch_bucket_from_side(0, lr_img.device)
             self._mark(f"SR{i} bwd")
             if late and i == self.stu_iter - 1:
                 # q is needed from here on: the semantic losses of all stages (the softmax is recomputed into a scratch: 6 us each)
@@ -323,7 +318,10 @@ class TPGSRTrainStep:
             if getattr(self, "_debug", False):
                 self._dbg.setdefault("dprior", {})[i] = dprior.clone()
                 self._dbg.setdefault("dlogits", {})[i] = st["dlogits"].clone()
-            dgray = stu._engine().backward(N, st["gray"][i], st["dlogits"], need_dgray=i > 0, slot=i)
+            kw = {}
+            if i == 0 and self.collective and self._overlap_exchange and self._exchanger() is not None and self._early_bucket is not None:
+                kw["after_early"] = lambda: self._launch_bucket_from_side(self._early_bucket, lr_img.device)
+            dgray = stu._engine().backward(N, st["gray"][i], st["dlogits"], need_dgray=i > 0, slot=i, **kw)
             if i > 0:
                 self._dbg_dgray = dgray
                 K.bicubic_gray_bwd(dgray, N, C, H2, W2, 32, 100, st["dcas"])
@@ -337,12 +335,34 @@ class TPGSRTrainStep:
         if self._exch is None or self._exch.flat.data_ptr() != self.pool.grad.data_ptr():
             inv = self._static["inv_world"]
             b_sr, b_stu = self.pool.span(self.sr), self.pool.span(self.stu)
-            self._exch = GradientExchanger(self.pool.grad, [b_sr, (b_sr[1], b_stu[1])], self.pg,
+            bounds = [b_sr, (b_sr[1], b_stu[1])]
+            # ONE text-prior generator whose backward pass is recorded in two plans (CRNNEngine): everything from conv3 to the end of its
+            # arena (95.6 %) is final between them and travels under the rest of the pass; what is left for the end is 1.5 MB
+            self._early_bucket = None
+            eng = self.stu[0]._engine() if len(self.stu) == 1 else None
+            off = eng.early_final_offset() if hasattr(eng, "early_final_offset") else None
+            if off is not None:
+                cut = self.pool.ranges[id(self.stu[0])][0] + off
+                bounds = [b_sr, (cut, b_stu[1]), (b_sr[1], cut)]
+                self._early_bucket = 1
+            self._exch = GradientExchanger(self.pool.grad, bounds, self.pg,
                                            scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv), force=self.collective)
         return self._exch
 
+    def _launch_bucket_from_side(self, b, device):
+        """launch bucket b's all-reduce FROM the weight-gradient stream: its tail is ordered after the weight gradients and slab reduces
+        recorded so far (and the leaf stream); it is made to wait for this stream's BatchNorm / PReLU-slope gradients; this stream does
+        not wait for anything"""
+        if self._defer_join and not K.DRYRUN:
+            side = K.side_stream(device)
+            side.wait_stream(K.current_stream())
+            with K.stream_ctx(side):
+                self._exchanger().launch(b)
+        else:
+            self._exchanger().launch(b)
+
     def _exchange(self):
-        """two buckets of ONE flat buffer (SR nets | students); bucket 0 was launched inside the backward pass"""
+        """buckets of ONE flat buffer (SR nets | students, the single student cut in two); all but the last were launched inside the backward pass"""
         if self.collective:
             self._exchanger().finish()
 

@@ -432,6 +432,18 @@ class recording:
         return False
 
 
+def continue_in(plan: Plan):
+    """The recording goes on in `plan` (same streams, run right after the current one): the caller of the two plans regains control in
+    between -- a train step launches a gradient bucket there.  Side-stream work of the first plan stays pending (no join): the second
+    plan's launches follow it in stream order, and its join covers both."""
+    global _REC
+    assert _REC is not None and _REC.sid == 0 and _REC.hold is None, "continue_in inside a stream section / side batch"
+    assert not getattr(_REC, "deferred", None), "deferred slab reduces must be flushed before the recording moves on"
+    if _REC.forks or _REC.leaf_pending:
+        plan.forks += 1            # something of the first plan may still run on the side stream: the second plan's join must be emitted
+    _REC = plan
+
+
 def _launch(name, *args):
     fn = getattr(_lib.load(), name)
     if _REC is not None:
