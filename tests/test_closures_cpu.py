@@ -115,15 +115,14 @@ def test_create_window_shape_and_empty_batch():
             ResizeNormalize((128, 32), mask=True, device="cpu")([])     # GPU only, also for an empty batch
 
 
-def test_hardware_queue_count_is_raised_before_hip_initialises():
-    """the step's three streams + RCCL's need more than HIP's default four hardware queues: importing the package
-    or bench.py sets GPU_MAX_HW_QUEUES=8 unless the caller chose a value"""
+def test_bench_raises_the_hardware_queue_count_before_hip_initialises():
+    """the step's three streams + RCCL's need more than HIP's default four hardware queues: bench.py sets
+    GPU_MAX_HW_QUEUES=8 before it imports torch, unless the caller chose a value"""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    code = "import os, sys; sys.path.insert(0, %r); import %s; print(os.environ['GPU_MAX_HW_QUEUES'])"
-    for mod in ("tpgsr_amd", "bench"):
-        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-        assert subprocess.run([sys.executable, "-c", code % (root, mod)], capture_output=True, text=True, env=env, timeout=300).stdout.strip() == "8"
-        env["GPU_MAX_HW_QUEUES"] = "6"
-        assert subprocess.run([sys.executable, "-c", code % (root, mod)], capture_output=True, text=True, env=env, timeout=300).stdout.strip() == "6"
+    code = "import os, sys; sys.path.insert(0, %r); import bench; print(os.environ['GPU_MAX_HW_QUEUES'])" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "6"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300).stdout.strip() == "6"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 3, call t: teacher forward launched after the student's (fills the SR network's BiGRU kernels), side batch split at gru2: parity, A/B
+# (TPGSR_TEACHER_LATE was removed from the tree afterwards: slower, and its bitwise test differed once in three suite runs)
 OUT=gpurun_out/r03t; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_crnn_gpu.py -m gpu -q -x -p no:cacheprovider -k "teacher_late or hipgraph or golden" > $OUT/tests1.log 2>&1; echo "tests1 rc=$?"; tail -3 $OUT/tests1.log

@@ -194,10 +194,6 @@ class TPGSRTrainStep:
         # gradients), so the collective starts when the gradients are final and the main stream still does not wait.
         self._defer_join = os.environ.get("TPGSR_DEFER_JOIN", "1") != "0"
         self._sr_pre_side = os.environ.get("TPGSR_SR_PRE_SIDE", "1") != "0"
-        # teacher forward started AFTER the first student forward instead of next to it: its soft target q only enters the semantic
-        # loss and the student's backward pass (the prior itself does not need it), so it can fill the SR network's BiGRU kernels
-        # (latency-bound, a fraction of the CUs) instead of competing with the student's convolutions
-        self._teacher_late = os.environ.get("TPGSR_TEACHER_LATE", "0") == "1"
 
     def _mark(self, name):
         """diagnostics (tools/lab/step_phases.py): with `self._marks = []` set, an event on the caller's stream at every phase boundary"""
@@ -219,7 +215,7 @@ class TPGSRTrainStep:
                       part_sem=[torch.empty(_NBLK, 2, device=dev) for _ in range(S)],
                       l_img=[torch.zeros((), device=dev) for _ in range(S)], l_sem=[torch.zeros((), device=dev) for _ in range(S)],
                       gray=[torch.empty(N, 1, 32, 100, device=dev) for _ in range(S)],
-                      p=[torch.empty(N, 26, 37, device=dev) for _ in range(S)], p_tmp=torch.empty(N, 26, 37, device=dev),
+                      p=[torch.empty(N, 26, 37, device=dev) for _ in range(S)],
                       prior=[torch.empty(N, 37, 1, 26, device=dev) for _ in range(S)],
                       dsr=[torch.empty(N, C, 2 * H, 2 * W, device=dev) for _ in range(S)],
                       dcas=torch.empty(N, C, 2 * H, 2 * W, device=dev), dlogits=torch.empty(N, 26, 37, device=dev))
@@ -239,17 +235,11 @@ class TPGSRTrainStep:
         # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
         # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
         main, aux = K.current_stream(), K.aux_stream(lr_img.device)
-        late = self._teacher_late
-
-        def teacher_forward():
-            aux.wait_stream(main)
-            with K.stream_ctx(aux):
-                K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
-                t_logits = self.teacher._engine().forward(st["gray_hr"], False)
-                K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
-
-        if not late:
-            teacher_forward()
+        aux.wait_stream(main)
+        with K.stream_ctx(aux):
+            K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
+            t_logits = self.teacher._engine().forward(st["gray_hr"], False)
+            K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
         cascade, ch, cw = lr_img, H, W
         srs, logits_keep = [], []
         # the SR network's prior-independent prologue (operand packing, STN head, rectification, block1: ~0.3 ms of small launches) runs
@@ -266,17 +256,11 @@ class TPGSRTrainStep:
             K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
             logits = stu._engine().forward(st["gray"][i], True, slot=i)
             self._mark(f"student{i} fwd")
-            if late:
-                if i == 0:
-                    teacher_forward()           # ordered after the student's forward pass on the caller's stream
-                logits_keep.append(logits)
-                K.softmax_prior_fwd(logits, None, N, 26, 37, N // 4, st["p"][i], st["prior"][i], None, _NBLK)
-            else:
-                if i == 0:
-                    main.wait_stream(aux)       # the teacher's distribution q is needed from here on
-                    self._mark("wait teacher")
-                K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
-                K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
+            if i == 0:
+                main.wait_stream(aux)           # the teacher's distribution q is needed from here on
+                self._mark("wait teacher")
+            K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
+            K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
             if pre_side:
                 main.wait_stream(side)
                 self._mark(f"wait SR prologue{i}")
@@ -292,8 +276,7 @@ class TPGSRTrainStep:
         for i in range(self.stu_iter):
             if i > 0:
                 K.add(st["loss"], st["l_img"][i], 1, st["loss"])
-            if not late:
-                K.add(st["loss"], st["l_sem"][i], 1, st["loss"])
+            K.add(st["loss"], st["l_sem"][i], 1, st["loss"])
         # backward, last stage first
         for i in range(self.stu_iter - 1, -1, -1):
             stu = self.stu[0 if self.tpg_share else i]
@@ -306,14 +289,6 @@ class TPGSRTrainStep:
                 # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
                 self._launch_bucket_from_side(0, lr_img.device)
             self._mark(f"SR{i} bwd")
-            if late and i == self.stu_iter - 1:
-                # q is needed from here on: the semantic losses of all stages (the softmax is recomputed into a scratch: 6 us each)
-                main.wait_stream(aux)
-                self._mark("wait teacher")
-                for j in range(self.stu_iter):
-                    K.softmax_prior_fwd(logits_keep[j], st["q"], N, 26, 37, 0, st["p_tmp"], None, st["part_sem"][j], _NBLK)
-                    K.semantic_loss_finalize(st["part_sem"][j], _NBLK, N * 26 * 37, 100.0, st["l_sem"][j])
-                    K.add(st["loss"], st["l_sem"][j], 1, st["loss"])
             K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
             if getattr(self, "_debug", False):
                 self._dbg.setdefault("dprior", {})[i] = dprior.clone()
