@@ -135,6 +135,50 @@ def test_bucketed_overlapped_exchange_two_ranks():
     assert (f0 - want).abs().max() < 1e-6
 
 
+def _three_bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tpgsr_amd.distributed import GradientExchanger
+    g = torch.Generator().manual_seed(200 + rank)
+    flat = torch.randn(1000, generator=g)
+    mine = flat.clone()
+    # the C3 step's layout: SR networks [0, 300) | gap + the generator's first layers [300, 340) | the generator from conv3 on [340, 1000):
+    # bucket 1 is the LATER address range and leaves first (between the generator's two backward plans), bucket 2 at the end
+    ex = GradientExchanger(flat, [(0, 300), (340, 1000), (300, 340)], None)
+    ex.begin()
+    ex.launch(0)
+    flat[300:] += 1.0                  # "the generator's backward" still writes both of its ranges
+    ex.launch(1)
+    flat[300:340] += 2.0               # ... and only the first layers after the early bucket left
+    ex.finish()
+    q.put((rank, mine, flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_three_buckets_launched_out_of_address_order_two_ranks():
+    """the bounds TPGSRTrainStep hands the exchanger with one text-prior generator: three buckets, the middle address range last"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_three_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+    (_, a0, f0), (_, a1, f1) = res
+    want = (a0 + a1) / 2
+    want[300:] += 1.0
+    want[300:340] += 2.0
+    assert torch.equal(f0, f1)
+    assert (f0 - want).abs().max() < 1e-6
+
+
 def test_arena_pool_and_dataparallel_wrapper_cpu():
     """ArenaPool layout (contiguous, 256-byte aligned slices, SR nets before students) and the .module-exposing wrapper's
     state_dict prefix -- host logic only, no kernels (the engines bind lazily on the GPU)."""
