@@ -180,3 +180,34 @@ def test_plan_side_batch_on_cpu():
         K.side_batch_end(sb)
         empty.join()
     assert [(op[0], op[3]) for op in empty.ops] == [("tpgsr_zero", 0)]
+
+
+def test_plan_continue_in_on_cpu():
+    """K.continue_in: a pass recorded as two plans (the caller regains control in between).  The first plan leaves its side-stream work
+    pending -- no join -- and the second plan's join is emitted even when it has no side section of its own"""
+    from tpgsr_amd import kernels as K
+    a, b = K.Plan("a"), K.Plan("b")
+    a.overlap = b.overlap = True
+    with K.recording(a):
+        K._launch("tpgsr_zero", 0x1000, 16)
+        with K.side():
+            K._launch("tpgsr_zero", 0x2000, 16)
+        K.continue_in(b)
+        K._launch("tpgsr_zero", 0x3000, 16)
+        K._REC.join()
+    assert [(op[0], op[3]) for op in a.ops] == [("tpgsr_zero", 0), ("fork", 0), ("tpgsr_zero", 1)]
+    assert [(op[0], op[3]) for op in b.ops] == [("tpgsr_zero", 0), ("join", 0)]
+    c, d = K.Plan("c"), K.Plan("d")                    # nothing pending: no join needed in the second plan
+    with K.recording(c):
+        K._launch("tpgsr_zero", 0x1000, 16)
+        K.continue_in(d)
+        K._launch("tpgsr_zero", 0x3000, 16)
+        K._REC.join()
+    assert [(op[0], op[3]) for op in d.ops] == [("tpgsr_zero", 0)]
+    e, f = K.Plan("e"), K.Plan("f")                    # not from inside a side section / a side batch
+    e.overlap = True
+    with K.recording(e):
+        sb = K.side_batch_begin()
+        with pytest.raises(AssertionError):
+            K.continue_in(f)
+        K.side_batch_end(sb)

@@ -57,6 +57,8 @@ stus = [crnn.CRNN(32, 1, 37, 256).train() for _ in range(3)]
 ts = TPGSRTrainStep([sr], stus[:1], teacher, stu_iter=1)
 ts.step(lr, hr)
 out["c3"] = conv_stats([sr, stus[0], teacher])
+spl = [pl for pl in stus[0]._engine()._plans.values() if "bwd" in pl and len(pl["bwd"])][0]
+out["stu_bwd_split"] = [[op[0] for op in spl[k].ops if op[1] is None] for k in ("bwd", "bwd_b")] + [stus[0]._engine().early_final_offset()]
 sr5 = tsrn.TSRN_TL(STN=True, mask=True).train()
 ts5 = TPGSRTrainStep([sr5], stus, teacher, stu_iter=3, sr_share=True)
 ts5.step(lr, hr)
@@ -111,6 +113,11 @@ def test_record_all_plans_without_gpu():
     assert res["c2"][2].get("conv_fwd+bnb", 0) == 11 + 1
     assert res["c3"][2].get("tpgsr_bn_bwd_reduce", 0) == res["c3"][2]["tpgsr_bn_bwd_finalize"] - 17
     assert res["c3"][2].get("tpgsr_act_bwd", 0) == 0
+    # the text-prior generator's backward pass is two plans: the first forks and never joins, the second ends with THE join; everything
+    # from conv3 on (offset 370176 of 8331304 floats) is final in between
+    a_edges, b_edges, cut = res["stu_bwd_split"]
+    assert "join" not in a_edges and a_edges.count("fork") >= 2 and b_edges[-1] == "join" and b_edges.count("join") == 1
+    assert cut == 370176
     assert res["pool"][0] >= res["pool"][1] and res["views"] and res["sr_first"]
     assert res["live_after_bwd"] == 0
     assert res["live_after_dropped_graphs"] == 0
