@@ -59,7 +59,9 @@ ARITH = {"f32": "fp32 operands on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
          "x3b2": "forward passes fp32-equivalent (x3: split into 3 bf16 terms, 6 MFMAs per product block); backward GEMMs (data and weight "
                  "gradients) on the two-term split (3 MFMAs per product block); fp32 accumulate everywhere",
          "x2": "two-term split: every fp32 operand as the sum of TWO bf16 terms (16 significand bits), 3 bf16 MFMAs per product block, fp32 "
-               "accumulate, in the SR network and all backward GEMMs; the text-prior generator's forward stays fp32-equivalent (x3)",
+               "accumulate, in the SR network, in all backward GEMMs AND in the frozen teacher recogniser's forward (its softmax is only the "
+               "soft distillation target); the STUDENT text-prior generator's forward stays fp32-equivalent (x3), so its arg-max prior is "
+               "computed exactly as under x3",
          "bf16": "bf16 operands (RNE from fp32) on the bf16 matrix cores with fp32 accumulation in the SR network and all backward "
                  "GEMMs; the text-prior generator's forward stays fp32-equivalent (split operands) so arg-max priors are identical "
                  "to the fp32 oracle; activations / statistics / recurrences / losses / optimiser fp32"}
@@ -203,10 +205,13 @@ def measure_traffic(cfg_key, timeout_s=400):
     if not shutil.which("rocprofv3"):
         return None
     out = os.path.join("gpurun_out", "bench_pmc")
+    result = os.path.join(ROOT, out, "traffic.json")
+    if os.path.exists(result):        # a file left by an earlier run must never be reported as this run's measurement
+        os.remove(result)
     try:
         subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_step.sh"), out, cfg_key, "4"], cwd=ROOT, capture_output=True, text=True,
                        timeout=timeout_s, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
-        return json.load(open(os.path.join(ROOT, out, "traffic.json")))
+        return json.load(open(result))
     except Exception as e:   # report, never hide
         _log(f"traffic measurement failed: {type(e).__name__}: {e}")
         return None
@@ -413,6 +418,7 @@ def main():
                                "bound": "mfma", "achieved": round(t["tflops"], 2), "peak": round(t["peak"], 1), "unit": "TFLOP/s",
                                "frac": round(t["frac"], 4),
                                "traffic": round(fam_bytes / t["launches"]) if fam_bytes else None,
+                               "traffic_live": bool(fam_bytes),     # measured by THIS run's two PMC passes (a stale result file is deleted first)
                                "traffic_note": "HBM-side bytes per launch (mean over the family's launches): FETCH_SIZE + WRITE_SIZE of the family's kernels in one "
                                                "training step, two rocprofv3 --pmc passes, calibrated in-pass (tools/pmc_step.sh); algorithmic_bytes_per_launch beside it",
                                "algorithmic_bytes_per_launch": round(t["alg_bytes"] / t["launches"]),

@@ -565,6 +565,27 @@ int tpgsr_plan_run(void* plan, void* main_stream, void* side_stream);
  * generator's backward pass on the main stream. */
 int tpgsr_plan_add_edge(void* plan, int src, int dst);
 int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream, void* leaf_stream);
+/* Execution modes of tpgsr_plan_run3, process-wide -- test and diagnostic instruments, no product entry point switches them on:
+ *   serial != 0      : every launch goes to the caller's stream in RECORDING order and the stream edges are dropped: the reference
+ *                      schedule the three-stream replay must equal bit for bit (tests/test_schedule_gpu.py);
+ *   fuzz_max_us > 0  : around every fork / join / edge a one-wave spin kernel of random length (0 .. fuzz_max_us microseconds,
+ *                      xorshift64* seeded with `seed`) delays a random stream, the edge's source and its destination -- an ordering
+ *                      that only holds because one stream happens to be ahead of another breaks under it;
+ *   noise_blocks > 0 : ... and a busy kernel of noise_blocks workgroups co-runs on a stream of its own (wave timing inside the
+ *                      step's kernels changes: a reduction whose order follows arrival would show).
+ * tpgsr_plan_fuzz_point(stream): the same perturbation for stream edges a caller makes outside a plan.
+ * tpgsr_spin: the spin kernel itself (blocks x threads busy-waiting `us` microseconds of the 100 MHz wall clock; work != 0: half of
+ * the waves run FMAs meanwhile). */
+void tpgsr_plan_set_mode(int serial, int fuzz_max_us, unsigned long long seed, int noise_blocks);
+int tpgsr_plan_get_mode(void);
+int tpgsr_plan_fuzz_point(void* stream);
+int tpgsr_spin(int blocks, int threads, float us, int work, void* stream);
+/* Stamp mode (un-profiled per-op time line): with tpgsr_plan_set_stamp(1) every launch of a plan is followed by a timing event on its
+ * stream; tpgsr_plan_stamp_epoch(stream) records the common origin; after a device synchronisation tpgsr_plan_read_stamps fills
+ * ms_out[i] = origin -> end of op i of the plan's last run (-1 for stream edges) and sid_out[i] = its stream (0 main, 1 side, 2 leaf). */
+int tpgsr_plan_set_stamp(int on);
+int tpgsr_plan_stamp_epoch(void* stream);
+int tpgsr_plan_read_stamps(void* plan, float* ms_out, int* sid_out, int cap);
 /* A HIP stream for the side-stream role, optionally confined to the compute units whose bits are set in cu_mask
  * (n_words 32-bit words, bit i of word w = CU 32*w + i; NULL / 0 = all CUs).  Returns NULL on failure. */
 void* tpgsr_stream_create(const unsigned int* cu_mask, int n_words);

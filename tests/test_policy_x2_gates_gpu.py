@@ -1,0 +1,142 @@
+"""GPU: the bench headline's arithmetic (`x2`: every fp32 operand as the sum of TWO bf16 terms in the SR network, in every backward
+GEMM and in the frozen teacher; the student's forward stays fp32-equivalent) gated on every configuration a number is quoted on, not
+only on C3 step 0 (tests/test_policy_x2_gpu.py): the C5-shaped cascade, C2, a multi-step trajectory against the REFERENCE's own
+losses, and element-wise gradients against oracle autograd with a stated bound.  The reference computes in fp32 end to end
+(model/tsrn.py:178-215, model/crnn/crnn.py:76-90); north_star's gates are |dPSNR| < 1e-3 dB and identical arg-max text priors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tpgsr_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture()
+def x2():
+    from tpgsr_amd import kernels as K
+    prev = K.POLICY
+    K.set_conv_prec("x2")
+    yield K
+    K.set_conv_prec(prev)
+
+
+def test_c5_shape_cascade_under_x2_holds_the_gates(x2):
+    """stu_iter 3, sr_share, three students, bs 32: later-stage students read an SR image the two-term SR network produced.
+    |dPSNR| < 1e-3 dB on the last SR image, stage-0 arg-max priors identical, later stages within the 0.5 % the x3 test allows."""
+    import test_fullsize_gpu as T
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    T._threads()
+    sr, stus, teacher, sd_sr, sd_s, sd_t = T._tpgsr(3, seeds=(21, 22, 23))
+    lr, hr = O.synthetic_batch(32, 555)
+    ts = TPGSRTrainStep([sr], stus, teacher, stu_iter=3, sr_share=True, tpg_share=False)
+    loss = ts.step(lr.to(DEV), hr.to(DEV))
+    torch.cuda.synchronize()
+    ps, pt, pu = O.as_params(sd_sr), O.as_params(sd_t, False), [O.as_params(x) for x in sd_s]
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
+    ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=3, sr_share=True, tpg_share=False)
+    dpsnr = abs(T._psnr(ts.last_sr, hr) - T._psnr(ref["sr"], hr))
+    mism = []
+    for i in range(3):
+        am = ts._static["p"][i].cpu().permute(1, 0, 2).argmax(-1)
+        mism.append(int((am != ref["priors"][i].argmax(-1)).sum()))
+    gn, gn_ref = ts.opt.grad_norm(sr).item(), float(ref["grad_norms"][0])
+    print(f"C5-shape bs32 x2: loss {loss.item():.6f} vs {ref['loss'].item():.6f}; |dPSNR| {dpsnr:.3e} dB; arg-max mismatches per stage "
+          f"{mism} / {am.numel()}; SR grad norm {gn:.4f} vs {gn_ref:.4f}")
+    assert dpsnr < 1e-3
+    assert mism[0] == 0
+    assert max(mism[1:]) <= am.numel() // 200
+    assert abs(loss.item() - ref["loss"].item()) < 5e-4 * ref["loss"].item()
+    assert abs(gn - gn_ref) < 2e-2 * gn_ref
+
+
+def test_c2_bs48_under_x2_holds_the_gates(x2):
+    """BASELINE configs[1] is an fp32 configuration: it is QUOTED under x3; this is the gate for running it two-term anyway"""
+    import test_fullsize_gpu as T
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    from tpgsr_amd.model import tsrn
+    T._threads()
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 1234, tps_hw=(16, 64))
+    net = tsrn.TSRN(STN=True, mask=True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    lr, hr = O.synthetic_batch(48, 1234)
+    ts = TSRNTrainStep(net)
+    loss = ts.step(lr.to(DEV), hr.to(DEV))
+    torch.cuda.synchronize()
+    p = O.as_params(sd)
+    opt = O.AdamState([p[k] for k in O.trainable_keys(p)])
+    ref = O.tsrn_train_step(p, opt, lr, hr)
+    gn = ts.opt.grad_norm(net).item()
+    dpsnr = abs(T._psnr(ts.last_sr, hr) - T._psnr(ref["sr"], hr))
+    print(f"C2 bs48 x2: loss {loss.item():.6f} vs {ref['loss'].item():.6f}; grad norm {gn:.4f} vs {float(ref['grad_norm']):.4f}; |dPSNR| {dpsnr:.3e} dB")
+    assert dpsnr < 1e-3
+    assert abs(loss.item() - ref["loss"].item()) < 2e-4 * ref["loss"].item()
+    assert abs(gn - float(ref["grad_norm"])) < 3e-3 * float(ref["grad_norm"])
+
+
+def test_trajectory_nostn_under_x2_vs_reference_losses(x2, golden_dir):
+    """4 steps of C2 without STN under x2 against the numbers the REFERENCE produced (tests/golden/train_c2_nostn.npz): the same
+    bounds the fp32-equivalent path is held to (tests/test_tsrn_gpu.py::test_train_trajectory_nostn)"""
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    from tpgsr_amd.model import tsrn
+    t = np.load(os.path.join(golden_dir, "train_c2_nostn.npz"))
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=False, mask=True), 201, tps_hw=(16, 64))
+    net = tsrn.TSRN(STN=False, mask=True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    ts = TSRNTrainStep(net)
+    lr, hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+    worst = 0.0
+    for step in range(4):
+        loss = ts.step(lr, hr)
+        gn = ts.opt.grad_norm(net)
+        rel = abs(loss.item() - t["loss"][step]) / t["loss"][step]
+        worst = max(worst, rel)
+        print(f"x2 step {step}: loss {loss.item():.6f} vs reference {t['loss'][step]:.6f} (rel {rel:.2e}); grad norm {gn.item():.4f} vs {t['gnorm'][step]:.4f}")
+        assert rel < 2e-4
+        assert abs(gn.item() - t["gnorm"][step]) < 2e-3 * t["gnorm"][step]
+    net.eval()
+    with torch.no_grad():
+        y = net(lr)
+    psnr = float(O.calculate_psnr(y.cpu(), hr.cpu()))
+    print(f"x2 after 4 steps: eval PSNR {psnr:.5f} vs reference {float(t['psnr_final']):.5f}")
+    assert abs(psnr - float(t["psnr_final"])) < 1e-2
+
+
+def test_sr_gradients_elementwise_under_x2():
+    """TSRN_TL without STN, every parameter gradient and the text-prior gradient against oracle autograd under x2.  Bound: 4e-3
+    relative L2 per tensor (fp32-equivalent path: 2e-3, tests/test_tsrn_gpu.py) -- the two-term split drops <= 3 * 2^-18 of a product,
+    which lands below the accumulation-order noise of an fp32 GEMM for these reductions (tests/test_policy_x2_gpu.py)."""
+    import test_tsrn_gpu as TT
+    net, sd = TT._build_tl(stn=False, seed=9)
+    lr, hr = O.synthetic_batch(3, 6)
+    g = torch.Generator().manual_seed(4)
+    prior = torch.softmax(torch.randn(3, 37, 1, 26, generator=g) * 2, 1)
+    p = O.as_params(sd)
+    pr = prior.clone().requires_grad_(True)
+    y = O.tsrn_forward(p, lr, pr, training=True, stn=False, text_prior=True)
+    (O.image_loss(y, hr).mean() * 100).backward()
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    net.train()
+    pd = prior.to(DEV).requires_grad_(True)
+    sr = net(lr.to(DEV), pd)
+    (ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.to(DEV)).mean() * 100).backward()
+    fwd_err = (sr.detach().cpu() - y.detach()).abs().max().item()
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    worst, bad = 0.0, []
+    for n, q in net.named_parameters():
+        ref = p[n].grad
+        rel = (q.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-3 * gmax)
+        worst = max(worst, rel)
+        if rel > 4e-3:
+            bad.append((n, rel))
+    relp = (pd.grad.cpu() - pr.grad).norm().item() / pr.grad.norm().item()
+    print(f"x2 element-wise: forward max err {fwd_err:.2e}; worst parameter-gradient rel err {worst:.2e}; prior-gradient rel err {relp:.2e}")
+    assert fwd_err < 2e-4
+    assert not bad, bad[:10]
+    assert relp < 4e-3

@@ -81,6 +81,13 @@ _SIGS = {
     "tpgsr_plan_add_edge": (ci, [vp, ci, ci]),
     "tpgsr_plan_run3": (ci, [vp, vp, vp, vp]),
     "tpgsr_stream_create": (vp, [C.POINTER(C.c_uint), ci]),
+    "tpgsr_plan_set_mode": (None, [ci, ci, C.c_ulonglong, ci]),
+    "tpgsr_plan_get_mode": (ci, []),
+    "tpgsr_plan_fuzz_point": (ci, [vp]),
+    "tpgsr_spin": (ci, [ci, ci, cf, ci, vp]),
+    "tpgsr_plan_set_stamp": (ci, [ci]),
+    "tpgsr_plan_stamp_epoch": (ci, [vp]),
+    "tpgsr_plan_read_stamps": (ci, [vp, C.POINTER(cf), C.POINTER(ci), ci]),
     "tpgsr_stream_destroy": (ci, [vp]),
     "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_mfma_probe": (ci, [vp, ci, ci, vp]),

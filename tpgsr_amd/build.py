@@ -24,36 +24,54 @@ def _hipcc():
     return "hipcc"
 
 
-def _digest():
+def _headers_digest():
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)) + ["../../include/tpgsr_hip.h"]:
         p = os.path.join(CSRC, f)
-        if os.path.isfile(p):
+        if os.path.isfile(p) and p.endswith(".h"):
+            h.update(f.encode())
             h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
 
+def _src_digest(src, hdr):
+    return hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr.encode()).hexdigest()
+
+
+def _digest():
+    hdr = _headers_digest()
+    return hashlib.sha256("".join(_src_digest(s, hdr) for s in SOURCES).encode()).hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Incremental: an object is recompiled when its source, any header under csrc/ (or include/tpgsr_hip.h) or the flags changed --
+    per-object stamps under build/, the library's stamp beside it."""
     stamp = LIB + ".stamp"
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    hdr = _headers_digest()
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        sd = _src_digest(src, hdr)
+        if not force and os.path.exists(obj) and os.path.exists(obj + ".stamp") and open(obj + ".stamp").read() == sd:
+            continue
         cmd = [_hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, obj, sd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, obj, sd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+        with open(obj + ".stamp", "w") as f:
+            f.write(sd)
         if verbose and out:
             print(out.decode())
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -40,12 +40,16 @@ extern "C" int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, int N,
                                                        int H, int W, int Co, int KS, float* __restrict__ dP,
                                                        float* __restrict__ dbp) {
-  __shared__ float sb[8];
-  if (threadIdx.x < 8) sb[threadIdx.x] = 0.f;
-  __syncthreads();
+  // bias-gradient partial of the block in a FIXED order: per channel a shuffle tree inside every wave, then the four waves'
+  // sums added by one thread.  (Until round 4 this was an LDS atomicAdd from every thread: the order of the float additions
+  // followed the waves' timing, so the partial -- and with it the tail bias gradient -- could differ in its last bits from run
+  // to run whenever something else shared the CUs.  DESIGN section 5, "the bit flip of round 3".)
+  __shared__ float sb[4][8];
   const int NP = KS * Co, half = KS / 2;
   long long total = (long long)N * H * W * NP;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float contrib = 0.f;
+  int cco = -1;
   if (i < total) {
     int np = (int)(i % NP);
     long long r = i / NP;
@@ -60,12 +64,21 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
       size_t o = (((size_t)n * Co + co) * H + h) * W + w;
       float y = out[o];
       v = dout[o] * (1.f - y * y);
-      if (kw == half && dbp) atomicAdd(&sb[co], v);
+      if (kw == half) {
+        contrib = v;
+        cco = co;
+      }
     }
     dP[i] = v;
   }
+  if (!dbp) return;                                    // (uniform)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < Co; ++c) {
+    const float s = wave_sum(cco == c ? contrib : 0.f);
+    if (lane == 0) sb[wave][c] = s;
+  }
   __syncthreads();
-  if (dbp && threadIdx.x < Co) dbp[(size_t)blockIdx.x * Co + threadIdx.x] = sb[threadIdx.x];
+  if (threadIdx.x < Co) dbp[(size_t)blockIdx.x * Co + threadIdx.x] = (sb[0][threadIdx.x] + sb[1][threadIdx.x]) + (sb[2][threadIdx.x] + sb[3][threadIdx.x]);
 }
 
 extern "C" int tpgsr_tail_bwd(const float* out_nchw, const float* dout_nchw, int N, int H, int W, int Co, int KS, float* dP,

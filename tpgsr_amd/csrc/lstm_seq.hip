@@ -23,8 +23,9 @@
 //            the forward pass, where an all-gather of dG would move 192 KB per workgroup and step.
 //
 // Both kernels need their 64 workgroups to become resident together at some point (they are: 64 workgroups on 256 CUs; other
-// kernels running next to them only delay that); a poll that sees nothing for ~seconds sets sync[2] and falls through instead of
-// hanging the GPU.
+// kernels running next to them only delay that); a poll that sees nothing for ~1 s sets sync[2], gives up instead of hanging the GPU
+// and POISONS its outputs with NaN from then on (see LS_SPINS below): a timed-out hand-off ends in a NaN loss, never in a silently
+// wrong one.
 #include "common.h"
 #include <mutex>
 
@@ -56,17 +57,27 @@ __device__ __forceinline__ floatx16 ls_mfma6(const ls_bf16x8 (&a)[3], const ls_b
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
+// A hand-off that never completes must not pass silently: a workgroup that gives up sets sync[2], every workgroup
+// that sees the flag stops waiting as well, and everything such a workgroup produces from then on is NaN -- the loss of the step goes
+// NaN, which no training loop overlooks.  Budgets: ~1 s per wait (the 64 workgroups need to be co-resident at some point: other
+// kernels only delay that), a handful of polls once the flag is up.
+#define LS_SPINS (1 << 20)
+#define LS_TRIES (1 << 18)
+
 // one lane: wait until `target` workgroups have arrived on *cnt (relaxed agent-scope polls; a sleeping poller costs the memory
-// system next to nothing).  ~0.1 s without progress: set the timeout flag and give up rather than hang the GPU.
-__device__ __forceinline__ void ls_wait(unsigned* cnt, unsigned target, unsigned* flag) {
+// system next to nothing).  Returns true when it gave up.
+__device__ __forceinline__ bool ls_wait(unsigned* cnt, unsigned target, unsigned* flag) {
   int spins = 0;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 17)) {
+    ++spins;
+    if ((spins & 255) == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+    if (spins > LS_SPINS) {
       __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
+      return true;
     }
   }
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -88,9 +99,11 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G
   float* cst = reinterpret_cast<float*>(lsm + 64 * 1024);
   unsigned short* hst = reinterpret_cast<unsigned short*>(lsm + 66 * 1024);
   float* bsm = reinterpret_cast<float*>(lsm + 69 * 1024);
+  __shared__ int tmo_s;       // a hand-off of this workgroup timed out: everything it produces from then on is NaN
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.x / LS_NW, u = blockIdx.x % LS_NW, u0 = u * 8;
   const float* W = whhT + (size_t)d * Hh * G4;
+  if (tid == 0) tmo_s = 0;
   // W fragments: B operand of k-block kb: lane l holds column c = l & 31 (gate c >> 3, unit u0 + (c & 7)), k = 16 kb + 8 (l >> 5) + j
   for (int idx = tid; idx < 16 * 64; idx += 256) {
     const int kb = idx >> 6, l = idx & 63, c = l & 31;
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G
       }
     }
     if (s > 0) {
-      if (tid == 0) ls_wait(sync + d, (unsigned)s * LS_NW, sync + 2);
+      if (tid == 0 && !tmo_s && ls_wait(sync + d, (unsigned)s * LS_NW, sync + 2)) tmo_s = 1;
       __syncthreads();
       // gh partial of this wave: row block rb, k-blocks 8 kh .. 8 kh + 7 of the h everybody published in step s - 1
       const unsigned hp = (unsigned)((((s - 1) & 1) * par_elems + d * dir_elems) * 2);
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G
         }
         const float ig = sigmoid_f(p[0]), fg = sigmoid_f(p[1]), gg = tanh_f(p[2]), og = sigmoid_f(p[3]);
         const float c = fg * cst[item] + ig * gg;
-        const float h = og * tanh_f(c);
+        const float h = tmo_s ? __builtin_nanf("") : og * tanh_f(c);
         cst[item] = c;
         unsigned short hv[3];
         ls_split3(h, hv);
@@ -265,6 +278,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
   const __amdgpu_buffer_rsrc_t rs = ls_rsrc(hg, 2 * (size_t)par_bytes);
   const int ul = tid & 7;
   const bool row_live = rb * 32 + (lane & 31) < N;   // rows past the batch are never published: their tags are not checked
+  bool tmo = false;                                  // (wave-uniform) a hand-off of this wave timed out
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
     float pre[2][4];
@@ -300,14 +314,18 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
         const bool ok = !row_live || (bad >> 16) == 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++tries > (1 << 14)) {          // tens of ms without progress: flag it and go on with what is there rather than hang the GPU
+        ++tries;
+        // ~1 s without progress (or somebody else gave up): flag it, stop waiting for good, and poison what this wave computes
+        if (tmo || tries > LS_TRIES || ((tries & 255) == 0 && __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           if (lane == 0) __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tmo = true;
           break;
         }
       }
       floatx16 acc;
+      const float acc0 = tmo ? __builtin_nanf("") : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[r] = acc0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         ls_u32x4 av[3];
@@ -411,9 +429,11 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
   unsigned short* afr = reinterpret_cast<unsigned short*>(lsb + 48 * 1024 + 256 * LSB_PLD * 4);
   float* rsum = reinterpret_cast<float*>(lsb + 48 * 1024 + 256 * LSB_PLD * 4 + 12 * 1024);
   float* dcc = reinterpret_cast<float*>(lsb + 48 * 1024 + 256 * LSB_PLD * 4 + 16 * 1024);
+  __shared__ int tmo_s;       // a hand-off of this workgroup timed out: everything it produces from then on is NaN
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.x / LS_NW, u = blockIdx.x % LS_NW, u0 = u * 8;
   const float* W = d == 0 ? w0 : w1;
+  if (tid == 0) tmo_s = 0;
   // B operand of (n-block nb, k-block kb): lane l holds unit nb 32 + (l & 31), k = 16 kb + 8 (l >> 5) + j <-> gate column (k >> 3) Hh + u0 + (k & 7)
   for (int idx = tid; idx < 8 * 2 * 64; idx += 256) {
     const int nb = idx >> 7, kb = (idx >> 6) & 1, l = idx & 63;
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
       }
     }
     if (s > 0) {
-      if (tid == 0) ls_wait(sync + d, (unsigned)s * LS_NW, sync + 2);
+      if (tid == 0 && !tmo_s && ls_wait(sync + d, (unsigned)s * LS_NW, sync + 2)) tmo_s = 1;
       __syncthreads();
       // gather: my region [32 producers][8 units][64 rows]; thread = (producer group g of 16, unit gu, row quad rq)
       const int g = tid >> 7, gu = (tid >> 4) & 7, rq = tid & 15;
@@ -490,6 +510,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
         if (s > 0) {
           dhh += rsum[ul * 64 + n] + rsum[(8 + ul) * 64 + n];
           dc = dcc[item];
+          if (tmo_s) dhh = __builtin_nanf("");
         }
         const float tc = tanh_f(cc[it]);
         const float dog = dhh * tc * og * (1.f - og);
@@ -608,6 +629,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwdg_kernel(float* __restrict__ 
   const __amdgpu_buffer_rsrc_t rs_px = ls_rsrc(pg, 2 * par_f * 8);
   const unsigned ep = sync[4 + d] & 0xffffffu;
   const int ul = tid & 7;
+  bool tmo = false;                                  // (wave-uniform) a hand-off of this wave timed out
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
     const int tp = d == 0 ? t - 1 : t + 1;           // previous state in this direction's forward order
@@ -655,11 +677,14 @@ __global__ __launch_bounds__(256) void lstm_seq_bwdg_kernel(float* __restrict__ 
         }
         if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++tries > (1 << 14)) {
+        ++tries;
+        if (tmo || tries > LS_TRIES || ((tries & 255) == 0 && __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           if (lane == 0) __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tmo = true;
           break;
         }
       }
+      if (tmo) sum = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
       if (live) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) {     // producer order: deterministic

@@ -97,11 +97,67 @@ struct Op {
 struct Plan {
   std::vector<Op> ops;
   std::vector<std::unique_ptr<char[]>> blobs;
+  std::vector<hipEvent_t> stamps;   // stamp mode: one timing event per op (recorded behind it on its stream)
+  bool stamped = false;             // the last run recorded them
   ~Plan() {
     for (auto& o : ops)
       if (o.ev) (void)hipEventDestroy(o.ev);
+    for (auto e : stamps)
+      if (e) (void)hipEventDestroy(e);
   }
 };
+
+// ---- execution modes of tpgsr_plan_run3 (process-wide; tests and diagnostics, see tpgsr_plan_set_mode in the header) ----
+struct Mode {
+  int serial = 0;            // every launch on the caller's stream in recording order, stream edges dropped
+  int fuzz_max_us = 0;       // > 0: a spin kernel of random length (0 .. fuzz_max_us) around every stream edge
+  int noise_blocks = 0;      // > 0: ... and a co-running busy kernel of that many workgroups on a stream of its own
+  unsigned long long rng = 0x9E3779B97F4A7C15ull;
+  int stamp = 0;
+  hipStream_t noise_stream = nullptr;
+  hipEvent_t epoch = nullptr;
+} g_mode;
+
+inline unsigned long long rng_next() {   // xorshift64*
+  unsigned long long x = g_mode.rng;
+  x ^= x >> 12;
+  x ^= x << 25;
+  x ^= x >> 27;
+  g_mode.rng = x;
+  return x * 0x2545F4914F6CDD1Dull;
+}
+
+// busy-wait for `ticks` of the 100 MHz wall clock; `work` != 0: half of the waves keep the vector ALU busy meanwhile instead of sleeping
+__global__ void spin_kernel(long long ticks, int work, float* sink) {
+  const long long t0 = wall_clock64();
+  float a = (float)threadIdx.x, b = 1.0001f;
+  const bool busy = work && ((threadIdx.x >> 6) & 1);
+  while (wall_clock64() - t0 < ticks) {
+    if (busy) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) a = __builtin_fmaf(a, b, 0.5f);
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (sink && a == 12345.678f) *sink = a;   // (keeps the arithmetic alive)
+}
+
+inline void spin_on(hipStream_t st, int blocks, int threads, float us, int work) {
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), 0, st, (long long)(us * 100.f), work, (float*)nullptr);
+}
+
+// fuzz: delay stream `st` by a random time with probability 1/2
+inline void fuzz_delay(hipStream_t st) {
+  const unsigned long long r = rng_next();
+  if (g_mode.fuzz_max_us > 0 && (r & 1)) spin_on(st, 1, 64, (float)((r >> 8) % (unsigned)(g_mode.fuzz_max_us + 1)), 0);
+}
+inline void fuzz_noise() {
+  if (g_mode.noise_blocks <= 0) return;
+  if (!g_mode.noise_stream && hipStreamCreateWithFlags(&g_mode.noise_stream, hipStreamNonBlocking) != hipSuccess) return;
+  const unsigned long long r = rng_next();
+  if (r & 3) spin_on(g_mode.noise_stream, g_mode.noise_blocks, 256, (float)((r >> 8) % (unsigned)(g_mode.fuzz_max_us > 0 ? g_mode.fuzz_max_us + 1 : 21)), 1);
+}
 
 }  // namespace
 
@@ -198,17 +254,35 @@ extern "C" int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream,
     return -1;
   }
   hipStream_t s[3] = {(hipStream_t)main_stream, (hipStream_t)side_stream, (hipStream_t)leaf_stream};
+  const bool serial = g_mode.serial != 0;
+  if (serial) s[1] = s[2] = s[0];
+  const bool fuzz = !serial && (g_mode.fuzz_max_us > 0 || g_mode.noise_blocks > 0);
   const int n = (int)p->ops.size();
+  const bool stamp = g_mode.stamp != 0;
+  if (stamp && (int)p->stamps.size() != n) {
+    p->stamps.resize(n, nullptr);
+    for (int i = 0; i < n; ++i)
+      if (p->ops[i].kind == OP_LAUNCH && hipEventCreate(&p->stamps[i]) != hipSuccess) {
+        tpgsr_set_error("tpgsr_plan_run: hipEventCreate (stamp mode) failed");
+        return -2;
+      }
+  }
+  p->stamped = stamp;
   for (int i = 0; i < n; ++i) {
     Op& o = p->ops[i];
     if (o.kind == OP_LAUNCH) {
-      if (o.sid && (!s[o.sid] || s[o.sid] == s[0])) {
+      if (!serial && o.sid && (!s[o.sid] || s[o.sid] == s[0])) {
         tpgsr_set_error("tpgsr_plan_run: the plan has launches on stream %d but no distinct stream was given for it", o.sid);
         return -1;
       }
       int rc = o.fn(o.args, s[o.sid]);
       if (rc) return rc;   // the entry point has set the message
+      if (stamp && hipEventRecord(p->stamps[i], s[o.sid]) != hipSuccess) {
+        tpgsr_set_error("tpgsr_plan_run: hipEventRecord (stamp mode) failed");
+        return -2;
+      }
     } else {
+      if (serial) continue;   // one stream: recording order is execution order
       const int src = o.kind == OP_FORK ? 0 : o.kind == OP_JOIN ? 1 : o.sid;
       const int dst = o.kind == OP_FORK ? 1 : o.kind == OP_JOIN ? 0 : o.nargs;
       if ((src && !s[src]) || (dst && !s[dst]) || s[src] == s[dst]) {      // (the caller's stream may be the null stream)
@@ -219,10 +293,17 @@ extern "C" int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream,
         tpgsr_set_error("tpgsr_plan_run: hipEventCreateWithFlags failed");
         return -2;
       }
+      if (fuzz) {             // a missing edge only shows when the streams drift: push a random one of them back, on either side of the edge
+        const int k = (int)(rng_next() % 3);
+        fuzz_delay(s[k] ? s[k] : s[0]);
+        fuzz_delay(s[src]);
+        fuzz_noise();
+      }
       if (hipEventRecord(o.ev, s[src]) != hipSuccess || hipStreamWaitEvent(s[dst], o.ev, 0) != hipSuccess) {
         tpgsr_set_error("tpgsr_plan_run: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
         return -2;
       }
+      if (fuzz) fuzz_delay(s[dst]);
     }
   }
   return 0;
@@ -252,4 +333,77 @@ extern "C" int tpgsr_stream_destroy(void* stream) {
     return -2;
   }
   return 0;
+}
+
+// ---- execution modes / diagnostics ------------------------------------------------------------------------------------
+extern "C" void tpgsr_plan_set_mode(int serial, int fuzz_max_us, unsigned long long seed, int noise_blocks) {
+  g_mode.serial = serial ? 1 : 0;
+  g_mode.fuzz_max_us = fuzz_max_us > 0 ? fuzz_max_us : 0;
+  g_mode.noise_blocks = noise_blocks > 0 ? noise_blocks : 0;
+  g_mode.rng = seed ? seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull : 0x9E3779B97F4A7C15ull;
+  if (!g_mode.rng) g_mode.rng = 1;
+}
+
+extern "C" int tpgsr_plan_get_mode(void) {
+  return (g_mode.serial ? 1 : 0) | (g_mode.fuzz_max_us > 0 ? 2 : 0) | (g_mode.noise_blocks > 0 ? 4 : 0) | (g_mode.stamp ? 8 : 0);
+}
+
+/* the fuzz perturbation for stream edges made OUTSIDE a plan (a train step's own wait_stream calls): delays `stream` like an edge of a plan would */
+extern "C" int tpgsr_plan_fuzz_point(void* stream) {
+  if (g_mode.serial || (g_mode.fuzz_max_us <= 0 && g_mode.noise_blocks <= 0)) return 0;
+  fuzz_delay((hipStream_t)stream);
+  fuzz_noise();
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int tpgsr_spin(int blocks, int threads, float us, int work, void* stream) {
+  if (blocks < 1 || threads < 64 || threads > 1024 || (threads & 63) || us < 0.f || us > 1e6f) {
+    tpgsr_set_error("tpgsr_spin: bad arguments (blocks %d, threads %d, us %g)", blocks, threads, (double)us);
+    return -1;
+  }
+  spin_on((hipStream_t)stream, blocks, threads, us, work);
+  if (hipGetLastError() != hipSuccess) {
+    tpgsr_set_error("tpgsr_spin: launch failed");
+    return -2;
+  }
+  return 0;
+}
+
+/* stamp mode: every launch of a plan is followed by a timing event on its stream; tpgsr_plan_stamp_epoch records the common origin */
+extern "C" int tpgsr_plan_set_stamp(int on) {
+  g_mode.stamp = on ? 1 : 0;
+  return 0;
+}
+
+extern "C" int tpgsr_plan_stamp_epoch(void* stream) {
+  if (!g_mode.epoch && hipEventCreate(&g_mode.epoch) != hipSuccess) {
+    tpgsr_set_error("tpgsr_plan_stamp_epoch: hipEventCreate failed");
+    return -2;
+  }
+  if (hipEventRecord(g_mode.epoch, (hipStream_t)stream) != hipSuccess) {
+    tpgsr_set_error("tpgsr_plan_stamp_epoch: hipEventRecord failed");
+    return -2;
+  }
+  return 0;
+}
+
+/* after a device synchronisation: ms_out[i] = time from the epoch to the end of op i of the plan's last run (-1 for stream edges);
+ * sid_out[i] = its stream id; returns the number of ops written (<= cap), or a negative error */
+extern "C" int tpgsr_plan_read_stamps(void* plan, float* ms_out, int* sid_out, int cap) {
+  Plan* p = static_cast<Plan*>(plan);
+  if (!p || !ms_out || !p->stamped || !g_mode.epoch) {
+    tpgsr_set_error("tpgsr_plan_read_stamps: the plan's last run was not stamped (tpgsr_plan_set_stamp(1), tpgsr_plan_stamp_epoch first)");
+    return -1;
+  }
+  const int n = (int)p->ops.size() < cap ? (int)p->ops.size() : cap;
+  for (int i = 0; i < n; ++i) {
+    ms_out[i] = -1.f;
+    if (sid_out) sid_out[i] = p->ops[i].sid;
+    if (p->ops[i].kind != OP_LAUNCH) continue;
+    if (hipEventElapsedTime(&ms_out[i], g_mode.epoch, p->stamps[i]) != hipSuccess) {
+      tpgsr_set_error("tpgsr_plan_read_stamps: hipEventElapsedTime failed at op %d (synchronise the device first)", i);
+      return -2;
+    }
+  }
+  return n;
 }

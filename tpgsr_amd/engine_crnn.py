@@ -117,7 +117,10 @@ class LstmLayer:
             if not hasattr(self, "_seq"):
                 self._seq = {}
             gran = K.LSTM_GRANULE and T <= 31
-            key = (K.current_stream().cuda_stream, gran)       # one exchange buffer per stream (the teacher runs on its own)
+            # one exchange buffer per stream (the teacher runs on its own) AND batch size: rows >= N of a granule buffer are never
+            # rewritten, so a buffer shared across batch sizes could hand a larger batch granules whose (epoch, step) tag happens to
+            # match again after the 11-bit epoch has wrapped
+            key = (K.current_stream().cuda_stream, gran, N)
             if key not in self._seq:
                 self._seq[key] = K.lstm_seq_granule_buffers(self.eng.device) if gran else K.lstm_seq_buffers(self.eng.device)
             hx, sync = self._seq[key]
@@ -157,7 +160,7 @@ class LstmLayer:
             if not hasattr(self, "_seqb"):
                 self._seqb = {}
             gran = K.LSTM_GRANULE_BWD and T <= 255
-            key = (K.current_stream().cuda_stream, gran)
+            key = (K.current_stream().cuda_stream, gran, N)
             if key not in self._seqb:
                 self._seqb[key] = K.lstm_seq_bwd_granule_buffers(self.eng.device) if gran else K.lstm_seq_bwd_buffers(self.eng.device)
             px, sync = self._seqb[key]

@@ -18,11 +18,23 @@ from ..optim import FusedAdam
 _NBLK = 128
 
 
+def _warn_hw_queues(collective: bool):
+    """The step's three streams plus RCCL's are more than the four hardware queues HIP multiplexes streams onto by default: two of them
+    share a queue and an event wait of one blocks the other (+0.9 ms per C3 step measured).  The variable is read
+    when the HIP runtime initialises, so a library cannot set it any more -- it can only say so."""
+    if collective and not K.DRYRUN and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+        import warnings
+        warnings.warn("tpgsr_amd: a gradient exchange is on but GPU_MAX_HW_QUEUES is %s (< 8): the train step's streams and RCCL's will "
+                      "share hardware queues (~0.9 ms per step on MI355X).  Export GPU_MAX_HW_QUEUES=8 before the process starts "
+                      "(INTEGRATION.md section 4)." % os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)"), RuntimeWarning, stacklevel=3)
+
+
 class TSRNTrainStep:
     def __init__(self, model, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
                  process_group=None, world_size: int = 1, force_collectives: bool = False):
         self.model = model
         self.collective = world_size > 1 or bool(force_collectives)   # force: drive RCCL at world size 1 too (tests)
+        _warn_hw_queues(self.collective)
         self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
         self.pool = ArenaPool([model])
         self.opt = FusedAdam([model], lr=lr, betas=betas, clip_modules=[model], max_norm=max_norm, pool=self.pool)
@@ -169,6 +181,7 @@ class TPGSRTrainStep:
                  loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1,
                  force_collectives=False):
         self.collective = world_size > 1 or bool(force_collectives)   # force: drive RCCL at world size 1 too (tests)
+        _warn_hw_queues(self.collective)
         self.sr = list(sr_models) if isinstance(sr_models, (list, tuple)) else [sr_models]
         self.stu = list(students) if isinstance(students, (list, tuple)) else [students]
         self.teacher = teacher
@@ -235,7 +248,7 @@ class TPGSRTrainStep:
         # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
         # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
         main, aux = K.current_stream(), K.aux_stream(lr_img.device)
-        aux.wait_stream(main)
+        K.order(aux, main)
         with K.stream_ctx(aux):
             K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
             t_logits = self.teacher._engine().forward(st["gray_hr"], False)
@@ -250,19 +263,19 @@ class TPGSRTrainStep:
             stu = self.stu[0 if self.tpg_share else i]
             srm = self.sr[0 if self.sr_share else i]
             if pre_side:
-                side.wait_stream(main)
+                K.order(side, main)
                 with K.stream_ctx(side):
                     srm._engine().forward_pre(lr_img, True, slot=i, defer_join=self._defer_join)
             K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
             logits = stu._engine().forward(st["gray"][i], True, slot=i)
             self._mark(f"student{i} fwd")
             if i == 0:
-                main.wait_stream(aux)           # the teacher's distribution q is needed from here on
+                K.order(main, aux)              # the teacher's distribution q is needed from here on
                 self._mark("wait teacher")
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
             K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
             if pre_side:
-                main.wait_stream(side)
+                K.order(main, side)
                 self._mark(f"wait SR prologue{i}")
             sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join, pre_done=pre_side)
             K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
@@ -328,12 +341,15 @@ class TPGSRTrainStep:
         """launch bucket b's all-reduce FROM the weight-gradient stream: its tail is ordered after the weight gradients and slab reduces
         recorded so far (and the leaf stream); it is made to wait for this stream's BatchNorm / PReLU-slope gradients; this stream does
         not wait for anything"""
-        if self._defer_join and not K.DRYRUN:
-            side = K.side_stream(device)
-            side.wait_stream(K.current_stream())
-            with K.stream_ctx(side):
-                self._exchanger().launch(b)
-        else:
+        if K.DRYRUN:
+            self._exchanger().launch(b)
+            return
+        # ALWAYS from the weight-gradient stream, also with TPGSR_DEFER_JOIN=0: the text-prior generator's first backward plan never
+        # joins it (K.continue_in), so a launch from this stream could read gradients its weight-gradient / slab-reduce launches are
+        # still writing (ADVICE round 3)
+        side = K.side_stream(device)
+        K.order(side, K.current_stream())
+        with K.stream_ctx(side):
             self._exchanger().launch(b)
 
     def _exchange(self):
@@ -343,7 +359,7 @@ class TPGSRTrainStep:
 
     def _join_side(self, device):
         if self._defer_join and not K.DRYRUN:
-            K.current_stream().wait_stream(K.side_stream(device))
+            K.order(K.current_stream(), K.side_stream(device))
 
     def _phase_b(self):
         self.opt.step()

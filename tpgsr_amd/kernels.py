@@ -124,6 +124,32 @@ def _stream():
 
 _SIDE = {}
 
+# Schedule modes (tests / diagnostics; tpgsr_plan_set_mode in include/tpgsr_hip.h): SERIAL folds the side / leaf / teacher streams onto
+# the caller's stream -- the whole train step then runs in recording order on ONE stream, the reference the three-stream schedule must
+# equal bit for bit; FUZZ delays random streams around every stream edge.
+SERIAL = False
+FUZZ = False
+
+
+def set_schedule(serial: bool = False, fuzz_us: int = 0, seed: int = 0, noise_blocks: int = 0):
+    """serial: one stream, recording order; fuzz_us > 0: spin kernels of 0..fuzz_us microseconds around every stream edge (seeded);
+    noise_blocks > 0: plus a co-running busy kernel of that many workgroups.  set_schedule() restores the default schedule."""
+    global SERIAL, FUZZ
+    SERIAL, FUZZ = bool(serial), bool(fuzz_us > 0 or noise_blocks > 0) and not serial
+    _lib.load().tpgsr_plan_set_mode(int(SERIAL), int(fuzz_us), int(seed), int(noise_blocks))
+
+
+def order(dst, src):
+    """stream `dst` waits for everything enqueued on `src` so far -- every stream edge a train step makes outside a recorded plan goes
+    through here, so the schedule modes see it"""
+    if SERIAL or DRYRUN or dst is src or getattr(dst, "cuda_stream", 0) == getattr(src, "cuda_stream", 1):
+        return
+    if FUZZ:
+        check(_lib.load().tpgsr_plan_fuzz_point(src.cuda_stream), "tpgsr_plan_fuzz_point")
+    dst.wait_stream(src)
+    if FUZZ:
+        check(_lib.load().tpgsr_plan_fuzz_point(dst.cuda_stream), "tpgsr_plan_fuzz_point")
+
 
 def parse_cu_mask(spec: str):
     """'0xffff...': hex bit mask (bit i = CU i); 'N' or 'N/S': N CUs, every S-th (default: the first N)"""
@@ -145,6 +171,8 @@ def parse_cu_mask(spec: str):
 def side_stream(device=None) -> "torch.cuda.Stream":
     """The per-device second HIP stream weight-gradient launches are recorded on (see Plan.side).
     TPGSR_SIDE_CUMASK confines it to a subset of the compute units (parse_cu_mask)."""
+    if SERIAL:
+        return torch.cuda.current_stream(device)
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _SIDE.get(idx)
     if st is None:
@@ -172,6 +200,8 @@ def aux_stream(device=None) -> "torch.cuda.Stream":
     text-prior path runs on it next to the student's forward pass)."""
     if DRYRUN:
         return _DummyStream()
+    if SERIAL:
+        return torch.cuda.current_stream(device)
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _AUX.get(idx)
     if st is None:
@@ -312,6 +342,8 @@ class Plan:
         streams = (main.cuda_stream, side.cuda_stream, leaf.cuda_stream)
         for name, fn, args, sid in self.ops:
             if fn is None:
+                if SERIAL:
+                    continue
                 if name == "fork":
                     side.wait_stream(main)
                 elif name == "join":
