@@ -132,6 +132,14 @@ def conv_family(nets):
                     elif name == "tpgsr_conv_wgrad":
                         a = args[0]._obj.c
                         kind, terms = "wgrad", a.terms
+                    elif name == "tpgsr_gru_wgrad":
+                        # every weight gradient of one GruBlock in one launch (csrc/gru_wgrad.hip): dWc [Cin x 192] + 2 x dWhh [32 x 96],
+                        # contracted over the pixels; algorithmic bytes = loader(x) + h + dgi + dghn once
+                        a = args[0]._obj.c
+                        M = a.N * a.H * a.W
+                        items.append(dict(kind="wgrad", terms=a.terms, shape=(a.N, a.H, a.W, a.Cin, 192, 1, 1), label="GruBlock, all weights",
+                                          flops=2.0 * M * (a.Cin * 192 + 2 * 32 * 96), bytes=4.0 * M * (a.Cin + 64 + 192 + 64), fn=fn, args=args))
+                        continue
                     elif name in ("tpgsr_wgrad_reduce_program", "tpgsr_wgrad_reduce"):
                         items.append(dict(kind="wgrad", terms=None, shape=("slab reduce",), flops=0.0, bytes=0.0, fn=fn, args=args))
                         continue
@@ -153,10 +161,10 @@ def conv_roofline(nets, reps=5):
     items = conv_family(nets)
     groups = {}
     for it in items:
-        groups.setdefault((it["kind"], it["terms"], it["shape"]), []).append(it)
+        groups.setdefault((it["kind"], it["terms"], it["shape"], it.get("label", "")), []).append(it)
     s = torch.cuda.current_stream().cuda_stream
     rows = []
-    for (kind, terms, shape), its in groups.items():
+    for (kind, terms, shape, label), its in groups.items():
         for it in its:      # warm
             it["fn"](*it["args"], s)
         torch.cuda.synchronize()
@@ -170,7 +178,7 @@ def conv_roofline(nets, reps=5):
         ms = e0.elapsed_time(e1) / reps
         flops = sum(it["flops"] for it in its)
         peak = PEAK_BY_TERMS.get(terms)
-        rows.append(dict(kind=kind, terms=terms, shape=shape, launches=len(its), ms=ms, flops=flops, bytes=sum(it["bytes"] for it in its),
+        rows.append(dict(kind=kind, terms=terms, shape=shape, label=label, launches=len(its), ms=ms, flops=flops, bytes=sum(it["bytes"] for it in its),
                          ms_at_peak=(flops / (peak * 1e12) * 1e3) if peak else 0.0))
 
     def agg(sel):
@@ -190,7 +198,7 @@ def conv_roofline(nets, reps=5):
             table.append(dict(kind="wgrad slab reduce", launches=x["launches"], us_per_launch=round(1e3 * x["ms"] / x["launches"], 1)))
             continue
         N_, H_, W_, Ci, Co, KH, KW = x["shape"]
-        table.append(dict(kind=x["kind"], shape=f"N{N_} {H_}x{W_} {Ci}->{Co} {KH}x{KW}", terms=x["terms"], launches=x["launches"],
+        table.append(dict(kind=x["kind"], shape=f"N{N_} {H_}x{W_} {Ci}->{Co} {KH}x{KW}" + (f" ({x['label']})" if x["label"] else ""), terms=x["terms"], launches=x["launches"],
                           us_per_launch=round(1e3 * x["ms"] / x["launches"], 1), tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1),
                           frac=round(x["ms_at_peak"] / x["ms"], 3)))
     return dict(total=total, by_kind=by_kind, by_terms=by_terms, table=table)

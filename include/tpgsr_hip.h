@@ -341,6 +341,32 @@ int tpgsr_bigru_fwd(const float* gi, const float* w_hh /* [2][96][32] */, const 
  * as plain GEMMs / column sums (tpgsr_conv_wgrad against the input resp. the one-step-shifted states). */
 int tpgsr_bigru_bwd(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
                     const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dgh, void* stream);
+/* tpgsr_bigru_bwd with the hidden-side gradient written compactly: dghn [P][64] = dn_pre * r of both directions (column = dir*32 + j) --
+ * the r and z planes of dgh equal dgi's, and tpgsr_gru_wgrad reads them there. */
+int tpgsr_bigru_bwd2(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
+                     const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dghn, void* stream);
+/* ALL weight gradients of one GruBlock in one launch (csrc/gru_wgrad.hip; model/tsrn.py:491-508, the backward pass of GruBlock.forward):
+ *   c      the A side of the composed 1x1 projection gi = loader(x) Wc^T + bc, as tpgsr_conv_args (in / in_ld / in_coff, optional
+ *          in_scale + in_shift, in2 (residual add) or in_b (concatenated [N][W][Cb] strip, cin_a); N, H, W, Cin = 64 | 96, Cout = 192,
+ *          1x1, OH = H, OW = W; terms = 1 | 2 | 3: split-bf16 matrix-core path only)
+ *   dgi [P][192], dghn [P][64] from tpgsr_bigru_bwd2; h [P][64] the BiGRU's output (h_prev = h one step against the scan direction)
+ *   zsplits = tpgsr_gru_wgrad_splits(P) = Z; slabs for tpgsr_wgrad_reduce(_program):
+ *   partC [Z][Cin][192], dbC [Z][192]   -> dWc, dbc (composed operand; chain rule: tpgsr_compose_bwd_program)
+ *   partH [2][Z][32][96], dbH [2][Z][96] -> weight_hh_l0(_reverse) [96][32] (layout 0), bias_hh_l0(_reverse) */
+typedef struct tpgsr_gru_wgrad_args {
+  tpgsr_conv_args c;
+  const float* dgi;
+  const float* dghn;
+  const float* h;
+  float* partC;
+  float* dbC;
+  float* partH;
+  float* dbH;
+  int axis;
+  int zsplits;
+} tpgsr_gru_wgrad_args;
+int tpgsr_gru_wgrad_splits(long long P);
+int tpgsr_gru_wgrad(const tpgsr_gru_wgrad_args* w, void* stream);
 /* look-ahead, in time steps, of the operand prefetch rings of tpgsr_bigru_fwd / _bwd: 4, 8 (default) or 12 (TPGSR_GRU_PF); speed only */
 void tpgsr_gru_set_prefetch(int steps);
 
@@ -582,10 +608,10 @@ int tpgsr_plan_fuzz_point(void* stream);
 int tpgsr_spin(int blocks, int threads, float us, int work, void* stream);
 /* Stamp mode (un-profiled per-op time line): with tpgsr_plan_set_stamp(1) every launch of a plan is followed by a timing event on its
  * stream; tpgsr_plan_stamp_epoch(stream) records the common origin; after a device synchronisation tpgsr_plan_read_stamps fills
- * ms_out[i] = origin -> end of op i of the plan's last run (-1 for stream edges) and sid_out[i] = its stream (0 main, 1 side, 2 leaf). */
+ * ms_out[i] = origin -> end of op i of the plan's last run (-1 for stream edges) and stream_out[i] = the HIP stream it ran on. */
 int tpgsr_plan_set_stamp(int on);
 int tpgsr_plan_stamp_epoch(void* stream);
-int tpgsr_plan_read_stamps(void* plan, float* ms_out, int* sid_out, int cap);
+int tpgsr_plan_read_stamps(void* plan, float* ms_out, long long* stream_out, int cap);
 /* A HIP stream for the side-stream role, optionally confined to the compute units whose bits are set in cu_mask
  * (n_words 32-bit words, bit i of word w = CU 32*w + i; NULL / 0 = all CUs).  Returns NULL on failure. */
 void* tpgsr_stream_create(const unsigned int* cu_mask, int n_words);

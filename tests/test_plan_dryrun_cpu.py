@@ -88,6 +88,22 @@ p2.bind(torch.device("cpu"))
 out["repointed"] = sr5._engine().arena.flat.data_ptr() == p2.flat.data_ptr()
 p1.bind(torch.device("cpu"))
 out["first_pool_rebuilt"] = sr5._engine().arena.flat.data_ptr() == p1.flat.data_ptr() + 4 * p1.ranges[id(sr5)][0]
+# C5 with the gradient exchange on: every text-prior generator has its own early bucket (conv3 .. end, launched between the two plans
+# of ITS backward pass) and a rest bucket (after its second plan); the shared SR network's bucket leaves after the last SR backward
+# (stage 0).  The exchanger is inactive here (no process group): its launch calls are recorded.
+sr6 = tsrn.TSRN_TL(STN=True, mask=True).train()
+stus6 = [crnn.CRNN(32, 1, 37, 256).train() for _ in range(3)]
+ts6 = TPGSRTrainStep([sr6], stus6, teacher, stu_iter=3, sr_share=True, world_size=1, force_collectives=True)
+ts6.pool.bind(lr.device)
+ts6._buffers(lr)
+ex = ts6._exchanger()
+order = []
+ex.launch = lambda b: order.append(b)
+ts6.step(lr, hr)
+out["c5_bucket_order"] = order
+out["c5_bounds"] = ex.bounds
+out["c5_ranges"] = [list(ts6.pool.ranges[id(m)]) for m in ts6.pool.modules]
+out["c5_cut"] = stus6[0]._engine().early_final_offset()
 print("RESULT " + json.dumps(out))
 '''
 
@@ -122,6 +138,18 @@ def test_record_all_plans_without_gpu():
     assert res["live_after_bwd"] == 0
     assert res["live_after_dropped_graphs"] == 0
     assert res["repointed"] and res["first_pool_rebuilt"]
+    # C5's buckets: [SR | stu0 early, stu0 rest | stu1 early, stu1 rest | stu2 early, stu2 rest]; the cascade's backward pass runs stage 2,
+    # 1, 0, so stage 2's and stage 1's generators leave first, the shared SR network after its last backward pass (stage 0), then stage
+    # 0's early bucket; stage 0's rest (bucket 2) is what finish() still has to launch
+    assert res["c5_bucket_order"] == [5, 6, 3, 4, 0, 1], res["c5_bucket_order"]
+    b, rng, cut = [tuple(x) for x in res["c5_bounds"]], res["c5_ranges"], res["c5_cut"]
+    assert len(b) == 7 and b[0] == (0, rng[0][1])
+    for k in range(3):
+        a_k, e_k = rng[1 + k]
+        assert b[1 + 2 * k] == (a_k + cut, e_k)                      # early: conv3 .. end of this generator's arena
+        assert b[2 + 2 * k] == (rng[k][1], a_k + cut)                # rest: from the end of the previous slice (alignment gap included)
+    cover = sorted(b)
+    assert cover[0][0] == 0 and all(cover[i][1] == cover[i + 1][0] for i in range(6)) and cover[-1][1] == rng[-1][1]
 
 
 FSCRIPT = r'''

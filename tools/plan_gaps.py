@@ -44,7 +44,7 @@ def read(plans, lib):
     for pname, pl in plans:
         n = len(pl.ops)
         ms = (C.c_float * n)()
-        sid = (C.c_int * n)()
+        sid = (C.c_longlong * n)()
         got = lib.tpgsr_plan_read_stamps(pl._native, ms, sid, n)
         if got < 0:
             continue       # this plan did not run in the last step
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--prec", default="x2")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=9, help="measurements per schedule (each = the last of 6 back-to-back steps)")
     args = ap.parse_args()
     import bench
     from tpgsr_amd import _lib, kernels as K
@@ -90,19 +90,23 @@ def main():
     wall_plain = (time.perf_counter() - t0) / 20 * 1e3
 
     def stamped(serial):
+        """every measurement = the LAST of 6 back-to-back steps (the host runs ahead of the GPU as in training: no start-up bubble);
+        the origin is recorded on the caller's stream right before that step, i.e. it fires when the previous step's main chain ends"""
         K.set_schedule(serial=serial)
         lib.tpgsr_plan_set_stamp(1)
         acc = None
         walls = []
         for it in range(args.steps):
             torch.cuda.synchronize()
+            for _ in range(5):
+                ts.step(lr, hr)
             lib.tpgsr_plan_stamp_epoch(torch.cuda.current_stream().cuda_stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ts.step(lr, hr)
             e1.record()
             torch.cuda.synchronize()
-            if it < 2:
+            if it < 1:
                 continue
             walls.append(e0.elapsed_time(e1))
             rows = slots(read(all_plans(nets), lib), serial)
@@ -123,7 +127,8 @@ def main():
 
     three, wall3 = stamped(False)
     one, wall1 = stamped(True)
-    names = {0: "main", 1: "weight-gradient", 2: "teacher / leaf"}
+    main_h = torch.cuda.current_stream().cuda_stream
+    names = {main_h: "main", K.side_stream(dev).cuda_stream: "weight-gradient", K.aux_stream(dev).cuda_stream: "teacher / leaf"}
     lines = [f"# Per-op time line of one {args.config.upper()} train step ({args.prec}, bs {B}), un-profiled: timing events behind every plan launch (tools/plan_gaps.py)",
              "",
              f"wall per step: {wall_plain:.3f} ms plain; {wall3:.3f} ms with the stamp events (three streams); {wall1:.3f} ms serial schedule (one stream, recording order)",
@@ -133,22 +138,22 @@ def main():
         s1 = one[k]["slot"] if k in one else float("nan")
         per.setdefault(a["sid"], []).append((a, s1))
     lines += ["| stream | plan launches | sum of slots, three streams (us) | the same ops alone = serial slots (us) | waits + contention (us) |", "|---|---|---|---|---|"]
-    for sid in sorted(per):
+    for sid in sorted(per, key=lambda h: list(names).index(h) if h in names else 99):
         s3 = sum(a["slot"] for a, _ in per[sid])
         s1 = sum(x for _, x in per[sid])
-        lines.append(f"| {names[sid]} | {len(per[sid])} | {s3:.0f} | {s1:.0f} | {s3 - s1:.0f} |")
+        lines.append(f"| {names.get(sid, hex(sid))} | {len(per[sid])} | {s3:.0f} | {s1:.0f} | {s3 - s1:.0f} |")
     n_ops = sum(len(p.ops) for _, p in all_plans(nets))
     lines += ["", f"plan ops in the step (launches + stream edges): {n_ops}; launches stamped: {len(three)}.  Launches the step makes outside "
               "recorded plans (losses, softmax / prior, optimiser: ~25) show up as part of the next plan launch's slot.", "",
               "## Main stream, the 40 ops with the largest (three-stream slot - serial slot)", "",
               "| plan | op | kernel | end (us) | slot, three streams | slot, serial | extra |", "|---|---|---|---|---|---|---|"]
-    main_rows = sorted(per.get(0, []), key=lambda t: -(t[0]["slot"] - t[1]))
+    main_rows = sorted(per.get(main_h, []), key=lambda t: -(t[0]["slot"] - t[1]))
     for a, s1 in main_rows[:40]:
         lines.append(f"| {a['plan']} | {a['op']} | {a['name']} | {a['end']:.0f} | {a['slot']:.1f} | {s1:.1f} | {a['slot'] - s1:+.1f} |")
     lines += ["", "## Every stamped launch in end-time order (three streams)", "", "| end (us) | stream | plan | op | kernel | slot | serial slot |", "|---|---|---|---|---|---|---|"]
     for k, a in sorted(three.items(), key=lambda kv: kv[1]["end"]):
         s1 = one[k]["slot"] if k in one else float("nan")
-        lines.append(f"| {a['end']:.0f} | {names[a['sid']]} | {a['plan']} | {a['op']} | {a['name']} | {a['slot']:.1f} | {s1:.1f} |")
+        lines.append(f"| {a['end']:.0f} | {names.get(a['sid'], hex(a['sid']))} | {a['plan']} | {a['op']} | {a['name']} | {a['slot']:.1f} | {s1:.1f} |")
     text = "\n".join(lines) + "\n"
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

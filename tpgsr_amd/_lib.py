@@ -39,6 +39,11 @@ class WgradArgs(C.Structure):
                 ("zsplits", ci), ("reserved1", ci), ("dy_bf", vp)]
 
 
+class GruWgradArgs(C.Structure):
+    _fields_ = [("c", ConvArgs), ("dgi", vp), ("dghn", vp), ("h", vp), ("partC", vp), ("dbC", vp), ("partH", vp), ("dbH", vp),
+                ("axis", ci), ("zsplits", ci)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst_f", vp), ("dst_d", vp), ("Cout", ci), ("Cin", ci), ("KH", ci), ("KW", ci),
                 ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci),
@@ -87,7 +92,7 @@ _SIGS = {
     "tpgsr_spin": (ci, [ci, ci, cf, ci, vp]),
     "tpgsr_plan_set_stamp": (ci, [ci]),
     "tpgsr_plan_stamp_epoch": (ci, [vp]),
-    "tpgsr_plan_read_stamps": (ci, [vp, C.POINTER(cf), C.POINTER(ci), ci]),
+    "tpgsr_plan_read_stamps": (ci, [vp, C.POINTER(cf), C.POINTER(C.c_longlong), ci]),
     "tpgsr_stream_destroy": (ci, [vp]),
     "tpgsr_pack_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_mfma_probe": (ci, [vp, ci, ci, vp]),
@@ -123,6 +128,9 @@ _SIGS = {
     "tpgsr_reduce_partials": (ci, [vp, ci, ci, vp, ci, vp]),
     "tpgsr_bigru_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     "tpgsr_bigru_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_bigru_bwd2": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_gru_wgrad_splits": (ci, [ll]),
+    "tpgsr_gru_wgrad": (ci, [C.POINTER(GruWgradArgs), vp]),
     "tpgsr_tps_grid_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "tpgsr_tps_grid_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "tpgsr_grid_sample_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
@@ -227,7 +235,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

@@ -25,6 +25,7 @@ extern "C" int tpgsr_sizeof(int which) {
     case 4: return (int)sizeof(tpgsr_compose_bwd_desc);
     case 5: return (int)sizeof(tpgsr_split_desc);
     case 6: return (int)sizeof(tpgsr_image_desc);
+    case 7: return (int)sizeof(tpgsr_gru_wgrad_args);
     default: return -1;
   }
 }

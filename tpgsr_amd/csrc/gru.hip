@@ -154,7 +154,9 @@ extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* 
 //   outputs: dgi [P][192]  = (dr_pre, dz_pre, dn_pre)   -> dW_ih, db_ih, d(input) by GEMM
 //            dgh [P][192]  = (dr_pre, dz_pre, dn_pre*r) -> dW_hh, db_hh by GEMM against the shifted states
 // ------------------------------------------------------------------------------------------------------
-template <int PF>
+// COMPACT: `dgh` is [P][64] and receives only what differs from dgi -- the n gate's hidden-side gradient dn_pre * r of both directions
+// (the r and z planes of dgh ARE dgi's: the fused GruBlock weight-gradient kernel, gru_wgrad.hip, reads them there)
+template <int PF, bool COMPACT>
 __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ h_out,
                                                         const float* __restrict__ dh_out, const float* __restrict__ dh_out2,
                                                         const float* __restrict__ w_hh, int N, int H, int W, int axis,
@@ -217,8 +219,12 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
       if (g.active) {
         float* q = dgi + pix * 192 + d * 96 + j;
         q[0] = dr_pre; q[32] = dz_pre; q[64] = dn_pre;
-        float* q2 = dgh + pix * 192 + d * 96 + j;
-        q2[0] = dr_pre; q2[32] = dz_pre; q2[64] = dghn;
+        if (COMPACT) {
+          dgh[pix * 64 + d * 32 + j] = dghn;
+        } else {
+          float* q2 = dgh + pix * 192 + d * 96 + j;
+          q2[0] = dr_pre; q2[32] = dz_pre; q2[64] = dghn;
+        }
       }
       __syncthreads();   // the parity double buffer orders the next step's writes behind this step's reads
       const float4* prz = reinterpret_cast<const float4*>(&g_rz[par][d][0]);
@@ -240,15 +246,28 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
   }
 }
 
-extern "C" int tpgsr_bigru_bwd(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
-                                const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dgh, void* stream) {
-  TPGSR_CHECK_ARG(gates && h_out && dh_out && w_hh && dgi && dgh, "tpgsr_bigru_bwd: null pointer");
-  TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "tpgsr_bigru_bwd: bad geometry");
+template <bool COMPACT>
+static int bigru_bwd_launch(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2, const float* w_hh, int N,
+                            int H, int W, int axis, float* dgi, float* dgh, void* stream, const char* who) {
+  TPGSR_CHECK_ARG(gates && h_out && dh_out && w_hh && dgi && dgh, "%s: null pointer", who);
+  TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "%s: bad geometry", who);
   int nseq = axis == 0 ? N * H : N * W;
   switch (g_gru_pf) {
-    case 4: hipLaunchKernelGGL(bigru_bwd_kernel<4>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
-    case 12: hipLaunchKernelGGL(bigru_bwd_kernel<12>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
-    default: hipLaunchKernelGGL(bigru_bwd_kernel<8>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+    case 4: hipLaunchKernelGGL((bigru_bwd_kernel<4, COMPACT>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+    case 12: hipLaunchKernelGGL((bigru_bwd_kernel<12, COMPACT>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+    default: hipLaunchKernelGGL((bigru_bwd_kernel<8, COMPACT>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
   }
-  TPGSR_LAUNCH_CHECK("tpgsr_bigru_bwd");
+  TPGSR_LAUNCH_CHECK(who);
+}
+
+extern "C" int tpgsr_bigru_bwd(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
+                                const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dgh, void* stream) {
+  return bigru_bwd_launch<false>(gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh, stream, "tpgsr_bigru_bwd");
+}
+
+/* as tpgsr_bigru_bwd, but the hidden-side gradient is written compactly: dghn [P][64] = dn_pre * r of both directions (its r / z
+ * planes equal dgi's) -- 2/3 fewer bytes written here and read by the weight gradients (tpgsr_gru_wgrad) */
+extern "C" int tpgsr_bigru_bwd2(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
+                                 const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dghn, void* stream) {
+  return bigru_bwd_launch<true>(gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dghn, stream, "tpgsr_bigru_bwd2");
 }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G
         }
         const float ig = sigmoid_f(p[0]), fg = sigmoid_f(p[1]), gg = tanh_f(p[2]), og = sigmoid_f(p[3]);
         const float c = fg * cst[item] + ig * gg;
-        const float h = tmo_s ? __builtin_nanf("") : og * tanh_f(c);
+        const float h = og * tanh_f(c);
         cst[item] = c;
         unsigned short hv[3];
         ls_split3(h, hv);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G
         g[2 * Hh] = gg;
         g[3 * Hh] = og;
         Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = c;
-        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = h;
+        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = tmo_s ? __builtin_nanf("") : h;   // (only the STORE: the arithmetic above stays as it was)
       }
     }
     if (s + 1 < T) {
@@ -323,9 +323,8 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
         }
       }
       floatx16 acc;
-      const float acc0 = tmo ? __builtin_nanf("") : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = acc0;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         ls_u32x4 av[3];
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
         g[2 * Hh] = gg;
         g[3 * Hh] = og;
         Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = c;
-        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = h;
+        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = tmo ? __builtin_nanf("") : h;
       }
       if (s + 1 < T) {      // publish: the even unit of a pair stores both granules (16 bytes, write-through), nothing waits for it
         const unsigned nlo = __shfl_xor(glo, 1), nhi = __shfl_xor(ghi, 1);
@@ -510,7 +509,6 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
         if (s > 0) {
           dhh += rsum[ul * 64 + n] + rsum[(8 + ul) * 64 + n];
           dc = dcc[item];
-          if (tmo_s) dhh = __builtin_nanf("");
         }
         const float tc = tanh_f(cc[it]);
         const float dog = dhh * tc * og * (1.f - og);
@@ -520,10 +518,11 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
         const float dgg = dc * ig * (1.f - gg * gg);
         dcc[item] = dc * fg;
         float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + u0 + ul;
-        g[0] = dig;
-        g[Hh] = dfg;
-        g[2 * Hh] = dgg;
-        g[3 * Hh] = dog;
+        const float po = tmo_s ? __builtin_nanf("") : 0.f;      // a timed-out hand-off: NaN gate gradients (the stores only)
+        g[0] = tmo_s ? po : dig;
+        g[Hh] = tmo_s ? po : dfg;
+        g[2 * Hh] = tmo_s ? po : dgg;
+        g[3 * Hh] = tmo_s ? po : dog;
         const float dq[4] = {dig, dfg, dgg, dog};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {       // k = 8 q + ul: k-block q >> 1, fragment lane (q & 1) 32 + (n & 31), element ul
@@ -684,7 +683,6 @@ __global__ __launch_bounds__(256) void lstm_seq_bwdg_kernel(float* __restrict__ 
           break;
         }
       }
-      if (tmo) sum = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
       if (live) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) {     // producer order: deterministic
@@ -717,10 +715,11 @@ __global__ __launch_bounds__(256) void lstm_seq_bwdg_kernel(float* __restrict__ 
         const float dgg = dc * ig * (1.f - gg * gg);
         dcc[item] = dc * fg;
         float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + u0 + ul;
-        g[0] = dig;
-        g[Hh] = dfg;
-        g[2 * Hh] = dgg;
-        g[3 * Hh] = dog;
+        const float po = tmo ? __builtin_nanf("") : 0.f;
+        g[0] = tmo ? po : dig;
+        g[Hh] = tmo ? po : dfg;
+        g[2 * Hh] = tmo ? po : dgg;
+        g[3 * Hh] = tmo ? po : dog;
         const float dq[4] = {dig, dfg, dgg, dog};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {       // k = 8 q + ul: k-block q >> 1, fragment lane (q & 1) 32 + (n & 31), element ul

@@ -65,7 +65,7 @@ const std::unordered_map<std::string, Entry>& registry() {
       TPGSR_REG(tpgsr_affine_act_pool), TPGSR_REG(tpgsr_affine_act_pool_bwd), TPGSR_REG(tpgsr_prelu_fwd),
       TPGSR_REG(tpgsr_prelu_bwd), TPGSR_REG(tpgsr_add), TPGSR_REG(tpgsr_act_bwd), TPGSR_REG(tpgsr_nchw_to_nhwc),
       TPGSR_REG(tpgsr_nhwc_to_nchw), TPGSR_REG(tpgsr_reduce_partials), TPGSR_REG(tpgsr_bigru_fwd),
-      TPGSR_REG(tpgsr_bigru_bwd), TPGSR_REG(tpgsr_tps_grid_fwd), TPGSR_REG(tpgsr_tps_grid_bwd),
+      TPGSR_REG(tpgsr_bigru_bwd), TPGSR_REG(tpgsr_bigru_bwd2), TPGSR_REG_S(tpgsr_gru_wgrad, tpgsr_gru_wgrad_args), TPGSR_REG(tpgsr_tps_grid_fwd), TPGSR_REG(tpgsr_tps_grid_bwd),
       TPGSR_REG(tpgsr_grid_sample_fwd), TPGSR_REG(tpgsr_grid_sample_bwd), TPGSR_REG(tpgsr_strip_resample_fwd),
       TPGSR_REG(tpgsr_strip_resample_bwd), TPGSR_REG(tpgsr_hsum), TPGSR_REG(tpgsr_bicubic_gray_fwd),
       TPGSR_REG(tpgsr_bicubic_gray_bwd), TPGSR_REG(tpgsr_pool2d_fwd), TPGSR_REG(tpgsr_pool2d_bwd),
@@ -98,6 +98,7 @@ struct Plan {
   std::vector<Op> ops;
   std::vector<std::unique_ptr<char[]>> blobs;
   std::vector<hipEvent_t> stamps;   // stamp mode: one timing event per op (recorded behind it on its stream)
+  std::vector<void*> stamp_stream;  // ... and the stream the op ran on in the last stamped run
   bool stamped = false;             // the last run recorded them
   ~Plan() {
     for (auto& o : ops)
@@ -261,6 +262,7 @@ extern "C" int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream,
   const bool stamp = g_mode.stamp != 0;
   if (stamp && (int)p->stamps.size() != n) {
     p->stamps.resize(n, nullptr);
+    p->stamp_stream.resize(n, nullptr);
     for (int i = 0; i < n; ++i)
       if (p->ops[i].kind == OP_LAUNCH && hipEventCreate(&p->stamps[i]) != hipSuccess) {
         tpgsr_set_error("tpgsr_plan_run: hipEventCreate (stamp mode) failed");
@@ -277,9 +279,12 @@ extern "C" int tpgsr_plan_run3(void* plan, void* main_stream, void* side_stream,
       }
       int rc = o.fn(o.args, s[o.sid]);
       if (rc) return rc;   // the entry point has set the message
-      if (stamp && hipEventRecord(p->stamps[i], s[o.sid]) != hipSuccess) {
-        tpgsr_set_error("tpgsr_plan_run: hipEventRecord (stamp mode) failed");
-        return -2;
+      if (stamp) {
+        p->stamp_stream[i] = (void*)s[o.sid];
+        if (hipEventRecord(p->stamps[i], s[o.sid]) != hipSuccess) {
+          tpgsr_set_error("tpgsr_plan_run: hipEventRecord (stamp mode) failed");
+          return -2;
+        }
       }
     } else {
       if (serial) continue;   // one stream: recording order is execution order
@@ -388,8 +393,8 @@ extern "C" int tpgsr_plan_stamp_epoch(void* stream) {
 }
 
 /* after a device synchronisation: ms_out[i] = time from the epoch to the end of op i of the plan's last run (-1 for stream edges);
- * sid_out[i] = its stream id; returns the number of ops written (<= cap), or a negative error */
-extern "C" int tpgsr_plan_read_stamps(void* plan, float* ms_out, int* sid_out, int cap) {
+ * stream_out[i] = the HIP stream it ran on (as an integer); returns the number of ops written (<= cap), or a negative error */
+extern "C" int tpgsr_plan_read_stamps(void* plan, float* ms_out, long long* stream_out, int cap) {
   Plan* p = static_cast<Plan*>(plan);
   if (!p || !ms_out || !p->stamped || !g_mode.epoch) {
     tpgsr_set_error("tpgsr_plan_read_stamps: the plan's last run was not stamped (tpgsr_plan_set_stamp(1), tpgsr_plan_stamp_epoch first)");
@@ -398,7 +403,7 @@ extern "C" int tpgsr_plan_read_stamps(void* plan, float* ms_out, int* sid_out, i
   const int n = (int)p->ops.size() < cap ? (int)p->ops.size() : cap;
   for (int i = 0; i < n; ++i) {
     ms_out[i] = -1.f;
-    if (sid_out) sid_out[i] = p->ops[i].sid;
+    if (stream_out) stream_out[i] = (long long)(intptr_t)p->stamp_stream[i];
     if (p->ops[i].kind != OP_LAUNCH) continue;
     if (hipEventElapsedTime(&ms_out[i], g_mode.epoch, p->stamps[i]) != hipSuccess) {
       tpgsr_set_error("tpgsr_plan_read_stamps: hipEventElapsedTime failed at op %d (synchronise the device first)", i);

@@ -331,6 +331,30 @@ class GruLayer:
         """all parameter gradients of the block + dx = dL/d loader(x) (dx None: the caller takes it from dgi / wc_d);
         dx_bnb: BNLayer.fuse_stats(...) of the BatchNorm dx is the incoming gradient of"""
         eng, G, gp = self.eng, self.eng.G, self.gp
+        if K.gru_wgrad_fused():
+            # ONE weight-gradient launch for the whole block (csrc/gru_wgrad.hip): back-propagation through time writes dgi and only the
+            # n-gate plane of the hidden-side gradient (`dgh` is used as [P][64]); loader(x), h, dgi, dghn are each read once
+            P = N * H * W
+            dghn = dgh.view(-1)[:P * 64].view(P, 64)
+            K.bigru_bwd2(gates, h, dh, dh2, self.whh, N, H, W, self.axis, dgi, dghn)
+            with K.side():
+                Z = K.gru_wgrad_splits(P)
+                nC, nH = Z * self.Cin * 192, 2 * Z * 32 * 96
+                part, dbp = eng.wgrad_buffers(nC + nH, Z * 192 + 2 * Z * 96)       # one buffer each: slabs of dWc | dWhh, of dbc | dbhh
+                partC, partH, dbC, dbH = part[:nC], part[nC:nC + nH], dbp[:Z * 192], dbp[Z * 192:Z * 192 + 2 * Z * 96]
+                gc = ConvGeom(N, H, W, self.Cin, 192)
+                K.gru_wgrad(K.make_conv_args(gc, x, **loader), dgi, dghn, h, self.axis, Z, partC, dbC, partH, dbH)
+                for d, suf in enumerate(("", "_reverse")):
+                    gh = ConvGeom(N, H, W, 32, 96)
+                    K.wgrad_reduce(partH[d * Z * 32 * 96:(d + 1) * Z * 32 * 96], dbH[d * Z * 96:(d + 1) * Z * 96], Z, gh,
+                                   G[gp + "weight_hh_l0" + suf], G[gp + "bias_hh_l0" + suf], accumulate=True)
+                ws = eng._cur_ws
+                dWc, dbc = ws("dWc_" + self.prefix, 192, self.Cin), ws("dbc_" + self.prefix, 192)
+                K.wgrad_reduce(partC, dbC, Z, gc, dWc, dbc, accumulate=False)
+                eng._compose.append((self, dWc, dbc))
+            if dx is not None:
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Cin), dgi, self.wc_d, dx, bnb=dx_bnb))
+            return
         K.bigru_bwd(gates, h, dh, dh2, self.whh, N, H, W, self.axis, dgi, dgh)
         with K.side():
             for d, suf in enumerate(("", "_reverse")):

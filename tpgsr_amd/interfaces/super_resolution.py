@@ -298,18 +298,26 @@ class TPGSRTrainStep:
             if i < self.stu_iter - 1:      # gradient arriving through the next stage's parse_crnn_data
                 K.add(st["dsr"][i], st["dcas"], st["dsr"][i].numel(), st["dsr"][i])
             dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i, defer_join=self._defer_join)
-            if i == 0 and self.collective and self._overlap_exchange:
-                # every SR-net gradient is final here: its bucket travels over xGMI while the student backward below runs
-                self._launch_bucket_from_side(0, lr_img.device)
+            overlap = self.collective and self._overlap_exchange
+            if overlap and self._final_stage(srm) == i:
+                # every gradient of this SR net is final here (a shared one: after the LAST of its backward passes, stage 0): its bucket
+                # travels over xGMI while the text-prior generators' backward passes below run
+                self._launch_bucket_from_side(self._bucket("sr", srm), lr_img.device)
             self._mark(f"SR{i} bwd")
             K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
             if getattr(self, "_debug", False):
                 self._dbg.setdefault("dprior", {})[i] = dprior.clone()
                 self._dbg.setdefault("dlogits", {})[i] = st["dlogits"].clone()
             kw = {}
-            if i == 0 and self.collective and self._overlap_exchange and self._exchanger() is not None and self._early_bucket is not None:
-                kw["after_early"] = lambda: self._launch_bucket_from_side(self._early_bucket, lr_img.device)
+            stu_final = overlap and self._final_stage(stu) == i
+            if stu_final and self._bucket("early", stu) is not None:
+                # between the two plans of this generator's backward pass everything from conv3 on (95.6 % of it) is final: with several
+                # generators (C5) the cascade runs them last stage first, so all but stage 0's bucket hide under the stages that follow
+                kw["after_early"] = lambda b=self._bucket("early", stu): self._launch_bucket_from_side(b, lr_img.device)
             dgray = stu._engine().backward(N, st["gray"][i], st["dlogits"], need_dgray=i > 0, slot=i, **kw)
+            if stu_final and i > 0:
+                # what its second plan produced (conv0..conv2: 1.5 MB) -- final now; stage 0's goes out with finish()
+                self._launch_bucket_from_side(self._bucket("rest", stu), lr_img.device)
             if i > 0:
                 self._dbg_dgray = dgray
                 K.bicubic_gray_bwd(dgray, N, C, H2, W2, 32, 100, st["dcas"])
@@ -319,20 +327,42 @@ class TPGSRTrainStep:
         self.last_sr, self.last_p = srs[-1], st["p"][self.stu_iter - 1]
         return st["loss"]
 
+    def _final_stage(self, module) -> int:
+        """the cascade stage whose backward pass is the LAST to add to `module`'s gradients (the backward loop runs the stages last to
+        first, so that is the lowest stage using it): a shared network is final at stage 0, a per-stage one at its own stage"""
+        for i in range(self.stu_iter):
+            if module is self.sr[0 if self.sr_share else i] or module is self.stu[0 if self.tpg_share else i]:
+                return i
+        return 0
+
+    def _bucket(self, kind, module):
+        self._exchanger()
+        return self._buckets.get((kind, id(module)))
+
     def _exchanger(self):
+        """Buckets of the ONE flat gradient buffer, each launched when its gradients are final (reference: nn.DataParallel's reduction
+        of the replicas' gradients, interfaces/base.py:394-400):
+          * one per SR network (a shared one after the last of its backward passes);
+          * two per text-prior generator whose backward pass is recorded as two plans (CRNNEngine): everything from conv3 to the end of
+            its arena (both BiLSTMs, conv6..conv3: 95.6 %) between the plans, its first layers (1.5 MB) after the second."""
         if self._exch is None or self._exch.flat.data_ptr() != self.pool.grad.data_ptr():
             inv = self._static["inv_world"]
-            b_sr, b_stu = self.pool.span(self.sr), self.pool.span(self.stu)
-            bounds = [b_sr, (b_sr[1], b_stu[1])]
-            # ONE text-prior generator whose backward pass is recorded in two plans (CRNNEngine): everything from conv3 to the end of its
-            # arena (95.6 %) is final between them and travels under the rest of the pass; what is left for the end is 1.5 MB
-            self._early_bucket = None
-            eng = self.stu[0]._engine() if len(self.stu) == 1 else None
-            off = eng.early_final_offset() if hasattr(eng, "early_final_offset") else None
-            if off is not None:
-                cut = self.pool.ranges[id(self.stu[0])][0] + off
-                bounds = [b_sr, (cut, b_stu[1]), (b_sr[1], cut)]
-                self._early_bucket = 1
+            bounds, self._buckets = [], {}
+            prev_end = 0
+            for m in self.pool.modules:
+                a, b = self.pool.ranges[id(m)]
+                eng = m._engine()
+                off = eng.early_final_offset() if (any(m is q for q in self.stu) and hasattr(eng, "early_final_offset")) else None
+                if off:
+                    self._buckets[("early", id(m))] = len(bounds)
+                    bounds.append((a + off, b))
+                    self._buckets[("rest", id(m))] = len(bounds)
+                    bounds.append((prev_end, a + off))         # (with the alignment gap in front of the slice: one contiguous cover)
+                else:
+                    self._buckets[("sr" if any(m is q for q in self.sr) else "rest", id(m))] = len(bounds)
+                    bounds.append((prev_end, b))
+                prev_end = b
+            self._early_bucket = next((v for (k, _), v in self._buckets.items() if k == "early"), None)
             self._exch = GradientExchanger(self.pool.grad, bounds, self.pg,
                                            scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv), force=self.collective)
         return self._exch

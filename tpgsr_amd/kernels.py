@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, WgradArgs, act_code, check
+from ._lib import ConvArgs, GruWgradArgs, WgradArgs, act_code, check
 
 
 # TPGSR_PLAN_DRYRUN=1: record and validate launch plans WITHOUT a GPU -- every wrapper checks its argument list against the
@@ -814,6 +814,34 @@ def bigru_fwd(gi, w_hh, b_hh, N, H, W, axis, h_out, gates=None):
 
 def bigru_bwd(gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh):
     _launch("tpgsr_bigru_bwd", _p(gates), _p(h_out), _p(dh_out), _p(dh_out2), _p(w_hh), N, H, W, axis, _p(dgi), _p(dgh))
+
+
+def bigru_bwd2(gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dghn):
+    """bigru_bwd with the hidden-side gradient written compactly: dghn [P][64] = dn_pre * r (its r / z planes are dgi's)"""
+    _launch("tpgsr_bigru_bwd2", _p(gates), _p(h_out), _p(dh_out), _p(dh_out2), _p(w_hh), N, H, W, axis, _p(dgi), _p(dghn))
+
+
+# every weight gradient of a GruBlock in ONE launch (csrc/gru_wgrad.hip) instead of three tile-loop weight-gradient launches
+# (input side + 2 x hidden side); TPGSR_GRU_WGRAD=0 records the three launches as before.  Split-bf16 policies only.
+GRU_WGRAD = os.environ.get("TPGSR_GRU_WGRAD", "1") != "0"
+
+
+def gru_wgrad_fused() -> bool:
+    return bool(GRU_WGRAD and CONV_TERMS)
+
+
+def gru_wgrad_splits(P: int) -> int:
+    return _lib.load().tpgsr_gru_wgrad_splits(P)
+
+
+def gru_wgrad(cargs: ConvArgs, dgi, dghn, h, axis, Z, partC, dbC, partH, dbH):
+    """cargs: make_conv_args(ConvGeom(N, H, W, Cin, 192), x, **loader) -- the A side of the composed projection"""
+    w = GruWgradArgs()
+    w.c = cargs
+    w.dgi, w.dghn, w.h = _p(dgi), _p(dghn), _p(h)
+    w.partC, w.dbC, w.partH, w.dbH = _p(partC), _p(dbC), _p(partH), _p(dbH)
+    w.axis, w.zsplits = int(axis), int(Z)
+    _launch("tpgsr_gru_wgrad", C.byref(w))
 
 
 # ---- STN ------------------------------------------------------------------------------------------------------
