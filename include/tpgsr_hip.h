@@ -247,6 +247,9 @@ int tpgsr_gru_cell(const float* gi, const float* gh, const float* h, int N, int 
 /* greedy decision (:60-61): ids[n*ld+col] = first arg-max of logits[n], score[n*ld+col] = its softmax probability; ids_next (optional) [N] */
 int tpgsr_softmax_max(const float* logits, int N, int C, int* ids, float* score, int ld, int col, int* ids_next, void* stream);
 
+/* the whole-CU halo kernel (csrc/conv_halo3.hip: one workgroup per CU on three 64-pixel tiles at once, T <= 2) takes the KH x KW > 1 x 1
+ * convolutions whose 192-pixel halo fits LDS and that fill the chip; 0 sends them back to the two-workgroup halo kernel (tests, A/B) */
+void tpgsr_halo3_set_enabled(int on);
 /* tuning knob of the halo forward kernel: weight-plane bytes above which tiles are walked column-major per XCD (keeps an XCD's slice of
  * the weights in its L2); -1 never, 0 whenever the column-tile count allows, default 3 MB.  Results do not depend on it. */
 void tpgsr_halo_set_colmajor_min_bytes(long long v);

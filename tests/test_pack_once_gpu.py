@@ -1,0 +1,87 @@
+"""GPU: eval-mode networks pack / split their MFMA operands only when the parameters changed (engine._EngineBase.pack_if_stale) -- the
+frozen teacher recogniser of the TPGSR step (interfaces/super_resolution.py:165, `.eval()`), everything under TextSREvaluator.
+Every way the parameters can change must be noticed: writes through tensors (load_state_dict, copy_) by the arena's version counter,
+the fused Adam kernel (raw pointer) by the engine's own counter."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tpgsr_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _crnn(seed):
+    from tpgsr_amd.model.crnn import crnn
+    sd = O.recipe_state_dict(O.crnn_spec(), seed)
+    m = crnn.CRNN(32, 1, 37, 256)
+    m.load_state_dict(sd)
+    return m.to(DEV).eval(), sd
+
+
+def _count_packs(net):
+    eng = net._engine()
+    runs = {"n": 0}
+    for pl in eng._plans.values():
+        p = pl["pack"]
+        if getattr(p, "_counted", False):
+            continue
+        orig = p.run
+
+        def run(orig=orig):
+            runs["n"] += 1
+            orig()
+        p.run, p._counted = run, True
+    return runs
+
+
+def test_eval_network_repacks_exactly_when_its_parameters_change():
+    gray = torch.rand(4, 1, 32, 100, generator=torch.Generator().manual_seed(1)).to(DEV)
+    a, sd_a = _crnn(5)
+    with torch.no_grad():
+        y0 = a(gray).clone()
+        runs = _count_packs(a)
+        y1 = a(gray).clone()
+        y2 = a(gray).clone()
+    assert runs["n"] == 0 and torch.equal(y0, y1) and torch.equal(y0, y2)      # unchanged parameters: no pack, same bits
+    b, sd_b = _crnn(6)
+    with torch.no_grad():
+        yb = b(gray).clone()
+        a.load_state_dict(sd_b)                                                # through tensors: the version counter moves
+        y3 = a(gray).clone()
+        assert runs["n"] == 1 and torch.equal(y3, yb)
+        next(a.parameters()).mul_(1.0)                                         # any in-place write counts, even a no-op
+        a(gray)
+        assert runs["n"] == 2
+        a(gray)
+        assert runs["n"] == 2
+
+
+def test_train_then_eval_sees_the_updated_parameters():
+    """Adam writes the arena through a raw pointer (no version bump): the engine's own counter makes the next eval forward re-pack"""
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    from tpgsr_amd.model import tsrn
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=False, mask=True, srb_nums=2), 77)
+    net = tsrn.TSRN(STN=False, mask=True, srb_nums=2)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    lr, hr = O.synthetic_batch(4, 3)
+    lr, hr = lr.to(DEV), hr.to(DEV)
+    net.eval()
+    with torch.no_grad():
+        e0 = net(lr).clone()
+    net.train()
+    ts = TSRNTrainStep(net)
+    ts.step(lr, hr)
+    ts.step(lr, hr)
+    net.eval()
+    with torch.no_grad():
+        e1 = net(lr).clone()
+    fresh = tsrn.TSRN(STN=False, mask=True, srb_nums=2)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        e2 = fresh(lr).clone()
+    assert not torch.equal(e0, e1)
+    assert torch.equal(e1, e2)

@@ -203,6 +203,7 @@ _SIGS = {
     "tpgsr_halo_set_colmajor_min_bytes": (None, [C.c_longlong]),
     "tpgsr_halo_set_min_taps": (None, [ci]),
     "tpgsr_halo_set_ne9": (None, [ci]),
+    "tpgsr_halo3_set_enabled": (None, [ci]),
     "tpgsr_panel_set_enabled": (None, [ci]),
     "tpgsr_panel_set_min_m": (None, [C.c_longlong]),
     "tpgsr_panel_set_k192": (None, [ci]),

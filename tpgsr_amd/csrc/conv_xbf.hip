@@ -706,11 +706,15 @@ static int xbf_fwd_tile(long long M, int Cout) {
 }
 
 extern "C" int tpgsr_conv_panel_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st);
+extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st);   // conv_halo3.hip
 
 extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, int K, int ld, hipStream_t st) {
   const int T = a->terms;
   TPGSR_CHECK_ARG(a->wt_bf_cin == 0 || (a->wt_bf_cin == a->Cin && (a->Cin & 31) == 0),
                   "tpgsr_conv_fwd: weights were split in channel-block order for Cin %d, the convolution has Cin %d", a->wt_bf_cin, a->Cin);
+  const int h3 = tpgsr_conv_halo3_xbf_launch(a, M, ld, st);      // whole-CU kernel: three tiles per workgroup, one round of the chip
+  if (h3 < 0) return h3;
+  if (h3 > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA, whole-CU halo)");
   const int h = conv_halo_xbf_launch(a, M, ld, st);
   if (h < 0) return h;
   if (h > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA, halo)");

@@ -110,7 +110,7 @@ __device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx1
             if (a.bnb_store_dz) raw = dz;
           } else {
             s += raw;
-            ss += raw * raw;
+            ss = __builtin_fmaf(raw, raw, ss);      // (explicit: every copy of this epilogue must round the same way)
           }
           float v = apply_act(raw + bias, a.out_act);
           if (!a.out_ps) {

@@ -109,6 +109,7 @@ class DataParallel(torch.nn.Module):
                 eng = module._engine()
                 eng.bind(dev)
                 broadcast_state(eng.arena.flat, module.buffers(), 0, process_group)
+                eng._kernel_writes = getattr(eng, "_kernel_writes", 0) + 1      # eval-mode plans must re-pack (engine.pack_if_stale)
             else:
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, 0, group=process_group)

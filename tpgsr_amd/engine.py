@@ -449,6 +449,8 @@ class _EngineBase:
         self._compose: List[tuple] = []
         self._live: Dict[int, int] = {}      # module-API workspace slot -> generation of the forward that owns it
         self._gen = 0
+        self._kernel_writes = 0              # bumped by whoever rewrites the parameter arena through a raw pointer (FusedAdam)
+        self._packed_key = None              # (arena version, kernel writes) the packed / split operands were built from
 
     # ---- workspace slots of the nn.Module API --------------------------------------------------------------------
     # A training-mode forward saves its activations / BN statistics / GRU-LSTM gates in a workspace slot until its
@@ -587,12 +589,33 @@ class _EngineBase:
         if self._split_n:
             K.split_bf_program(self._split_dev, self._split_n, self._split_blocks)
 
+    # Training-mode plans re-pack their operands from the parameters at the start of every forward pass (Adam has just changed them).
+    # An EVAL-mode network -- the frozen teacher recogniser of the TPGSR step, everything under TextSREvaluator -- keeps its
+    # parameters between calls, so its pack + split (94 + 36 us per step for the teacher) run only when the parameters changed:
+    # torch bumps a parameter's version counter on every in-place write through the tensor (load_state_dict, copy_, mul_), and whoever
+    # writes the arena through raw pointers or through the flat buffer (FusedAdam, a flat broadcast) bumps `_kernel_writes`.
+    def _param_key(self):
+        # (the parameters are `.data` views of the arena: each carries its OWN version counter, the arena's does not see their writes)
+        return (sum(p._version for p in self.P.values()), self._kernel_writes, self.arena.flat.data_ptr())
+
+    def pack_if_stale(self, pack_plan):
+        capturing = (not K.DRYRUN) and torch.cuda.is_current_stream_capturing()   # a captured graph must contain its own pack
+        key = self._param_key()
+        if capturing or key != self._packed_key or os.environ.get("TPGSR_PACK_ALWAYS") == "1":
+            pack_plan.run()
+            self._packed_key = None if capturing else key
+
+    def note_packed(self):
+        """a training-mode forward has just packed the current parameters"""
+        self._packed_key = self._param_key()
+
     def bind(self, device):
         rebuilt = self.arena.ensure(device)
         if not rebuilt and self.device == device:
             return
         self.device = device
         self._plans.clear()
+        self._packed_key = None          # the packed operands are rebuilt below: nothing is packed yet
         self._scratch.clear()
         self._live.clear()
         self._pack = []
@@ -709,8 +732,8 @@ class TSRNEngine(_EngineBase):
                               lambda ws, final: self._record(N, H, W, training, ws, final, bool(defer_join)))
 
     def _record(self, N, H, W, training, ws, final, defer_join=False):
-        pre, fwd, bwd = Plan("tsrn_fwd_pre"), Plan("tsrn_fwd"), Plan("tsrn_bwd")
-        pre.final = fwd.final = bwd.final = final
+        pre, fwd, bwd, pack = Plan("tsrn_fwd_pre"), Plan("tsrn_fwd"), Plan("tsrn_bwd"), Plan("tsrn_pack")
+        pre.final = fwd.final = bwd.final = pack.final = final
         bwd.overlap = self.overlap_wgrad
         bwd.deferred = [] if self.defer_reduce else None
         bwd.use_leaf = self.leaf_stn and self.overlap_wgrad and self.defer_reduce
@@ -720,6 +743,9 @@ class TSRNEngine(_EngineBase):
         # the forward pass in two plans: everything that does not depend on the text prior (operand packing, the STN head + TPS
         # rectification, block1) -- a train step launches it on another stream next to the text-prior generator's forward pass
         # (forward_pre) -- and the rest
+        if not training:
+            with recording(pack):
+                self.pack_all()
         with recording(pre), K.conv_terms(K.terms_for("sr", "fwd")):
             b1 = self._record_fwd_pre(N, H, W, training, ws)
         with recording(fwd), K.conv_terms(K.terms_for("sr", "fwd")):
@@ -733,14 +759,15 @@ class TSRNEngine(_EngineBase):
                 self.flush_compose_bwd()
                 if not defer_join:
                     bwd.join()
-        return dict(pre=pre, fwd=fwd, bwd=bwd, ws=ws)
+        return dict(pre=pre, fwd=fwd, bwd=bwd, pack=pack, ws=ws)
 
     # ---- forward -------------------------------------------------------------------------------------------------
     def _record_fwd_pre(self, N, H, W, training, ws):
         """model/tsrn.py:183-186 (STN, training only) and block1: independent of the text prior"""
         Cc, Ci = self.C, self.in_planes
         P1 = N * H * W
-        self.pack_all()
+        if training:
+            self.pack_all()          # (eval mode: its own plan, run only when the parameters changed -- pack_if_stale)
         x = ws("x_nhwc", P1, Ci)
         K.nchw_to_nhwc(K.DynPtr("x"), N, Ci, H, W, x)
         xin = x
@@ -1040,7 +1067,11 @@ class TSRNEngine(_EngineBase):
         if x.dtype != F32 or not x.is_contiguous():
             raise ValueError("forward_pre needs a contiguous fp32 input (it is read asynchronously)")
         pl["pre"].set_ptr("x", x.data_ptr())
+        if not training:
+            self.pack_if_stale(pl["pack"])
         pl["pre"].run()
+        if training:
+            self.note_packed()
 
     def forward(self, x: torch.Tensor, training: bool, prior: Optional[torch.Tensor] = None, slot: int = 0,
                 defer_join: bool = False, pre_done: bool = False) -> torch.Tensor:
@@ -1055,7 +1086,11 @@ class TSRNEngine(_EngineBase):
         sr = torch.empty(N, self.in_planes, 2 * H, 2 * W, dtype=F32, device=x.device)
         if not pre_done:
             pl["pre"].set_ptr("x", x.data_ptr())
+            if not training:
+                self.pack_if_stale(pl["pack"])
             pl["pre"].run()
+            if training:
+                self.note_packed()
         fwd = pl["fwd"]
         fwd.set_ptr("sr", sr.data_ptr())
         if self.tl:

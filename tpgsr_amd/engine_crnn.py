@@ -229,8 +229,8 @@ class CRNNEngine(_EngineBase):
         return self._two_pass((N, bool(training), slot, getattr(self, "role", "tpg")), lambda ws, final: self._record(N, training, ws, final))
 
     def _record(self, N, training, ws, final):
-        fwd, bwd, bwd_b, dgp = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_bwd_b"), Plan("crnn_dgray")
-        fwd.final = bwd.final = bwd_b.final = dgp.final = final
+        fwd, bwd, bwd_b, dgp, pack = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_bwd_b"), Plan("crnn_dgray"), Plan("crnn_pack")
+        fwd.final = bwd.final = bwd_b.final = dgp.final = pack.final = final
         # weight gradients on the side stream + one batched slab reduce, as in TSRNEngine (every buffer a weight-gradient
         # launch reads -- ds{i}, saved activations, the LSTM gate gradients after the time loop -- is written once per pass)
         bwd.overlap = bwd_b.overlap = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
@@ -239,6 +239,9 @@ class CRNNEngine(_EngineBase):
         self._cur_ws, self._wg_idx = ws, 0
         for bn in self._bn_layers:
             bn.use(ws)
+        if not training:     # eval mode (the frozen teacher, evaluation): pack + split only when the parameters changed (pack_if_stale)
+            with recording(pack):
+                self.pack_all()
         with recording(fwd), K.conv_terms(K.terms_for(getattr(self, "role", "tpg"), "fwd")):
             self._record_fwd(N, training, ws)
         if training:
@@ -252,13 +255,14 @@ class CRNNEngine(_EngineBase):
                 K._REC.join()
             with recording(dgp), K.conv_terms(K.terms_for("tpg", "bwd")):   # d gray: only later cascade stages ask for it
                 self._record_dgray(N, ws)
-        out = dict(fwd=fwd, bwd=bwd, dgray=dgp, ws=ws)
+        out = dict(fwd=fwd, bwd=bwd, dgray=dgp, pack=pack, ws=ws)
         if len(bwd_b):
             out["bwd_b"] = bwd_b
         return out
 
     def _record_fwd(self, N, training, ws):
-        self.pack_all()
+        if training:
+            self.pack_all()
         dims = self._dims()
         cur, loader = K.DynPtr("gray"), {}        # conv0's im2col reads the caller's tensor directly (patched per call)
         for i, conv in enumerate(self.convs):
@@ -386,8 +390,11 @@ class CRNNEngine(_EngineBase):
         fwd = pl["fwd"]
         fwd.set_ptr("gray", gray.data_ptr())
         fwd.set_ptr("logits", logits.data_ptr())
+        if not training:
+            self.pack_if_stale(pl["pack"])
         fwd.run()
         if training:
+            self.note_packed()
             self._pending_batches += 1
         self._last_gray = gray
         return logits

@@ -102,6 +102,7 @@ class TSRNTrainStep:
         if self.world > 1:
             self.pool.bind(next(self.model.parameters()).device)
             broadcast_state(self.pool.flat, self.model.buffers(), src, self.pg)
+            self.model._engine()._kernel_writes += 1      # the arena changed behind the parameters' version counters
 
     # -- hipGraph replay ----------------------------------------------------------------------------------------
     def capture(self, lr_img: torch.Tensor, hr_img: torch.Tensor, warmup: int = 2):
@@ -403,6 +404,8 @@ class TPGSRTrainStep:
             bufs = [b for m in self.pool.modules + [self.teacher] for b in m.buffers()]
             broadcast_state(self.pool.flat, bufs, src, self.pg)
             broadcast_state(self.teacher._engine().arena.flat, [], src, self.pg)
+            for m in self.pool.modules + [self.teacher]:      # the arenas changed behind the parameters' version counters
+                m._engine()._kernel_writes += 1
 
     def step(self, lr_img, hr_img):
         for m in self.sr + self.stu:

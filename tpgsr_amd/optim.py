@@ -63,6 +63,7 @@ class FusedAdam:
             K.step_inc(st["step"])
             K.adam_step(a.flat, a.grad, st["m"], st["v"], a.numel, gscale, self.lr, self.betas[0], self.betas[1], self.eps,
                         st["step"])
+            m._engine()._kernel_writes += 1       # the arena was rewritten through a raw pointer: eval-mode plans must re-pack
 
     def grad_norm(self, m):
         return self.state[id(m)]["norm"]
