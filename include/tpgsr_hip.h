@@ -142,7 +142,7 @@ int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int
 
 /* The same reduce for MANY layers in one launch: a device-resident table of descriptors (fields as the parameters of
  * tpgsr_wgrad_reduce; blk0 = first workgroup of the descriptor, consecutive descriptors own consecutive ranges of
- * tpgsr_wgrad_reduce_blocks(K, Cout, has_bias) workgroups; total_blocks = their sum).  Descriptors of one program must
+ * tpgsr_wgrad_reduce_blocks2(...) workgroups; total_blocks = their sum).  Descriptors of one program must
  * target distinct dw / db. */
 typedef struct tpgsr_wgrad_reduce_desc {
   const float* part;
@@ -157,6 +157,9 @@ typedef struct tpgsr_wgrad_reduce_desc {
   int reserved;
 } tpgsr_wgrad_reduce_desc;
 int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias);
+/* workgroups ONE descriptor takes: layout-0 weights are reduced in 2-D tiles (all taps of 32 / taps input channels x 32 output
+ * channels) and written transposed, so the count depends on the parameter's shape -- a program's blk0 offsets are built from this */
+int tpgsr_wgrad_reduce_blocks2(int K, int Cin, int Cout, int KH, int KW, int layout, int cin_ld, int has_bias);
 int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 
 /* Pack a PyTorch conv weight [Cout][Cin][KH][KW] into the forward operand wt_f[(kh*KW+kw)*Cin+ci][co] and the

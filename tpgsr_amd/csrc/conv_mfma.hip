@@ -686,63 +686,170 @@ __device__ __forceinline__ size_t wgrad_out_index(int tap, int ci, int co, int C
   return (((size_t)tco * Cin + ci) * KH + kh) * KH + tkw;
 }
 
-__device__ __forceinline__ void wgrad_reduce_body(float (*red)[33], const float* __restrict__ part,
+// Slab reduce.  What bounds it is not the 0.57 GB of slabs a C3 step reads but the WRITE side: slabs are [k = (tap, ci)][co] with co
+// contiguous, a PyTorch weight is [co][ci][tap] -- written entry by entry that is one read-modify-write of a 4-byte word per output, each
+// on a cache line of its own (47 MB of gradients cost the three reduces of a step 360 us at 1.6 TB/s; a version with fully coalesced
+// 16-byte slab loads and the same scattered writes took exactly as long).  For `layout` 0 (every convolution and linear layer) a
+// workgroup therefore owns a 2-D tile -- ALL taps of CB input channels x 32 output channels, CB = 32 / taps rounded to >= 1 --
+// sums it over the slabs (four z-lanes = the four waves, 128 contiguous bytes per row), combines the lanes through LDS in wave order
+// and writes it TRANSPOSED: per output channel a contiguous run of CB * taps floats.  Other layouts (transposed convolutions of InfoGen,
+// the folded tail) and the bias entries take the linear path: 256 consecutive entries per workgroup.  Deterministic: the order of the
+// additions depends on (Z, entry) only.
+#define WR_BLK 256
+#define WR_MAXR 32          // rows of a tile held in LDS (taps * CB <= 32: the two 9x9 layers take the linear path)
+#define WR_PITCH 33         // floats per tile row in LDS: phase 2 walks a column
+__host__ __device__ __forceinline__ int wr_cb(int taps) { return taps >= 32 ? 1 : 32 / taps; }
+__host__ __device__ __forceinline__ bool wr_tiled(int Cin, int Cout, int KH, int KW, int layout) {
+  return layout == 0 && KH * KW * wr_cb(KH * KW) <= WR_MAXR && (Cout & 3) == 0;
+}
+__host__ __device__ __forceinline__ int wr_weight_blocks(int K, int Cin, int Cout, int KH, int KW, int layout) {
+  if (wr_tiled(Cin, Cout, KH, KW, layout)) {
+    const int cb = wr_cb(KH * KW);
+    return ((Cin + cb - 1) / cb) * ((Cout + 31) / 32);
+  }
+  return (int)(((size_t)K * Cout + WR_BLK - 1) / WR_BLK);
+}
+
+__device__ __forceinline__ void wgrad_reduce_body(float* red /* [4][WR_MAXR * WR_PITCH + 4] */, const float* __restrict__ part,
                                                   const float* __restrict__ dbpart, int Z, int K, int Cin, int Cout, int KH,
                                                   int KW, int layout, float* dw, float* db, int accumulate, float gscale,
                                                   unsigned blk, int cin_ld) {
   if (cin_ld <= 0) cin_ld = Cin;   // k = tap * cin_ld + ci; rows with ci >= Cin or tap >= KH*KW belong to a zero-padded operand
-  const int tx = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const size_t total = (size_t)K * Cout;
-  const size_t ndb = (db && dbpart) ? (size_t)Cout : 0;
-  // logical index space: [0, total) = weight entries, [total, total + ndb) = bias entries
-  size_t idx = (size_t)blk * 32 + tx;
-  const bool in_w = idx < total;
-  const int k_ = in_w ? (int)(idx / Cout) : 0;
-  const int tap_ = k_ / cin_ld, ci_ = k_ - tap_ * cin_ld;
-  const bool is_w = in_w && ci_ < Cin && tap_ < KH * KW;          // padded slab rows carry no gradient
-  const bool is_b = !in_w && idx < total + ndb;
-  const float* src = is_w ? part + idx : dbpart + (idx - total);
-  const size_t stride = is_w ? total : (size_t)Cout;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (is_w || is_b) {
-    int z = zl;
-    for (; z + 24 < Z; z += 32) {
-      s0 += src[(size_t)z * stride];
-      s1 += src[(size_t)(z + 8) * stride];
-      s2 += src[(size_t)(z + 16) * stride];
-      s3 += src[(size_t)(z + 24) * stride];
+  const int nwblk = wr_weight_blocks(K, Cin, Cout, KH, KW, layout);
+  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  constexpr int LZ = WR_MAXR * WR_PITCH + 4;       // floats per z-lane in `red`
+  if ((int)blk < nwblk && wr_tiled(Cin, Cout, KH, KW, layout)) {
+    const int taps = KH * KW, cb = wr_cb(taps), R = taps * cb;
+    const int nct = (Cout + 31) / 32;
+    const int rt = (int)blk / nct, ct = (int)blk - rt * nct;
+    const int c0 = rt * cb, co0 = ct * 32;
+    // phase 1: this wave's z-lane of the tile, rows r = tap * cb + c, 8 quads per row: 8 rows per load instruction
+    const int quad = lane & 7;
+    const bool colok = co0 + quad * 4 < Cout;
+    for (int rb = 0; rb < R; rb += 8) {
+      const int r = rb + (lane >> 3);
+      const int tap = r / cb, c = r - tap * cb;
+      const bool ok = r < R && c0 + c < Cin && colok;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+      if (ok) {
+        const float* src = part + ((size_t)tap * cin_ld + c0 + c) * Cout + co0 + quad * 4;
+        int z = zl;
+        for (; z + 12 < Z; z += 16) {          // four independent 16-byte loads in flight
+          const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)z * total);
+          const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(z + 4) * total);
+          const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(z + 8) * total);
+          const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(z + 12) * total);
+          s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+          s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+          s0.x += v2.x; s0.y += v2.y; s0.z += v2.z; s0.w += v2.w;
+          s1.x += v3.x; s1.y += v3.y; s1.z += v3.z; s1.w += v3.w;
+        }
+        for (; z < Z; z += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (size_t)z * total);
+          s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        }
+      }
+      if (r < R) {
+        float* d = red + zl * LZ + r * WR_PITCH + quad * 4;
+        d[0] = s0.x + s1.x; d[1] = s0.y + s1.y; d[2] = s0.z + s1.z; d[3] = s0.w + s1.w;
+      }
     }
-    for (; z < Z; z += 8) s0 += src[(size_t)z * stride];
+    __syncthreads();
+    // phase 2: transposed write -- entry e = (local co, j = c * taps + tap): runs of cb * taps contiguous floats per output channel
+    for (int e = threadIdx.x; e < 32 * R; e += 256) {
+      const int col = e / R, jj = e - col * R;
+      const int c = jj / taps, tap = jj - c * taps;
+      if (co0 + col < Cout && c0 + c < Cin) {
+        const int r = tap * cb + c;
+        const int a = r * WR_PITCH + col;
+        float v = ((red[a] + red[LZ + a]) + red[2 * LZ + a]) + red[3 * LZ + a];
+        const size_t o = ((size_t)(co0 + col) * Cin + c0 + c) * taps + tap;
+        v *= gscale;
+        dw[o] = accumulate ? dw[o] + v : v;
+      }
+    }
+    return;
   }
-  red[zl][tx] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (zl == 0 && (is_w || is_b)) {
-    float s = red[0][tx];
+  if ((int)blk < nwblk) {
+    // linear path: 256 consecutive slab entries, four z-lanes, scattered writes
+    const size_t q0 = (size_t)blk * WR_BLK + (size_t)lane * 4;      // first of this thread's four entries
+    const bool vec = (total & 3) == 0 && (((uintptr_t)part) & 15) == 0;
+    float4 s[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (q0 < total) {
+      if (vec) {
+        const float* src = part + q0;
+        int z = zl;
+        for (; z + 12 < Z; z += 16) {
+          float4 v[4];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) s += red[i][tx];
-    if (is_w) {
-      int co = (int)(idx - (size_t)k_ * Cout);
-      size_t o = wgrad_out_index(tap_, ci_, co, Cin, Cout, KH, KW, layout);
-      s *= gscale;
-      dw[o] = accumulate ? dw[o] + s : s;
-    } else {
-      size_t o = idx - total;
-      db[o] = accumulate ? db[o] + s : s;
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + 4 * u) * total);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s[u & 1].x += v[u].x; s[u & 1].y += v[u].y; s[u & 1].z += v[u].z; s[u & 1].w += v[u].w;
+          }
+        }
+        for (; z < Z; z += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (size_t)z * total);
+          s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+        }
+      } else {
+        for (int z = zl; z < Z; z += 4) {
+          const float* src = part + (size_t)z * total + q0;
+          s[0].x += src[0];
+          if (q0 + 1 < total) s[0].y += src[1];
+          if (q0 + 2 < total) s[0].z += src[2];
+          if (q0 + 3 < total) s[0].w += src[3];
+        }
+      }
     }
+    *reinterpret_cast<float4*>(red + zl * LZ + lane * 4) = make_float4(s[0].x + s[1].x, s[0].y + s[1].y, s[0].z + s[1].z, s[0].w + s[1].w);
+    __syncthreads();
+    const size_t idx = (size_t)blk * WR_BLK + threadIdx.x;
+    if (idx < total) {
+      const int k_ = (int)(idx / Cout);
+      const int tap_ = k_ / cin_ld, ci_ = k_ - tap_ * cin_ld;
+      if (ci_ < Cin && tap_ < KH * KW) {          // padded slab rows carry no gradient
+        float v = ((red[0 * LZ + threadIdx.x] + red[1 * LZ + threadIdx.x]) + red[2 * LZ + threadIdx.x]) + red[3 * LZ + threadIdx.x];
+        const int co = (int)(idx - (size_t)k_ * Cout);
+        const size_t o = wgrad_out_index(tap_, ci_, co, Cin, Cout, KH, KW, layout);
+        v *= gscale;
+        dw[o] = accumulate ? dw[o] + v : v;
+      }
+    }
+    return;
+  }
+  // bias entries: 256 per block, four z-lanes
+  if (!(db && dbpart)) return;
+  const size_t c = (size_t)(blk - nwblk) * WR_BLK + lane * 4;
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = zl; z < Z; z += 4) {
+    const float* src = dbpart + (size_t)z * Cout + c;
+    if (c < (size_t)Cout) sb.x += src[0];
+    if (c + 1 < (size_t)Cout) sb.y += src[1];
+    if (c + 2 < (size_t)Cout) sb.z += src[2];
+    if (c + 3 < (size_t)Cout) sb.w += src[3];
+  }
+  *reinterpret_cast<float4*>(red + zl * LZ + lane * 4) = sb;
+  __syncthreads();
+  const size_t o = (size_t)(blk - nwblk) * WR_BLK + threadIdx.x;
+  if (o < (size_t)Cout) {
+    const float v = ((red[0 * LZ + threadIdx.x] + red[1 * LZ + threadIdx.x]) + red[2 * LZ + threadIdx.x]) + red[3 * LZ + threadIdx.x];
+    db[o] = accumulate ? db[o] + v : v;
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            int Z, int K, int Cin, int Cout, int KH, int KW, int layout,
                                                            float* dw, float* db, int accumulate, float gscale) {
-  __shared__ float red[8][33];
+  __shared__ __attribute__((aligned(16))) float red[4 * (WR_MAXR * WR_PITCH + 4)];
   wgrad_reduce_body(red, part, dbpart, Z, K, Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale, blockIdx.x, 0);
 }
 
 // every slab reduce of a backward pass in ONE launch (device-resident descriptor table, like pack_program): the
 // per-layer reduces were ~70 launches of ~9 us each on the weight-gradient stream
 __global__ __launch_bounds__(256) void wgrad_reduce_program_kernel(const tpgsr_wgrad_reduce_desc* __restrict__ descs, int ndesc) {
-  __shared__ float red[8][33];
+  __shared__ __attribute__((aligned(16))) float red[4 * (WR_MAXR * WR_PITCH + 4)];
   __shared__ int s_d;
   if (threadIdx.x == 0) {
     int lo = 0, hi = ndesc - 1;  // last descriptor whose blk0 <= blockIdx.x
@@ -758,8 +865,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_program_kernel(const tpgsr_w
                     blockIdx.x - (unsigned)d.blk0, d.cin_ld);
 }
 
+/* workgroups one reduce takes (a descriptor's share of a program's grid) */
+extern "C" int tpgsr_wgrad_reduce_blocks2(int K, int Cin, int Cout, int KH, int KW, int layout, int cin_ld, int has_bias) {
+  (void)cin_ld;
+  return wr_weight_blocks(K, Cin, Cout, KH, KW, layout) + (has_bias ? cdiv(Cout, WR_BLK) : 0);
+}
+/* (legacy form: the workgroup count of a layer of which only K and Cout are known is no longer defined; kept for old callers of the
+ * single-launch tpgsr_wgrad_reduce, which sizes its own grid) */
 extern "C" int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias) {
-  return cdiv((size_t)K * Cout + (has_bias ? Cout : 0), 32);
+  return cdiv((size_t)K * Cout, WR_BLK) + (has_bias ? cdiv(Cout, WR_BLK) : 0);
 }
 
 extern "C" int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_dev, int ndesc, int total_blocks, void* stream) {
@@ -771,9 +885,9 @@ extern "C" int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_d
 extern "C" int tpgsr_wgrad_reduce(const float* part, const float* dbpart, int Z, int K, int Cin, int Cout, int KH, int KW,
                                   int layout, float* dw, float* db, int accumulate, float gscale, void* stream) {
   TPGSR_CHECK_ARG(part && dw && Z > 0 && K >= KH * KW * Cin, "tpgsr_wgrad_reduce: bad arguments");
-  size_t total = (size_t)K * Cout + ((db && dbpart) ? (size_t)Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, (hipStream_t)stream, part, dbpart, Z, K,
-                     Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale);
+  TPGSR_CHECK_ARG((((uintptr_t)part) & 15) == 0, "tpgsr_wgrad_reduce: slabs must be 16-byte aligned");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tpgsr_wgrad_reduce_blocks2(K, Cin, Cout, KH, KW, layout, 0, (db && dbpart) ? 1 : 0)), dim3(256), 0,
+                     (hipStream_t)stream, part, dbpart, Z, K, Cin, Cout, KH, KW, layout, dw, db, accumulate, gscale);
   TPGSR_LAUNCH_CHECK("tpgsr_wgrad_reduce");
 }
 

@@ -119,8 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv_panel_xbf_kernel(tpgsr_conv_args 
     kblock(S0{}, kb);
     kblock(S1{}, kb + 1);
   }
-  __syncthreads();                             // the panel is dead: its first bytes become the statistics scratch of the epilogue
-  xbf_epilogue<1, NBW>(a, acc, M, m0, 0, mblk, wm, wn, lane, tid, reinterpret_cast<float*>(psm));
+  __syncthreads();                             // the panel is dead: its first bytes become the statistics scratch of the epilogue,
+  float* red = reinterpret_cast<float*>(psm);  // then 4 KB per wave for the epilogue's transposition (the launcher sizes the LDS for both)
+  xbf_epilogue<1, NBW>(a, acc, M, m0, 0, mblk, wm, wn, lane, tid, red, red + 4 * 64 * NBW + wave * 1024);
 }
 
 static int g_panel_on = [] { const char* e = getenv("TPGSR_XBF_PANEL"); return !(e && e[0] == '0') ? 1 : 0; }();
@@ -150,7 +151,8 @@ extern "C" int tpgsr_conv_panel_xbf_launch(const tpgsr_conv_args* a, long long M
   if ((nq8 == 2 || nq8 == 3) && nb32 <= 6) nbw = 3;
   else if (nq8 == 6 && nb32 <= 2 && g_panel_k192) nbw = 1;
   else return 0;
-  const size_t lds = (size_t)T * 64 * (nq8 * 64 + 16);
+  size_t lds = (size_t)T * 64 * (nq8 * 64 + 16);
+  if (lds < (size_t)(4 * 64 * nbw + 4 * 1024) * 4) lds = (size_t)(4 * 64 * nbw + 4 * 1024) * 4;      // (epilogue scratch: statistics + staging)
   const void* fn = nullptr;
 #define PANEL_PICK(B, TT)                                                          \
   fn = nq8 == 2 ? (const void*)conv_panel_xbf_kernel<B, TT, 3, 2>                  \

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
   constexpr int BUF = T * A_PLANE;
   constexpr int NQ = BMT / 32;                    // A quads (4 consecutive k of one pixel) per thread and chunk
   constexpr bool TWO = (T == 3) && (WMB * WNB <= 2);   // separate accumulator for the correction terms (registers permitting)
-  __shared__ __attribute__((aligned(16))) unsigned char xsm[2 * BUF];
+  constexpr int EPI = (4 * 64 * WNB + 4 * 1024) * 4;      // the epilogue's scratch: BatchNorm partials + 4 KB of staging per wave
+  __shared__ __attribute__((aligned(16))) unsigned char xsm[2 * BUF > EPI ? 2 * BUF : EPI];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
         for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[TWO ? i : 0][TWO ? j : 0][r];
   }
 
-  xbf_epilogue<WMB, WNB>(a, acc, M, m0, n0, mblk, wm, wn, lane, tid, reinterpret_cast<float*>(xsm));
+  __syncthreads();      // every wave is through with the A image: it becomes the epilogue's scratch
+  xbf_epilogue<WMB, WNB>(a, acc, M, m0, n0, mblk, wm, wn, lane, tid, reinterpret_cast<float*>(xsm),
+                         reinterpret_cast<float*>(xsm) + 4 * 64 * WNB + wave * 1024);
 }
 
 // loader variants instantiated for the bf16 path (the same set as the fp32 kernel)

@@ -136,6 +136,70 @@ __device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx1
     }
   }
 }
+// ---- the same epilogue with WIDE stores.  xbf_store_tile above issues one four-byte store per accumulator register (a lane owns one
+// column of sixteen rows): 16 per 32 x 32 block, and it is the ISSUE of those stores that bounds it (1 us per block measured in the
+// whole-CU halo kernel's trace, profiles/r04l_*).  Here every wave transposes its block through 4 KB of LDS of its own -- `stage`,
+// 1024 floats per wave, wave-local: the LDS operations of one wave execute in order, no barrier -- and stores 4 x 16 bytes per lane.
+// Same values and the same BatchNorm partial sums, bit for bit (same expressions, same summation order).  Falls back to
+// xbf_store_tile for what it does not cover: pixel-shuffle stores, the BatchNorm-backward epilogue, unaligned rows.
+template <int WMB, int WNB>
+__device__ __forceinline__ void xbf_store_tile_wide(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int wm,
+                                                    int wn, int lane, float* red, float* stage) {
+  const bool fast = stage != nullptr && !a.out_ps && !a.bnb_y && (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 &&
+                    ((uintptr_t)a.out & 15) == 0;
+  if (!fast) {
+    xbf_store_tile<WMB, WNB>(a, acc, M, m0, n0, wm, wn, lane, red);
+    return;
+  }
+  constexpr int BNT = 64 * WNB;
+  const int quad = lane & 7;
+#pragma unroll
+  for (int j = 0; j < WNB; ++j) {
+    const int cloc = wn * 32 * WNB + 32 * j + (lane & 31);
+    const int n = n0 + cloc;
+    const bool nvalid = n < a.Cout;
+    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+    const int nq = n0 + wn * 32 * WNB + 32 * j + quad * 4;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const int mrow0 = m0 + wm * 32 * WMB + 32 * i;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float raw = acc[i][j][r];
+        if (m < M && nvalid) {
+          s += raw;
+          ss = __builtin_fmaf(raw, raw, ss);
+        }
+        v[r] = raw + bias;
+      }
+      if (a.out_act != TPGSR_ACT_NONE) {       // (uniform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], a.out_act);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v[r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 8 * k + (lane >> 3);
+        const int m = mrow0 + row;
+        const float4 q4 = *reinterpret_cast<const float4*>(stage + row * 32 + quad * 4);
+        if (m < M && nq < a.Cout) *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + a.out_coff + nq) = q4;
+      }
+    }
+    if (a.bn_partial) {
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * BNT + cloc] = s;
+        red[(wm * 2 + 1) * BNT + cloc] = ss;
+      }
+    }
+  }
+}
+
 // after a barrier: statistics per 64-pixel row block (the layout bn_finalize expects) out of the wave rows' partials
 template <int WMB, int WNB>
 __device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, int n0, int mblk, int tid, const float* red) {
@@ -156,10 +220,11 @@ __device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, in
     }
   }
 }
+// stage: 1024 floats of LDS per wave behind `red`'s 4 x 64 WNB floats (nullptr: four-byte stores)
 template <int WMB, int WNB>
 __device__ __forceinline__ void xbf_epilogue(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int mblk,
-                                             int wm, int wn, int lane, int tid, float* red) {
-  xbf_store_tile<WMB, WNB>(a, acc, M, m0, n0, wm, wn, lane, red);
+                                             int wm, int wn, int lane, int tid, float* red, float* stage = nullptr) {
+  xbf_store_tile_wide<WMB, WNB>(a, acc, M, m0, n0, wm, wn, lane, red, stage);
   if (a.bn_partial) {
     __syncthreads();
     xbf_bn_flush<WMB, WNB>(a, M, n0, mblk, tid, red);

@@ -695,7 +695,8 @@ def _reduce_program(items):
         d.dw, d.db = _p(dw), (_p(db) if has_b else None)
         d.Z, d.K, d.Cin, d.Cout, d.KH, d.KW, d.layout, d.accumulate, d.gscale, d.blk0 = Z, Kd, Cin, Cout, KH, KW, layout, acc, gscale, blk
         d.cin_ld = cin_ld
-        blk += lib.tpgsr_wgrad_reduce_blocks(Kd, Cout, int(has_b))
+        blk += lib.tpgsr_wgrad_reduce_blocks2(Kd, Cin, Cout, KH, KW, layout, cin_ld, int(has_b))
+        assert part.data_ptr() % 16 == 0, "weight-gradient slabs must be 16-byte aligned"
         assert dw.data_ptr() not in seen, "two deferred reduces of one program target the same gradient"
         seen.add(dw.data_ptr())
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][0].device)
