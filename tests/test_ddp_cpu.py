@@ -179,6 +179,58 @@ def test_three_buckets_launched_out_of_address_order_two_ranks():
     assert (f0 - want).abs().max() < 1e-6
 
 
+def _seven_bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tpgsr_amd.distributed import GradientExchanger
+    g = torch.Generator().manual_seed(300 + rank)
+    flat = torch.randn(2200, generator=g)
+    mine = flat.clone()
+    # the C5 step's layout (three text-prior generators behind the SR networks): per student an EARLY bucket = the generator from
+    # conv3 on (its first backward plan) and a REST bucket = the gap + its first layers (second plan).  The step runs the students'
+    # backwards last-to-first, so the launch order is 5, 6, 3, 4, 0 (SR networks: their final stage ends later), 1 and -- at finish -- 2.
+    bounds = [(0, 300), (340, 900), (300, 340), (940, 1500), (900, 940), (1540, 2200), (1500, 1540)]
+    ex = GradientExchanger(flat, bounds, None)
+    ex.begin()
+    written = torch.zeros(2200)
+    left = set()
+    for step, b in enumerate([5, 6, 3, 4, 0, 1]):
+        ex.launch(b)
+        left.add(b)
+        # "the backward passes still running" write every range that has not left yet
+        for j, (lo, hi) in enumerate(bounds):
+            if j not in left:
+                flat[lo:hi] += float(step + 1)
+                written[lo:hi] += float(step + 1)
+    ex.finish()
+    q.put((rank, mine, flat.clone(), written))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_seven_buckets_of_the_three_student_step_two_ranks():
+    """the bounds TPGSRTrainStep hands the exchanger with three text-prior generators (C5; tests/test_plan_dryrun_cpu.py pins that
+    order against the recorded plans): every student its own early bucket, all seven launched out of address order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_seven_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+    (_, a0, f0, w0), (_, a1, f1, w1) = res
+    assert torch.equal(w0, w1)
+    want = (a0 + a1) / 2 + w0
+    assert torch.equal(f0, f1)
+    assert (f0 - want).abs().max() < 1e-5
+
+
 def test_arena_pool_and_dataparallel_wrapper_cpu():
     """ArenaPool layout (contiguous, 256-byte aligned slices, SR nets before students) and the .module-exposing wrapper's
     state_dict prefix -- host logic only, no kernels (the engines bind lazily on the GPU)."""

@@ -55,6 +55,34 @@ for force in (False, True):
 assert l0 == l1, (l0, l1)
 assert torch.equal(g0, g1), float((g0 - g1).abs().max())
 assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+# three text-prior generators (the C5 shape): every student its own early bucket -- 1 + 2 * 3 buckets, launched from the
+# weight-gradient stream at the end of each plan that finishes a range (order pinned on the recorded plans by
+# tests/test_plan_dryrun_cpu.py) -- bitwise the plain step again
+res = []
+for force in (False, True):
+    sr = tsrn.TSRN_TL(STN=True, mask=True)
+    sr.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 21, tps_hw=(16, 64)))
+    srs, stus = [sr.to(dev).train()], []
+    for i in range(3):
+        stu = crnn.CRNN(32, 1, 37, 256)
+        stu.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 31 + i))
+        stus.append(stu.to(dev).train())
+    teacher = crnn.CRNN(32, 1, 37, 256)
+    teacher.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 12))
+    ts = TPGSRTrainStep(srs, stus, teacher.to(dev).eval(), stu_iter=3, sr_share=True, world_size=1, force_collectives=force)
+    ts.broadcast_parameters(0)
+    losses = [float(ts.step(lr, hr).item()) for _ in range(3)]
+    torch.cuda.synchronize()
+    if force:
+        ex = ts._exchanger()
+        assert ex.active and len(ex.bounds) == 7 and not ex._work
+        cover = sorted(ex.bounds)
+        assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), cover
+    res.append((losses, ts.pool.flat.clone(), ts.pool.grad.clone()))
+(l0, p0, g0), (l1, p1, g1) = res
+assert l0 == l1, (l0, l1)
+assert torch.equal(g0, g1), float((g0 - g1).abs().max())
+assert torch.equal(p0, p1), float((p0 - p1).abs().max())
 # the C2 driver (one flat bucket after the backward pass)
 res = []
 for force in (False, True):
