@@ -10,6 +10,7 @@ buckets, the SR bucket overlapped with the student backward], clip_grad_norm_(0.
 student -- all hand-written HIP kernels behind libtpgsr_hip.so.  `--gpus N` runs the same step data-parallel (= C4).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5]
+    python bench.py --eval [--steps K] [--warmup W]         # throughput of the evaluation pass (one GPU), its own line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
   --config c2: TSRN without text prior (BASELINE configs[1], fp32)       --config c5: stu_iter 3, sr_share, bs 32 (configs[4])
@@ -290,6 +291,97 @@ def cpu_baseline(cfg_key, seconds_budget=25.0, max_steps=6):
             "sample": f"{n} full {cfg_key.upper()} train steps (bs {B}) of oracle/tpgsr_oracle.py on the host CPU, {dt:.1f} s"}
 
 
+def build_eval(dev, stu_iter=1):
+    """the evaluation pass's networks (interfaces/super_resolution.py:540-900 / :1365-1432): eval-mode TSRN_TL + text-prior generator(s)
+    + the evaluation recogniser (`--test_model CRNN`), weights by recipe"""
+    from tpgsr_amd.interfaces.super_resolution import TextSREvaluator
+    from tpgsr_amd.model import tsrn
+    from tpgsr_amd.model.crnn import crnn
+    from tpgsr_amd.utils.synthetic import init_by_recipe
+    sr = init_by_recipe(tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 11).to(dev).eval()
+    tpgs = [init_by_recipe(crnn.CRNN(32, 1, 37, 256), 13 + k).to(dev).eval() for k in range(stu_iter)]
+    rec = init_by_recipe(crnn.CRNN(32, 1, 37, 256), 12).to(dev).eval()
+    ev = TextSREvaluator([sr], tpgs, recognizer=rec, stu_iter=stu_iter, sr_share=True, tpg_share=False)
+    # one eval batch = each generator once, the SR network stu_iter times, the recogniser three times (SR / LR / HR strings)
+    return ev, [sr] * stu_iter + tpgs + [rec] * 3
+
+
+def eval_bench(dev, steps, warmup, roofline=True, cpu=True):
+    """`bench.py --eval`: throughput of the EVALUATION pass (the reference's only printed throughput is this loop's `fps`,
+    interfaces/super_resolution.py:1373-1427).  One step = TextSREvaluator.eval_batch on a resident batch of 48: bicubic gray resize ->
+    text-prior generator -> softmax prior -> SR network (eval-mode BatchNorm folded into the consumers' loaders, STN off), PSNR + SSIM of
+    SR vs HR, CRNN recognition of SR / LR / HR with on-device CTC greedy decoding, strings compared on the host."""
+    from tpgsr_amd import kernels as K
+    B = 48
+    ev, nets = build_eval(dev)
+    lr_img, hr_img = synthetic_batch(B, 1234, dev)
+    labels = ["text%02d" % i for i in range(B)]
+    for _ in range(warmup):
+        out = ev.eval_batch(lr_img, hr_img, labels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ev.eval_batch(lr_img, hr_img, labels)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the device part alone: the SR images only (what `sr_time` brackets in the reference's loop, without its missing synchronize)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        ev.super_resolve(lr_img)
+    torch.cuda.synchronize()
+    dt_sr = time.perf_counter() - t1
+    res = {"metric": "evaluation img/s (16x64->32x128, bs=48), TPGSR-TSRN eval_batch: SR + PSNR/SSIM + CRNN strings of SR/LR/HR",
+           "value": round(B * steps / dt, 1), "unit": "img/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * dt / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": {"f32": "f32", "x3": "bf16x3", "x3b2": "bf16x3", "x2": "bf16x2", "bf16": "bf16"}[K.POLICY], "arithmetic_policy": K.POLICY,
+           "data": "synthetic",
+           "config": {"workload": "TPGSR-TSRN evaluation pass (TextSREvaluator.eval_batch), stu_iter 1, eval-mode networks, STN off, CRNN "
+                                  "evaluation recogniser, strings built on the host", "batch_per_gpu": B, "lr_hw": list(LR_HW), "hr_hw": [32, 128],
+                      "arithmetic": ARITH[K.POLICY]},
+           "super_resolve_only": {"ms_per_step": round(1e3 * dt_sr / steps, 4), "value": round(B * steps / dt_sr, 1), "unit": "img/s"},
+           "psnr": float(out["psnr"]), "ssim": float(out["ssim"])}
+    if roofline:
+        t = conv_roofline(nets)
+        tt = t["total"]
+        res["roofline"] = {"kernel": "MFMA implicit-GEMM convolution family: every conv / linear forward launch of one evaluation batch (SR network, "
+                                     "text-prior generator, recogniser x 3)", "bound": "mfma", "achieved": round(tt["tflops"], 2),
+                           "peak": round(tt["peak"], 1), "unit": "TFLOP/s", "frac": round(tt["frac"], 4), "traffic": None,
+                           "launches_per_step": tt["launches"], "gflop_per_step": round(tt["gflop"], 2),
+                           "ms_per_step_replayed": round(tt["ms"], 4), "algorithmic_bytes_per_launch": round(tt["alg_bytes"] / max(1, tt["launches"])),
+                           "per_shape": t["table"][:10]}
+    if cpu:
+        res["cpu_baseline"] = cpu_baseline_subprocess("eval")
+    return res
+
+
+def cpu_eval_baseline(seconds_budget=20.0, max_steps=40):
+    """oracle/tpgsr_oracle.py's tpgsr_eval_step (a port of the reference's evaluation branch) on the host cores, same batch"""
+    from oracle import tpgsr_oracle as O
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncores, 64)))
+    B = 48
+    lr, hr = O.synthetic_batch(B, 1234)
+    ps = O.as_params(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 11, tps_hw=LR_HW), False)
+    pt = O.as_params(O.recipe_state_dict(O.crnn_spec(), 13), False)
+    pr = O.as_params(O.recipe_state_dict(O.crnn_spec(), 12), False)
+    with torch.no_grad():
+        O.tpgsr_eval_step([ps], [pt], pr, lr, hr)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.tpgsr_eval_step([ps], [pt], pr, lr, hr)
+            n += 1
+            if time.perf_counter() - t0 > seconds_budget or n >= max_steps:
+                break
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 2), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} evaluation batches (bs {B}) of oracle/tpgsr_oracle.py tpgsr_eval_step on the host CPU, {dt:.1f} s"}
+
+
 def main():
     # ONE JSON line on stdout and nothing else: libraries write there too (RCCL prints a version banner when the process exits, gloo its
     # connection messages), so the descriptor the line goes to is kept aside and fd 1 is pointed at stderr for everybody else
@@ -300,7 +392,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + ["eval"], default="c3")
     ap.add_argument("--prec", choices=["f32", "x3", "x3b2", "x2", "bf16"], default=None,
                     help="arithmetic of the MFMA GEMMs, see tpgsr_amd/kernels.py (default: TPGSR_CONV_PREC if set, else x2 -- BASELINE.json quotes "
                          "this configuration in bf16; x2 = two bf16 terms per operand holds the north_star gates, tests/test_policy_x2_gpu.py)")
@@ -314,9 +406,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic (~1 min)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--eval", action="store_true", help="time the EVALUATION pass instead (TextSREvaluator.eval_batch, bs 48, one GPU): its own "
+                                                        "JSON line with its own roofline; the training line carries a short `eval` key either way")
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.config)), file=line_out, flush=True)
+        print(json.dumps(cpu_eval_baseline() if args.config == "eval" else cpu_baseline(args.config)), file=line_out, flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -352,6 +446,12 @@ def main():
     K.set_conv_prec(args.prec or os.environ.get("TPGSR_CONV_PREC") or "x2")
     global K_POLICY
     K_POLICY = K.POLICY
+    if args.eval or args.config == "eval":
+        if world > 1:
+            raise SystemExit("bench.py --eval is a one-GPU measurement (the evaluation pass has no exchange step: N ranks = N replicas)")
+        res = eval_bench(dev, args.steps, args.warmup, roofline=not args.no_roofline, cpu=not args.no_cpu_baseline)
+        print(json.dumps(res), file=line_out, flush=True)
+        return
     cfg = CONFIGS[args.config]
     B = cfg["batch"]
     torch.manual_seed(0)
@@ -465,6 +565,11 @@ def main():
                                                     "ms_per_step_replayed": round(t2["ms"], 4)}
             K.set_conv_prec(K_POLICY)
             del ts2, _nets2
+        if world == 1 and not args.no_roofline:
+            # the evaluation pass of the same networks (north_star: "training/inference path"): a short measurement, the full line with its
+            # own roofline is `bench.py --eval`
+            e = eval_bench(dev, 30, 8, roofline=False, cpu=False)
+            out["eval"] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "super_resolve_only")}
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args.config)

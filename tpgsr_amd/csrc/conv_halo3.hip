@@ -356,9 +356,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
     // BatchNorm-backward epilogue, 16-byte aligned rows: every wave transposes its 32 x 32 block through 4 KB of LDS of its own
     // (wave-local: LDS operations of one wave execute in order, no barrier) and stores 4 x 16 bytes per lane and tile; bias,
     // activation and the BatchNorm statistics exactly as xbf_store_tile computes them (same values, same summation order).
-    const bool fast = !a.out_ps && !a.bnb_y && (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && ((uintptr_t)a.out & 15) == 0;
+    const bool bnb = a.bnb_y != nullptr;
+    const bool fast = !a.out_ps && (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_coff & 3) == 0 && ((uintptr_t)a.out & 15) == 0 &&
+                      (!bnb || ((uintptr_t)a.bnb_y & 15) == 0);
     const bool full3 = m0 + 64 * (H3_TM - 1) < M;
-    if (fast && a.out_act == TPGSR_ACT_NONE && full3) {
+    if (fast && !bnb && a.out_act == TPGSR_ACT_NONE && full3) {
       // the common case (every trunk convolution): three tiles through TWO staging slots per wave, so a tile's 16 LDS writes overlap
       // the previous tile's reads and wide stores (LDS operations of one wave execute in order: slot 0 is rewritten by tile 2 only
       // behind tile 0's reads)
@@ -412,6 +414,33 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
     // ONE copy of the general epilogue code, looped over the three tiles (the accumulator is selected: 32 moves): unrolled three times,
     // with both paths and the run-time activation switch, the epilogue was 20 000 of the kernel's 25 000 instructions -- and a
     // one-round kernel runs every instruction out of a cold instruction cache
+    // BatchNorm-backward epilogue (every data gradient of the trunk): the BatchNorm input y comes in as 4 x 16 bytes per lane and tile
+    // (one tile ahead), goes through the wave's staging block the other way round -- written row-major, read back in accumulator
+    // order -- and the gradient leaves as in the plain case; xbf_bnb_elem is the arithmetic of xbf_store_tile, element for element
+    const int cloc = wn * 32 + (lane & 31), n = n0 + cloc;
+    const bool nvalid = n < a.Cout;
+    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+    const int quad = lane & 7, nq = n0 + wn * 32 + quad * 4;
+    float b_mu = 0.f, b_rs = 0.f, b_sc = 1.f, b_sh = 0.f;
+    if (bnb && nvalid) {
+      if (a.bn_partial) {
+        b_mu = a.bnb_mean[n];
+        b_rs = a.bnb_rstd[n];
+      }
+      if (a.bnb_act && a.bnb_scale) {
+        b_sc = a.bnb_scale[n];
+        b_sh = a.bnb_shift[n];
+      }
+    }
+    float4 yq[4];
+    auto load_y = [&](const int m, float4 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int mm = m0 + 64 * m + wm * 32 + 8 * k + (lane >> 3);
+        dst[k] = (mm < M && nq < a.Cout) ? *reinterpret_cast<const float4*>(a.bnb_y + (size_t)mm * a.Cout + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    if (bnb && fast) load_y(0, yq);
 #pragma clang loop unroll(disable)
     for (int m = 0; m < H3_TM; ++m) {
       if (m0 + 64 * m >= M) break;        // (uniform) a ragged last super-tile: tiles past the end have nothing to store
@@ -423,20 +452,31 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
         xbf_store_tile<1, 1>(a, tile, M, m0 + 64 * m, n0, wm, wn, lane, red);
         continue;
       }
-      const int cloc = wn * 32 + (lane & 31), n = n0 + cloc;
-      const bool nvalid = n < a.Cout;
-      const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
       float* stg = stage_base + wave * 2048;
+      float yv[16];
+      float4 ynx[4];
+      if (bnb) {
+        if (m + 1 < H3_TM) load_y(m + 1, ynx);      // (rows past the end load nothing)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(stg + (8 * k + (lane >> 3)) * 32 + quad * 4) = yq[k];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)];
+      }
       float sum = 0.f, sq = 0.f;
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int mm = m0 + 64 * m + wm * 32 + row;
-        const float raw = tile[0][0][r];
+        float raw = tile[0][0][r];
         if (mm < M && nvalid) {
-          sum += raw;
-          sq = __builtin_fmaf(raw, raw, sq);
+          if (bnb) {
+            const float dz = xbf_bnb_elem(raw, yv[r], b_sc, b_sh, b_mu, b_rs, a.bnb_act, sum, sq);
+            if (a.bnb_store_dz) raw = dz;
+          } else {
+            sum += raw;
+            sq = __builtin_fmaf(raw, raw, sq);
+          }
         }
         v[r] = raw + bias;
       }
@@ -454,13 +494,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
           red[(wm * 2 + 1) * 64 + cloc] = sq;
         }
       }
-      const int quad = lane & 7, nq = n0 + wn * 32 + quad * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = 8 * k + (lane >> 3);
         const int mm = m0 + 64 * m + wm * 32 + row;
         const float4 q4 = *reinterpret_cast<const float4*>(stg + row * 32 + quad * 4);
         if (mm < M && nq < a.Cout) *reinterpret_cast<float4*>(a.out + (size_t)mm * a.out_ld + a.out_coff + nq) = q4;
+      }
+      if (bnb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yq[k] = ynx[k];
       }
     }
     }

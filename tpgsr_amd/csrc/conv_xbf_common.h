@@ -61,6 +61,16 @@ __device__ __forceinline__ floatx16 mfma_terms(const bf16x8 (&a)[T], const bf16x
 #ifndef XBF_NT_STORE
 #define XBF_NT_STORE 0
 #endif
+// one element of the BatchNorm-backward epilogue (tpgsr_conv_args.bnb_y): dz = the activation backward of the gradient `raw` this launch
+// produced, s += dz, ss += dz * xhat.  ONE definition with explicit fused multiply-adds for every copy of the epilogue (the
+// whole-CU halo kernel has its own store path): under -ffp-contract=fast two copies of `ss += dz * (y - mu) * rs` may round differently.
+__device__ __forceinline__ float xbf_bnb_elem(float raw, float y, float sc, float sh, float mu, float rs, int act, float& s, float& ss) {
+  const float dz = act ? raw * act_grad(__builtin_fmaf(y, sc, sh), act) : raw;
+  s += dz;
+  ss = __builtin_fmaf(dz * (y - mu), rs, ss);
+  return dz;
+}
+
 template <int WMB, int WNB>
 __device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx16 (&acc)[WMB][WNB], int M, int m0, int n0, int wm,
                                                int wn, int lane, float* red) {
@@ -104,9 +114,7 @@ __device__ __forceinline__ void xbf_store_tile(const tpgsr_conv_args& a, floatx1
         if (m < M && nvalid) {
           float raw = acc[i][j][r];
           if (bnb) {
-            const float dz = a.bnb_act ? raw * act_grad(yv[r] * b_sc + b_sh, a.bnb_act) : raw;
-            s += dz;
-            ss += dz * (yv[r] - b_mu) * b_rs;
+            const float dz = xbf_bnb_elem(raw, yv[r], b_sc, b_sh, b_mu, b_rs, a.bnb_act, s, ss);
             if (a.bnb_store_dz) raw = dz;
           } else {
             s += raw;
