@@ -351,6 +351,8 @@ int tpgsr_bigru_bwd(const float* gates, const float* h_out, const float* dh_out,
  * the r and z planes of dgh equal dgi's, and tpgsr_gru_wgrad reads them there. */
 int tpgsr_bigru_bwd2(const float* gates, const float* h_out, const float* dh_out, const float* dh_out2,
                      const float* w_hh, int N, int H, int W, int axis, float* dgi, float* dghn, void* stream);
+/* test hook: the recurrence's own sigmoid / tanh (csrc/gru.hip: compensated v_exp_f32, v_rcp_f32 + one Newton step) over n values */
+int tpgsr_gru_gate_math_probe(const float* x, float* sg, float* th, int n, void* stream);
 /* ALL weight gradients of one GruBlock in one launch (csrc/gru_wgrad.hip; model/tsrn.py:491-508, the backward pass of GruBlock.forward):
  *   c      the A side of the composed 1x1 projection gi = loader(x) Wc^T + bc, as tpgsr_conv_args (in / in_ld / in_coff, optional
  *          in_scale + in_shift, in2 (residual add) or in_b (concatenated [N][W][Cb] strip, cin_a); N, H, W, Cin = 64 | 96, Cout = 192,

@@ -130,6 +130,7 @@ _SIGS = {
     "tpgsr_bigru_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     "tpgsr_bigru_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     "tpgsr_bigru_bwd2": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "tpgsr_gru_gate_math_probe": (ci, [vp, vp, vp, ci, vp]),
     "tpgsr_gru_wgrad_splits": (ci, [ll]),
     "tpgsr_gru_wgrad": (ci, [C.POINTER(GruWgradArgs), vp]),
     "tpgsr_tps_grid_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),

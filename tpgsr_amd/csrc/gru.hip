@@ -16,8 +16,8 @@
 // one wavefront per workgroup: the per-step barrier degenerates to wave-local ordering
 
 struct SeqGeom {
-  long long base;    // pixel index of t = 0
-  long long stride;  // pixel stride between time steps
+  int base;    // pixel index of t = 0 (32-bit: the launchers bound N H W 256 by 2^31 -- 64-bit multiplies were ~20 instructions of a step)
+  int stride;  // pixel stride between time steps
   int T;
   bool active;
 };
@@ -28,16 +28,62 @@ __device__ __forceinline__ SeqGeom seq_geom(int s, int N, int H, int W, int axis
   g.active = s < nseq;
   if (!g.active) s = 0;
   if (axis == 0) {
-    g.base = (long long)s * W;
+    g.base = s * W;
     g.stride = 1;
     g.T = W;
   } else {
     int n = s / W, col = s - n * W;
-    g.base = (long long)n * H * W + col;
+    g.base = n * H * W + col;
     g.stride = W;
     g.T = H;
   }
   return g;
+}
+
+// Gate functions of the recurrence.  A time step is ONE dependent instruction stream per wave (a step of the W-axis scan runs with at most
+// one wave per SIMD), so its length in instructions is its latency: libm's expf + expm1f + three IEEE divisions were ~110 of the ~190
+// instructions of a step.  These keep libm-level accuracy in a third of that:
+//   e^x   = v_exp_f32(t) * (1 + ln2 * lo),  t = fl(x log2e), lo = the exact rounding error of t + x * (log2e - fl(log2e))   (6 instructions;
+//           the bare v_exp_f32(x * log2e) loses |x| * 6e-8 relative -- common.h's note on what that did to the text-prior gradient)
+//   1 / d = v_rcp_f32 + one Newton step (3 instructions, <= 1 ulp)
+//   tanh  = x * P(x^2) for |x| < 0.35 (odd Taylor polynomial to x^11: 5e-9 relative), (1 - q) / (1 + q) with q = e^(-2|x|) elsewhere
+// Checked against fp64 over the gates' range by tests/test_gru_gate_math_gpu.py: worst case 3.5 ulp (sigmoid) / 4.5 ulp (tanh, where
+// 1 - q cancels one bit), against 2 ulp of the libm path; mean error 0.4 ulp either way.
+__device__ __forceinline__ float gru_exp(float x) {
+  const float t = x * 1.44269504088896341f;
+  float lo = __builtin_fmaf(x, 1.44269504088896341f, -t);
+  lo = __builtin_fmaf(x, 1.925963033500011e-08f, lo);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float gru_rcp(float d) {      // d finite, |d| in [2^-126, 2^126]
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+}
+__device__ __forceinline__ float gru_sigmoid(float x) { return gru_rcp(1.f + gru_exp(fminf(-x, 80.f))); }
+__device__ __forceinline__ float gru_tanh(float x) {
+  const float q = gru_exp(-2.f * fabsf(x));
+  const float big = (1.f - q) * gru_rcp(1.f + q);
+  const float x2 = x * x;
+  float p = __builtin_fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
+  p = __builtin_fmaf(x2, p, -17.f / 315.f);
+  p = __builtin_fmaf(x2, p, 2.f / 15.f);
+  p = __builtin_fmaf(x2, p, -1.f / 3.f);
+  p = __builtin_fmaf(x2, p, 1.f);
+  return fabsf(x) < 0.35f ? x * p : copysignf(big, x);
+}
+extern "C" __global__ void gru_gate_math_probe_kernel(const float* x, float* sg, float* th, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    sg[i] = gru_sigmoid(x[i]);
+    th[i] = gru_tanh(x[i]);
+  }
+}
+/* test hook (tests/test_gru_gate_math_gpu.py): the recurrence's sigmoid / tanh over n values */
+extern "C" int tpgsr_gru_gate_math_probe(const float* x, float* sg, float* th, int n, void* stream) {
+  TPGSR_CHECK_ARG(x && sg && th && n > 0, "tpgsr_gru_gate_math_probe: bad arguments");
+  hipLaunchKernelGGL(gru_gate_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, sg, th, n);
+  TPGSR_LAUNCH_CHECK("tpgsr_gru_gate_math_probe");
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -49,14 +95,17 @@ __device__ __forceinline__ f2 mk2(float x, float y) {
   return v;
 }
 
-template <int PF>
+// EXACT: T is a multiple of PF (both scan lengths of the 16 x 64 map with the default PF = 8): no per-step bounds tests, the ring's
+// refill is switched off per group of PF steps.  Offsets are running 32-bit element indices advanced by a constant per step.
+template <int PF, bool EXACT>
 __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                         const float* __restrict__ b_hh, int N, int H, int W, int axis,
                                                         float* __restrict__ h_out, float* __restrict__ gates) {
-  __shared__ __attribute__((aligned(16))) float hs[2][64];   // double-buffered by step parity: one barrier per step
+  __shared__ __attribute__((aligned(16))) float hs[2][64];   // double-buffered by step parity
   const int lane = threadIdx.x & 63;
   const int d = lane >> 5, j = lane & 31;
-  SeqGeom g = seq_geom(blockIdx.x, N, H, W, axis);
+  const SeqGeom g = seq_geom(blockIdx.x, N, H, W, axis);
+  if (!g.active) return;        // (one wave per workgroup: nobody waits for it)
   // row j of W_hr / W_hz interleaved (one packed FMA feeds both gates), row j of W_hn as k-pairs
   f2 wrz[GRU_H], wn2[GRU_H / 2];
   {
@@ -71,36 +120,38 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
   const float br = b_hh[d * 96 + j], bz = b_hh[d * 96 + 32 + j], bn = b_hh[d * 96 + 64 + j];
   float h = 0.f;
   hs[0][lane] = 0.f;
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order; this only pins the compiler's order
   const int T = g.T;
-  auto pix_of = [&](int step) { return g.base + (long long)(d == 0 ? step : T - 1 - step) * g.stride; };
+  const int dpix = d == 0 ? g.stride : -g.stride;                 // pixel step in the direction's own scan order
+  int pix = g.base + (d == 0 ? 0 : (T - 1) * g.stride);           // pixel of the current step
+  int fpix = pix;                                                 // pixel of the next step to fetch
   // The input projections do not depend on the recurrence: they are fetched PF steps ahead through a small register ring.  One
-  // step of look-ahead (a serial step is ~600 cycles) left the wave waiting on memory in EVERY step whenever a load took longer
-  // than that -- i.e. always, next to the other kernels of the training step (the backward kernel below learnt this first).
+  // step of look-ahead left the wave waiting on memory in EVERY step whenever a load took longer than a step -- i.e. always, next to
+  // the other kernels of the training step (the backward kernel below learnt this first).
   struct StepIn {
     float r, z, n;
   };
-  auto fetch = [&](int step) {
-    StepIn s = {0.f, 0.f, 0.f};
-    if (!g.active || step >= T) return s;
-    const float* p = gi + pix_of(step) * 192 + d * 96 + j;
+  auto fetch = [&]() __attribute__((always_inline)) {
+    StepIn s;
+    const float* p = gi + fpix * 192 + d * 96 + j;
     s.r = p[0]; s.z = p[32]; s.n = p[64];
+    fpix += dpix;
     return s;
   };
   StepIn ring[PF];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) ring[i] = fetch(i);
+  for (int i = 0; i < PF; ++i) ring[i] = (EXACT || i < T) ? fetch() : StepIn{0.f, 0.f, 0.f};
   for (int base = 0; base < T; base += PF) {
+    const bool more = base + PF < T;               // (EXACT) the next group exists: refill the ring
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int step = base + i;
-      if (step >= T) break;                       // wave-uniform
-      const long long pix = pix_of(step);
+      if (!EXACT && step >= T) break;             // wave-uniform
       const StepIn c = ring[i];
-      ring[i] = fetch(step + PF);
-      // W_hh h: six independent packed-FMA chains, 8 deep (the recurrence is latency-bound: one wave per SIMD)
+      if (EXACT ? more : step + PF < T) ring[i] = fetch();
+      // W_hh h: six independent packed-FMA chains, 8 deep
       f2 a0 = mk2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, n0 = a0, n1 = a0;
-      const float4* hp = reinterpret_cast<const float4*>(&hs[step & 1][d * 32]);
+      const float4* hp = reinterpret_cast<const float4*>(&hs[i & 1][d * 32]);      // (PF is even: step parity = i parity)
 #pragma unroll
       for (int k = 0; k < GRU_H / 4; ++k) {
         const float4 hv = hp[k];
@@ -113,19 +164,18 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
       }
       const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
       const float an = bn + (nn.x + nn.y);
-      const float r = sigmoid_f(c.r + (br + rz.x));
-      const float z = sigmoid_f(c.z + (bz + rz.y));
-      const float n = tanh_f(c.n + r * an);
+      const float r = gru_sigmoid(c.r + (br + rz.x));
+      const float z = gru_sigmoid(c.z + (bz + rz.y));
+      const float n = gru_tanh(c.n + r * an);
       h = (1.f - z) * n + z * h;
-      hs[(step + 1) & 1][lane] = h;
-      if (g.active) {
-        h_out[pix * 64 + d * 32 + j] = h;
-        if (gates) {
-          float* q = gates + pix * 256 + d * 128 + j;
-          q[0] = r; q[32] = z; q[64] = n; q[96] = an;
-        }
+      hs[(i + 1) & 1][lane] = h;
+      h_out[pix * 64 + d * 32 + j] = h;
+      if (gates) {
+        float* q = gates + pix * 256 + d * 128 + j;
+        q[0] = r; q[32] = z; q[64] = n; q[96] = an;
       }
-      __syncthreads();
+      pix += dpix;
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -139,12 +189,20 @@ extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* 
                                float* h_out, float* gates, void* stream) {
   TPGSR_CHECK_ARG(gi && w_hh && b_hh && h_out, "tpgsr_bigru_fwd: null pointer");
   TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "tpgsr_bigru_fwd: bad geometry");
+  TPGSR_CHECK_ARG((long long)N * H * W * 256 < (1ll << 31), "tpgsr_bigru_fwd: map too large for the kernel's 32-bit indices");
   int nseq = axis == 0 ? N * H : N * W;
+  const int T = axis == 0 ? W : H;
+#define GRU_FWD_CASE(PF)                                                                                                          \
+  if (T % PF == 0)                                                                                                                \
+    hipLaunchKernelGGL((bigru_fwd_kernel<PF, true>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); \
+  else                                                                                                                            \
+    hipLaunchKernelGGL((bigru_fwd_kernel<PF, false>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates);
   switch (g_gru_pf) {
-    case 4: hipLaunchKernelGGL(bigru_fwd_kernel<4>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); break;
-    case 12: hipLaunchKernelGGL(bigru_fwd_kernel<12>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); break;
-    default: hipLaunchKernelGGL(bigru_fwd_kernel<8>, dim3(nseq), dim3(64), 0, (hipStream_t)stream, gi, w_hh, b_hh, N, H, W, axis, h_out, gates); break;
+    case 4: GRU_FWD_CASE(4) break;
+    case 12: GRU_FWD_CASE(12) break;
+    default: GRU_FWD_CASE(8) break;
   }
+#undef GRU_FWD_CASE
   TPGSR_LAUNCH_CHECK("tpgsr_bigru_fwd");
 }
 
@@ -156,7 +214,7 @@ extern "C" int tpgsr_bigru_fwd(const float* gi, const float* w_hh, const float* 
 // ------------------------------------------------------------------------------------------------------
 // COMPACT: `dgh` is [P][64] and receives only what differs from dgi -- the n gate's hidden-side gradient dn_pre * r of both directions
 // (the r and z planes of dgh ARE dgi's: the fused GruBlock weight-gradient kernel, gru_wgrad.hip, reads them there)
-template <int PF, bool COMPACT>
+template <int PF, bool COMPACT, bool EXACT>
 __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ h_out,
                                                         const float* __restrict__ dh_out, const float* __restrict__ dh_out2,
                                                         const float* __restrict__ w_hh, int N, int H, int W, int axis,
@@ -165,7 +223,8 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
   __shared__ __attribute__((aligned(16))) float g_n[2][64];       // [parity][dir*32 + i] = dn_pre_i * r_i
   const int lane = threadIdx.x & 63;
   const int d = lane >> 5, j = lane & 31;
-  SeqGeom g = seq_geom(blockIdx.x, N, H, W, axis);
+  const SeqGeom g = seq_geom(blockIdx.x, N, H, W, axis);
+  if (!g.active) return;
   // column j of W_hr / W_hz interleaved, column j of W_hn as row pairs: dh_prev[j] = sum_i W[i][j] * dgate[i]
   f2 trz[GRU_H], tn2[GRU_H / 2];
 #pragma unroll
@@ -176,47 +235,50 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
     tn2[i] = mk2(w_hh[((size_t)(d * 96 + 2 * 32 + 2 * i)) * GRU_H + j], w_hh[((size_t)(d * 96 + 2 * 32 + 2 * i + 1)) * GRU_H + j]);
   const int T = g.T;
   float dh_carry = 0.f;
-  // operands of one step, prefetched one step ahead so the global loads never sit on the serial dependency chain
+  // steps run from the direction's LAST step to its first; dpix = pixel step in that order (the previous state sits one step further)
+  const int dpix = d == 0 ? -g.stride : g.stride;
+  int pix = g.base + (d == 0 ? (T - 1) * g.stride : 0);
+  int fpix = pix, fstep = T - 1;
+  // operands of one step: they do not depend on the recurrence, so they are fetched PF steps ahead through a small register ring (next
+  // to the weight-gradient GEMMs of the side stream a load takes several times its idle latency)
   struct StepIn {
-    float hprev, r, z, n, an, dho;
+    float hprev, r, z, n, an, dho, dho2;
   };
-  auto fetch = [&](int step) {
-    StepIn s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!g.active || step < 0) return s;
-    const int t = d == 0 ? step : T - 1 - step;
-    const int tprev = d == 0 ? t - 1 : t + 1;
-    const long long pix = g.base + (long long)t * g.stride;
-    if (step > 0) s.hprev = h_out[(g.base + (long long)tprev * g.stride) * 64 + d * 32 + j];
-    const float* p = gates + pix * 256 + d * 128 + j;
+  auto fetch = [&]() __attribute__((always_inline)) {
+    StepIn s;
+    s.hprev = 0.f;
+    s.dho2 = 0.f;
+    if (fstep > 0) s.hprev = h_out[(fpix + dpix) * 64 + d * 32 + j];
+    const float* p = gates + fpix * 256 + d * 128 + j;
     s.r = p[0]; s.z = p[32]; s.n = p[64]; s.an = p[96];
-    s.dho = dh_out[pix * 64 + d * 32 + j];
-    if (dh_out2) s.dho += dh_out2[pix * 64 + d * 32 + j];
+    s.dho = dh_out[fpix * 64 + d * 32 + j];
+    // (added at the step that consumes it: `s.dho += ...` here made every step wait for ALL its outstanding loads and stores --
+    //  one full memory round trip per time step in every launch with a second gradient, the look-ahead ring notwithstanding)
+    if (dh_out2) s.dho2 = dh_out2[fpix * 64 + d * 32 + j];
+    fpix += dpix;
+    --fstep;
     return s;
   };
-  // The operands do not depend on the recurrence, so they are fetched PF steps ahead through a small register ring: next
-  // to the weight-gradient GEMMs of the side stream a load takes several times its idle latency, and one step of
-  // look-ahead (the whole serial step is ~550 cycles) left the wave waiting on memory every step (75 us vs 35 us alone).
   StepIn ring[PF];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) ring[i] = fetch(T - 1 - i);
+  for (int i = 0; i < PF; ++i) ring[i] = (EXACT || i < T) ? fetch() : StepIn{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int base = T - 1; base >= 0; base -= PF) {
+    const bool more = base - PF >= 0;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int step = base - i;                 // `step` = position in the direction's own forward order
-      if (step < 0) break;                       // wave-uniform
-      const int t = d == 0 ? step : T - 1 - step;
-      const long long pix = g.base + (long long)t * g.stride;
+      if (!EXACT && step < 0) break;             // wave-uniform
       const StepIn c = ring[i];
-      ring[i] = fetch(step - PF);
-      const float dh = dh_carry + c.dho;
+      if (EXACT ? more : step - PF >= 0) ring[i] = fetch();
+      const float dh = dh_carry + (c.dho + c.dho2);
       const float dn_pre = dh * (1.f - c.z) * (1.f - c.n * c.n);
       const float dz_pre = dh * (c.hprev - c.n) * c.z * (1.f - c.z);
       const float dr_pre = dn_pre * c.an * c.r * (1.f - c.r);
       const float dghn = dn_pre * c.r;
-      const int par = step & 1;
+      const int par = i & 1;                     // (PF is even; only the alternation matters)
       *reinterpret_cast<float2*>(&g_rz[par][d][2 * j]) = make_float2(dr_pre, dz_pre);
       g_n[par][lane] = dghn;
-      if (g.active) {
+      {
         float* q = dgi + pix * 192 + d * 96 + j;
         q[0] = dr_pre; q[32] = dz_pre; q[64] = dn_pre;
         if (COMPACT) {
@@ -226,7 +288,8 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
           q2[0] = dr_pre; q2[32] = dz_pre; q2[64] = dghn;
         }
       }
-      __syncthreads();   // the parity double buffer orders the next step's writes behind this step's reads
+      pix += dpix;
+      __builtin_amdgcn_wave_barrier();   // one wave: its LDS operations execute in order; the parity double buffer is kept anyway
       const float4* prz = reinterpret_cast<const float4*>(&g_rz[par][d][0]);
       const float4* pn = reinterpret_cast<const float4*>(&g_n[par][d * 32]);
       f2 c0 = mk2(0.f, 0.f), c1 = c0, c2 = c0, c3 = c0, e0 = c0, e1 = c0;
@@ -251,12 +314,20 @@ static int bigru_bwd_launch(const float* gates, const float* h_out, const float*
                             int H, int W, int axis, float* dgi, float* dgh, void* stream, const char* who) {
   TPGSR_CHECK_ARG(gates && h_out && dh_out && w_hh && dgi && dgh, "%s: null pointer", who);
   TPGSR_CHECK_ARG(N > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1), "%s: bad geometry", who);
+  TPGSR_CHECK_ARG((long long)N * H * W * 256 < (1ll << 31), "%s: map too large for the kernel's 32-bit indices", who);
   int nseq = axis == 0 ? N * H : N * W;
+  const int T = axis == 0 ? W : H;
+#define GRU_BWD_CASE(PF)                                                                                                          \
+  if (T % PF == 0)                                                                                                                \
+    hipLaunchKernelGGL((bigru_bwd_kernel<PF, COMPACT, true>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); \
+  else                                                                                                                            \
+    hipLaunchKernelGGL((bigru_bwd_kernel<PF, COMPACT, false>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh);
   switch (g_gru_pf) {
-    case 4: hipLaunchKernelGGL((bigru_bwd_kernel<4, COMPACT>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
-    case 12: hipLaunchKernelGGL((bigru_bwd_kernel<12, COMPACT>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
-    default: hipLaunchKernelGGL((bigru_bwd_kernel<8, COMPACT>), dim3(nseq), dim3(64), 0, (hipStream_t)stream, gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh); break;
+    case 4: GRU_BWD_CASE(4) break;
+    case 12: GRU_BWD_CASE(12) break;
+    default: GRU_BWD_CASE(8) break;
   }
+#undef GRU_BWD_CASE
   TPGSR_LAUNCH_CHECK(who);
 }
 

@@ -36,6 +36,16 @@ def _new(like, *shape):
     return torch.empty(*shape, dtype=F32, device=like.device)
 
 
+# Parameter-gradient sinks (engine_functional.py, recorded mode): data_ptr of a parameter -> the fp32 buffer its gradient is ACCUMULATED
+# into by the operator's own backward kernels (the slab reduce / the BatchNorm-backward finalize with accumulate = 1).  The backward then
+# hands autograd `None` for that parameter: no AccumulateGrad node runs, i.e. no ATen `add_` that a recorded plan could not replay.
+GRAD_SINK: dict = {}
+
+
+def _sink(p):
+    return GRAD_SINK.get(p.data_ptr()) if (GRAD_SINK and p is not None) else None
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -119,6 +129,7 @@ class _Conv2d(torch.autograd.Function):
         K.conv_fwd(K.make_conv_args(g, x, wt_f, out, bias=b, out_ps=out_ps))
         ctx.save_for_backward(x, w, wt_d)
         ctx.cfg = (g, out_ps, transposed, wscale, b is not None)
+        ctx.bias_sink = _sink(b)
         return out
 
     @staticmethod
@@ -134,10 +145,17 @@ class _Conv2d(torch.autograd.Function):
             Z = K.wgrad_splits(g.M, g.K, g.Cout, geom=g)
             part = _new(x, Z, g.K, g.Cout)
             dbp = _new(x, Z, g.Cout) if has_b else None
-            K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, dbp, dy_ps=out_ps, zsplits=Z))
-            dw = torch.empty_like(w)
-            db = _new(x, g.Cout) if has_b else None
-            K.wgrad_reduce(part, dbp, Z, g, dw, db, layout=1 if transposed else 0, accumulate=False, gscale=wscale)
+            sw = _sink(w)
+            with K.side():      # a leaf of the graph: on the weight-gradient stream when a recorded plan overlaps them (no-op eagerly)
+                K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, dbp, dy_ps=out_ps, zsplits=Z))
+                if sw is not None:
+                    sb = ctx.bias_sink if has_b else None
+                    assert not has_b or sb is not None, "a sunk weight gradient needs its bias gradient sunk too"
+                    K.wgrad_reduce(part, dbp, Z, g, sw, sb, layout=1 if transposed else 0, accumulate=True, gscale=wscale)
+                else:
+                    dw = torch.empty_like(w)
+                    db = _new(x, g.Cout) if has_b else None
+                    K.wgrad_reduce(part, dbp, Z, g, dw, db, layout=1 if transposed else 0, accumulate=False, gscale=wscale)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -246,6 +264,7 @@ class _BatchNorm(torch.autograd.Function):
         K.affine_act(x, M, C, scale, shift, act, out)
         ctx.save_for_backward(x, gamma, scale, shift, mean, rstd)
         ctx.cfg = (training, act, M, C)
+        ctx.beta_sink = _sink(beta)
         return out
 
     @staticmethod
@@ -259,9 +278,15 @@ class _BatchNorm(torch.autograd.Function):
         nblk = max(1, min(1024, M // 64))
         part = torch.empty(nblk, 2, C, device=dev)
         coef = torch.empty(3, C, device=dev)
-        dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        sg, sb = _sink(gamma), ctx.beta_sink
         K.bn_bwd_reduce(dy, None, x, M, C, scale, shift, mean, rstd, act, part, nblk)
-        K.bn_bwd_finalize(part, nblk, C, M, gamma, mean, rstd, dgamma, dbeta, coef, accumulate=False)
+        if sg is not None:
+            assert sb is not None, "a sunk BatchNorm weight gradient needs its bias gradient sunk too"
+            dgamma = dbeta = None
+            K.bn_bwd_finalize(part, nblk, C, M, gamma, mean, rstd, sg, sb, coef, accumulate=True)
+        else:
+            dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            K.bn_bwd_finalize(part, nblk, C, M, gamma, mean, rstd, dgamma, dbeta, coef, accumulate=False)
         dx = torch.empty_like(x)
         K.bn_bwd_apply(dy, None, x, M, C, scale, shift, act, coef, dx)
         return dx, dgamma, dbeta, None, None, None, None, None, None
@@ -269,7 +294,7 @@ class _BatchNorm(torch.autograd.Function):
 
 def batch_norm(x, bn, training: bool, act: Optional[str] = None):
     """bn: a BatchNormParams holder (weight, bias, running_mean, running_var, momentum, eps); act fused: 'relu' | 'mish' | None"""
-    if training:
+    if training and K._REC is None:      # (a recorded plan's engine counts its replays: engine_functional.py flush_counters)
         bn.num_batches_tracked += 1
     return _BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training), bn.momentum, bn.eps, act)
 
@@ -351,6 +376,28 @@ class _Add(torch.autograd.Function):
 
 def add(a, b):
     return _Add.apply(a, b)
+
+
+class _Fork(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (the identity branch of a residual block): the two incoming gradients are summed by
+    tpgsr_add here, not by autograd's own accumulation (an ATen kernel -- and invisible to a recorded plan)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        out = torch.empty_like(ga, memory_format=torch.contiguous_format)
+        K.add(_c(ga), _c(gb), ga.numel(), out)
+        return out
+
+
+def fork(x):
+    return _Fork.apply(x)
 
 
 class _Cat(torch.autograd.Function):

@@ -28,9 +28,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        x, xr = Fh.fork(x)       # two consumers: their gradients are summed by a HIP kernel, not by autograd
         out = self.bn1(self.conv1(x), act="relu")
         out = self.bn2(self.conv2(out))
-        residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        residual = xr if self.downsample is None else self.downsample[1](self.downsample[0](xr))
         return Fh.relu(Fh.add(out, residual))
 
 
