@@ -75,7 +75,11 @@ def synthetic_batch(n, seed, device):
     return lr.to(device), hr.to(device)
 
 
-def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False):
+OPT_ARGS = dict(Transformation="None", FeatureExtraction="ResNet", SequenceModeling="None", Prediction="CTC", num_fiducial=20,
+                input_channel=1, output_channel=512, hidden_size=256, num_class=37)      # main.py:60-75's option set for `--tpg OPT`
+
+
+def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False, tpg="crnn"):
     """networks (weights by recipe: no pretrained files exist) + the train-step driver of the chosen configuration.
     Product code only: the CPU oracle is not needed to build or run the benchmarked step."""
     from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep, TSRNTrainStep
@@ -90,8 +94,13 @@ def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False):
                            process_group=pg, world_size=world, force_collectives=force_collectives)
         return ts, [net]
     sr = init_by_recipe(tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 11)
-    teacher = init_by_recipe(crnn.CRNN(32, 1, 37, 256), 12)
-    students = [init_by_recipe(crnn.CRNN(32, 1, 37, 256), 13 + k).to(dev).train() for k in range(cfg["stu_iter"])]
+    if tpg == "opt":      # `--tpg OPT`: the None-ResNet-None-CTC recogniser as teacher and students (interfaces/super_resolution.py:77-80)
+        from tpgsr_amd.model.crnn import model as opt_model
+        make = lambda: opt_model.Model(OPT_ARGS)
+    else:
+        make = lambda: crnn.CRNN(32, 1, 37, 256)
+    teacher = init_by_recipe(make(), 12)
+    students = [init_by_recipe(make(), 13 + k).to(dev).train() for k in range(cfg["stu_iter"])]
     ts = TPGSRTrainStep([sr.to(dev).train()], students, teacher.to(dev).eval(), stu_iter=cfg["stu_iter"], sr_share=True,
                         tpg_share=False, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
                         process_group=pg, world_size=world, force_collectives=force_collectives)
@@ -396,6 +405,8 @@ def main():
     ap.add_argument("--prec", choices=["f32", "x3", "x3b2", "x2", "bf16"], default=None,
                     help="arithmetic of the MFMA GEMMs, see tpgsr_amd/kernels.py (default: TPGSR_CONV_PREC if set, else x2 -- BASELINE.json quotes "
                          "this configuration in bf16; x2 = two bf16 terms per operand holds the north_star gates, tests/test_policy_x2_gpu.py)")
+    ap.add_argument("--tpg", choices=["crnn", "opt"], default="crnn", help="text-prior generator of the TPGSR configurations (the reference's --tpg): "
+                                                                           "CRNN (BASELINE's) or the OPT None-ResNet-None-CTC recogniser")
     ap.add_argument("--force-collectives", action="store_true", help="world size 1 with the RCCL gradient exchange forced on (diagnostic)")
     ap.add_argument("--alt-prec", default="x3", help="a second policy timed after the headline (same step, same batch) and printed as "
                                                       "`alt_precision` of the same line; 'none' skips it")
@@ -455,7 +466,7 @@ def main():
     cfg = CONFIGS[args.config]
     B = cfg["batch"]
     torch.manual_seed(0)
-    ts, nets = build_step(args.config, dev, world, pg, force_collectives=args.force_collectives)
+    ts, nets = build_step(args.config, dev, world, pg, force_collectives=args.force_collectives, tpg=args.tpg)
     ts.broadcast_parameters(0)
     lr_img, hr_img = synthetic_batch(B, 1234 + rank, dev)
 
@@ -501,7 +512,8 @@ def main():
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "x3": "bf16x3", "x3b2": "bf16x3 fwd / bf16x2 bwd", "x2": "bf16x2", "bf16": "bf16"}[K_POLICY], "arithmetic_policy": K_POLICY, "data": "synthetic",
-            "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
+            "config": {"workload": cfg["name"] + ("" if args.tpg == "crnn" else " -- with the OPT (None-ResNet-None-CTC) recogniser as teacher and "
+                                                  "student instead of CRNN: NOT BASELINE's configuration"), "tpg": args.tpg, "batch_per_gpu": B, "global_batch": B * world,
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
                        "kernel_launches_per_step": n_launch, "arithmetic": ARITH[K_POLICY],
@@ -570,6 +582,23 @@ def main():
             # own roofline is `bench.py --eval`
             e = eval_bench(dev, 30, 8, roofline=False, cpu=False)
             out["eval"] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "super_resolve_only")}
+        if world == 1 and not args.no_roofline and cfg["tl"] and args.tpg == "crnn":
+            # the same step with `--tpg OPT` (recorded plans traced from the operator-level network, tpgsr_amd/engine_functional.py)
+            try:
+                ts3, _n3 = build_step(args.config, dev, world, pg, tpg="opt")
+                for _ in range(6):
+                    ts3.step(lr_img, hr_img)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(20):
+                    ts3.step(lr_img, hr_img)
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t3
+                out["tpg_opt"] = {"workload": "the same step with the OPT recogniser (29 convolutions, ResNet) as teacher and student", "steps": 20,
+                                  "ms_per_step": round(1e3 * dt3 / 20, 4), "value": round(B * 20 / dt3, 1), "unit": "img/s"}
+                del ts3, _n3
+            except Exception as e:      # reported, never hidden
+                out["tpg_opt"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args.config)

@@ -546,6 +546,10 @@ extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M
   if (!g_h3_on || T < 1 || T > 2 || a->KH * a->KW < 3 || !((a->KH * a->KW) & 1) || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_b ||
       a->in_ps || (ld & ~7) || ld == 6 || a->OW + a->KW - 1 < 8)
     return 0;
+  // the residual-add loader carries two quads per entry and has ONE register set (no load of the next block in flight), and a
+  // pixel-shuffled store goes out four bytes at a time: with both (the up-sampling convolution: 102 us here, 87 us there) the
+  // two-workgroup kernel, whose second workgroup covers those waits, is faster
+  if ((ld & 4) && a->out_ps) return 0;
   const int Lcap = halo3_capacity(a);
   const size_t lds = (size_t)2 * T * H3_PLANE + 2 * H3_TM * 1024 + 8 * 4096;      // halo buffers + statistics scratch + epilogue staging (161 792 B at T = 2)
   if (Lcap > 32 * H3_NE || lds > 163840) return 0;

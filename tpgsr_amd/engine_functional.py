@@ -42,6 +42,7 @@ class FunctionalEngine:
         self._plans: Dict[tuple, dict] = {}      # (N, training, slot, role) -> recorded plans + their static buffers
         self._saved: Dict[int, tuple] = {}
         self._pending_batches = 0
+        self._kernel_writes = 0      # bumped by FusedAdam / broadcasts (engine protocol); every plan here re-packs its weights per replay
 
     def bind(self, device):
         rebuilt = self.arena.ensure(device)

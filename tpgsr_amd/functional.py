@@ -129,7 +129,7 @@ class _Conv2d(torch.autograd.Function):
         K.conv_fwd(K.make_conv_args(g, x, wt_f, out, bias=b, out_ps=out_ps))
         ctx.save_for_backward(x, w, wt_d)
         ctx.cfg = (g, out_ps, transposed, wscale, b is not None)
-        ctx.bias_sink = _sink(b)
+        ctx.bias_ptr = b.data_ptr() if b is not None else None     # (the sinks are looked up when the backward runs)
         return out
 
     @staticmethod
@@ -149,7 +149,7 @@ class _Conv2d(torch.autograd.Function):
             with K.side():      # a leaf of the graph: on the weight-gradient stream when a recorded plan overlaps them (no-op eagerly)
                 K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(g, x), dy, part, dbp, dy_ps=out_ps, zsplits=Z))
                 if sw is not None:
-                    sb = ctx.bias_sink if has_b else None
+                    sb = GRAD_SINK.get(ctx.bias_ptr) if has_b else None
                     assert not has_b or sb is not None, "a sunk weight gradient needs its bias gradient sunk too"
                     K.wgrad_reduce(part, dbp, Z, g, sw, sb, layout=1 if transposed else 0, accumulate=True, gscale=wscale)
                 else:
@@ -264,7 +264,7 @@ class _BatchNorm(torch.autograd.Function):
         K.affine_act(x, M, C, scale, shift, act, out)
         ctx.save_for_backward(x, gamma, scale, shift, mean, rstd)
         ctx.cfg = (training, act, M, C)
-        ctx.beta_sink = _sink(beta)
+        ctx.beta_ptr = beta.data_ptr()
         return out
 
     @staticmethod
@@ -278,7 +278,7 @@ class _BatchNorm(torch.autograd.Function):
         nblk = max(1, min(1024, M // 64))
         part = torch.empty(nblk, 2, C, device=dev)
         coef = torch.empty(3, C, device=dev)
-        sg, sb = _sink(gamma), ctx.beta_sink
+        sg, sb = _sink(gamma), GRAD_SINK.get(ctx.beta_ptr)
         K.bn_bwd_reduce(dy, None, x, M, C, scale, shift, mean, rstd, act, part, nblk)
         if sg is not None:
             assert sb is not None, "a sunk BatchNorm weight gradient needs its bias gradient sunk too"
