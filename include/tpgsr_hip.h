@@ -182,7 +182,8 @@ int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, f
  *           Wc[g][ci] = sum_u src[g][u] * src2[u][ci]  (src = weight_ih [Cout=96][KH=64 hidden-of-conv], src2 = conv1
  *           weight [64][Cin]) -> dst_f[ci*f_ld + f_coff + g] and dst_d[(f_coff + g)*Cin + ci]; numel = Cout*Cin
  *   kind 6: its bias: dst_f[f_coff + g] = sum_u src[g][u] * src2[u] + src3[g]  (src2 = conv1 bias, src3 = bias_ih)
- * blk0 = prefix sum of ceil(numel/256) over the preceding descriptors; total_blocks = the full sum. */
+ * blk0 = prefix sum of tpgsr_pack_blocks(...) over the preceding descriptors (ceil(numel / 256), except kind 0 with <= 9 taps and Cout * Cin >= 65536,
+ * which is packed in 32 x 32-channel tiles through LDS: ceil(Cout / 32) * ceil(Cin / 32) workgroups); total_blocks = the full sum. */
 typedef struct {
   const float* src;
   float* dst_f;
@@ -219,6 +220,7 @@ typedef struct tpgsr_compose_bwd_desc {
 } tpgsr_compose_bwd_desc;
 int tpgsr_compose_bwd_blocks(int Cin, int U, int G);
 int tpgsr_compose_bwd_program(const tpgsr_compose_bwd_desc* descs_dev, int ndesc, int total_blocks, void* stream);
+int tpgsr_pack_blocks(int kind, int Cout, int Cin, int KH, int KW, long long numel);
 int tpgsr_pack_program(const tpgsr_pack_desc* descs_dev, int ndesc, int total_blocks, void* stream);
 /* Split every packed fp32 MFMA operand of a network into bf16 planes for the bf16 matrix-core path, in ONE launch right
  * after tpgsr_pack_program: src fp32 [K][ld] (k-major, N <= ld columns used) -> dst bf16 planes

@@ -106,6 +106,7 @@ _SIGS = {
     "tpgsr_wgrad_halo_plan": (ci, [C.POINTER(ConvArgs), C.POINTER(ci), C.POINTER(C.c_longlong)]),
     "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
     "tpgsr_wgrad_reduce_blocks": (ci, [ci, ci, ci]),
+    "tpgsr_pack_blocks": (ci, [ci, ci, ci, ci, ci, ll]),
     "tpgsr_wgrad_reduce_blocks2": (ci, [ci, ci, ci, ci, ci, ci, ci, ci]),
     "tpgsr_wgrad_reduce_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_compose_bwd_blocks": (ci, [ci, ci, ci]),

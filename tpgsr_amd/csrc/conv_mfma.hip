@@ -955,8 +955,27 @@ extern "C" int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, flo
 // ------------------------------------------------------------------------------------------------------
 // pack program: ALL per-step operand packing of a model in one launch (a device-resident descriptor table)
 // ------------------------------------------------------------------------------------------------------
+// kind 0 (every convolution / linear weight: the bulk of a network) with <= 9 taps is packed in TILES of 32 output x 32 input channels x
+// all taps through LDS: the source [Cout][Cin][taps] is read in runs of 32 * taps floats, the k-major forward operand written in runs of
+// 32 output channels, the data-gradient operand in runs of 32 input channels.  Element by element (the other kinds: small) every write
+// of the forward operand lands on a cache line of its own -- the student recogniser's 8.3 M parameters took 77 us a step that way.
+#define PK_TILED_MAX_TAPS 9
+// (large layers only: a 64 x 64 x 9 weight would be FOUR workgroups of 9216 elements -- the SR network's 25 small layers packed in 57 us
+//  that way against 46 us element by element, 144 workgroups each)
+__host__ __device__ __forceinline__ bool pack_tiled(int kind, int Cout, int Cin, int KH, int KW) {
+  return kind == 0 && KH * KW <= PK_TILED_MAX_TAPS && (long long)Cout * Cin >= 65536;
+}
+__host__ __device__ __forceinline__ int pack_desc_blocks(int kind, int Cout, int Cin, int KH, int KW, long long numel) {
+  if (pack_tiled(kind, Cout, Cin, KH, KW)) return ((Cout + 31) / 32) * ((Cin + 31) / 32);
+  return (int)((numel + 255) / 256);
+}
+extern "C" int tpgsr_pack_blocks(int kind, int Cout, int Cin, int KH, int KW, long long numel) {
+  return pack_desc_blocks(kind, Cout, Cin, KH, KW, numel);
+}
+
 __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc* __restrict__ descs, int ndesc) {
   __shared__ int s_d;
+  __shared__ float tile[32 * (32 * PK_TILED_MAX_TAPS + 1)];
   if (threadIdx.x == 0) {
     int lo = 0, hi = ndesc - 1;  // last descriptor whose blk0 <= blockIdx.x
     while (lo < hi) {
@@ -967,6 +986,39 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
   }
   __syncthreads();
   const tpgsr_pack_desc d = descs[s_d];
+  if (pack_tiled(d.kind, d.Cout, d.Cin, d.KH, d.KW)) {
+    const int taps = d.KH * d.KW, R = 32 * taps, pitch = R | 1;
+    const int nci = (d.Cin + 31) / 32;
+    const int b = (int)blockIdx.x - d.blk0;
+    const int co0 = (b / nci) * 32, ci0 = (b - (b / nci) * nci) * 32;
+    const int cw = min(32, d.Cin - ci0) * taps;        // valid floats of a source run
+    for (int e = threadIdx.x; e < 32 * R; e += 256) {
+      const int row = e / R, pos = e - row * R;
+      float v = 0.f;
+      if (co0 + row < d.Cout && pos < cw) v = d.src[((size_t)(co0 + row) * d.Cin + ci0) * taps + pos] * d.wscale;
+      tile[row * pitch + pos] = v;
+    }
+    __syncthreads();
+    const int cin_ld = d.cin_ld > 0 ? d.cin_ld : d.Cin, d_ld = d.d_ld > 0 ? d.d_ld : d.Cin;
+    if (d.dst_f) {
+      for (int e = threadIdx.x; e < 32 * R; e += 256) {
+        const int co_l = e & 31, rest = e >> 5;
+        const int ci_l = rest & 31, tap = rest >> 5;
+        if (co0 + co_l < d.Cout && ci0 + ci_l < d.Cin)
+          d.dst_f[((size_t)tap * cin_ld + ci0 + ci_l) * d.f_ld + d.f_coff + co0 + co_l] = tile[co_l * pitch + ci_l * taps + tap];
+      }
+    }
+    if (d.dst_d) {
+      for (int e = threadIdx.x; e < 32 * R; e += 256) {
+        const int ci_l = e & 31, rest = e >> 5;
+        const int co_l = rest & 31, tap = rest >> 5;
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        if (co0 + co_l < d.Cout && ci0 + ci_l < d.Cin)
+          d.dst_d[((size_t)((d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw)) * d.Cout + co0 + co_l) * d_ld + ci0 + ci_l] = tile[co_l * pitch + ci_l * taps + tap];
+      }
+    }
+    return;
+  }
   long long idx = (long long)(blockIdx.x - d.blk0) * 256 + threadIdx.x;
   if (idx >= d.numel) return;
   if (d.kind == 5) {  // composed GruBlock operand: one 64-term dot product per output element

@@ -564,6 +564,8 @@ class _EngineBase:
         self._split_n, self._split_blocks = len(ops), blk
 
     def _finish_pack_table(self):
+        from ._lib import load
+        lib = load()
         n = len(self._pack)
         arr = (PackDesc * n)()
         blk = 0
@@ -578,7 +580,7 @@ class _EngineBase:
             d.d_ld, d.cin_ld = d_ld, cin_ld
             cnt = src.numel() if numel is None else numel
             d.numel, d.blk0 = cnt, blk
-            blk += (cnt + 255) // 256
+            blk += lib.tpgsr_pack_blocks(kind, Cout, Cin, KH, KW, cnt)
             self._pack_keep += [src, dst_f, dst_d, src2, src3]
         raw = bytes(arr)
         self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
@@ -753,9 +755,12 @@ class TSRNEngine(_EngineBase):
         if training:
             with recording(bwd), K.conv_terms(K.terms_for("sr", "bwd")):
                 self._record_bwd(N, H, W, ws)
-                bwd.leaf_to_side()          # the batched slab reduce reads the leaf stream's slabs too
                 if self.defer_reduce:
-                    K.flush_wgrad_reduces()
+                    # the leaf stream's slabs are reduced on the leaf stream (TPGSR_SPLIT_LEAF_REDUCE=0: one program on the
+                    # weight-gradient stream, which then waits for the leaf chain)
+                    K.flush_wgrad_reduces(split_leaf=os.environ.get("TPGSR_SPLIT_LEAF_REDUCE", "1") != "0")
+                else:
+                    bwd.leaf_to_side()
                 self.flush_compose_bwd()
                 if not defer_join:
                     bwd.join()

@@ -303,7 +303,7 @@ class TPGSRTrainStep:
             if overlap and self._final_stage(srm) == i:
                 # every gradient of this SR net is final here (a shared one: after the LAST of its backward passes, stage 0): its bucket
                 # travels over xGMI while the text-prior generators' backward passes below run
-                self._launch_bucket_from_side(self._bucket("sr", srm), lr_img.device)
+                self._launch_bucket_from_side(self._bucket("sr", srm), lr_img.device, sr_net=True)
             self._mark(f"SR{i} bwd")
             K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
             if getattr(self, "_debug", False):
@@ -368,17 +368,26 @@ class TPGSRTrainStep:
                                            scale_fn=lambda flat, _s: K.scale_(flat, flat.numel(), inv), force=self.collective)
         return self._exch
 
-    def _launch_bucket_from_side(self, b, device):
+    def _launch_bucket_from_side(self, b, device, sr_net=False):
         """launch bucket b's all-reduce FROM the weight-gradient stream: its tail is ordered after the weight gradients and slab reduces
-        recorded so far (and the leaf stream); it is made to wait for this stream's BatchNorm / PReLU-slope gradients; this stream does
-        not wait for anything"""
+        recorded so far; it is made to wait for this stream's BatchNorm / PReLU-slope gradients; this stream does not wait for anything.
+        sr_net: an SR network's bucket -- its STN head's gradients come off the LEAF stream (their slab reduce included), the last of
+        the three to finish, so the launch is made from THAT stream, ordered after the other two: the weight-gradient stream, with the
+        text-prior generator's weight gradients queued on it, does not wait for the leaf chain"""
         if K.DRYRUN:
             self._exchanger().launch(b)
             return
-        # ALWAYS from the weight-gradient stream, also with TPGSR_DEFER_JOIN=0: the text-prior generator's first backward plan never
-        # joins it (K.continue_in), so a launch from this stream could read gradients its weight-gradient / slab-reduce launches are
-        # still writing (ADVICE round 3)
+        # ALWAYS from a stream ordered after the weight-gradient stream, also with TPGSR_DEFER_JOIN=0: the text-prior generator's first
+        # backward plan never joins it (K.continue_in), so a launch from this stream could read gradients its weight-gradient /
+        # slab-reduce launches are still writing (ADVICE round 3)
         side = K.side_stream(device)
+        if sr_net:
+            aux = K.aux_stream(device)
+            K.order(aux, side)
+            K.order(aux, K.current_stream())
+            with K.stream_ctx(aux):
+                self._exchanger().launch(b)
+            return
         K.order(side, K.current_stream())
         with K.stream_ctx(side):
             self._exchanger().launch(b)
@@ -391,6 +400,8 @@ class TPGSRTrainStep:
     def _join_side(self, device):
         if self._defer_join and not K.DRYRUN:
             K.order(K.current_stream(), K.side_stream(device))
+            # the SR network's backward plan leaves its leaf stream (STN head backward + the slab reduce of its weight gradients) unjoined too
+            K.order(K.current_stream(), K.aux_stream(device))
 
     def _phase_b(self):
         self.opt.step()

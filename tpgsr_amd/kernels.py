@@ -676,7 +676,7 @@ def wgrad_reduce(part, dbpart, Z, g: ConvGeom, dw, db=None, *, layout=0, accumul
     Cin, KH, KW, cin_ld = real if real is not None else (g.Cin, g.KH, g.KW, 0)
     item = (part, dbpart, Z, g.K, Cin, g.Cout, KH, KW, layout, dw, db, int(accumulate), float(gscale), cin_ld)
     if deferring():   # the caller gave this layer its own slab buffers; reduced by flush_wgrad_reduces()
-        _REC.deferred.append(item)
+        _REC.deferred.append(item + (_REC.sid == 2,))       # (tagged: produced on the leaf stream)
     elif real is not None:
         _reduce_program([item])
     else:
@@ -689,7 +689,7 @@ def _reduce_program(items):
     arr = (_lib.WgradReduceDesc * len(items))()
     blk = 0
     seen = set()
-    for d, (part, dbpart, Z, Kd, Cin, Cout, KH, KW, layout, dw, db, acc, gscale, cin_ld) in zip(arr, items):
+    for d, (part, dbpart, Z, Kd, Cin, Cout, KH, KW, layout, dw, db, acc, gscale, cin_ld, *_leaf) in zip(arr, items):
         has_b = db is not None and dbpart is not None
         d.part, d.dbpart = _p(part), (_p(dbpart) if has_b else None)
         d.dw, d.db = _p(dw), (_p(db) if has_b else None)
@@ -700,16 +700,29 @@ def _reduce_program(items):
         assert dw.data_ptr() not in seen, "two deferred reduces of one program target the same gradient"
         seen.add(dw.data_ptr())
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(items[0][0].device)
-    with (side() if (_REC is None or _REC.sid == 0) else _NoSide()):   # already inside a side section: stay there
+    with (side() if (_REC is None or _REC.sid == 0) else _NoSide()):   # already inside a side / leaf section: stay there
         _launch("tpgsr_wgrad_reduce_program", _p(table), len(items), blk)
 
 
-def flush_wgrad_reduces():
-    """Emit ONE tpgsr_wgrad_reduce_program launch (side stream) for every reduce deferred so far in this plan."""
+def flush_wgrad_reduces(split_leaf=False):
+    """Emit ONE tpgsr_wgrad_reduce_program launch (side stream) for every reduce deferred so far in this plan.
+    split_leaf: the slabs written on the LEAF stream get a program of their own, at the end of that stream -- the weight-gradient stream
+    then never waits for the leaf chain (the STN head's backward: ~45 small launches in a row, the last to finish in a TPGSR step; the
+    one shared program made the stream -- and with it the text-prior generator's weight gradients queued behind -- wait ~0.6 ms for it).
+    Whoever reads the gradients next must be ordered after BOTH streams (Plan.join() does; TPGSRTrainStep._join_side)."""
     rec = _REC
     items, rec.deferred = rec.deferred, []
-    if items:
-        _reduce_program(items)
+    if not items:
+        return
+    leaf_items = [it for it in items if split_leaf and len(it) > 14 and it[14]]
+    side_items = [it for it in items if not (split_leaf and len(it) > 14 and it[14])]
+    if not leaf_items:
+        rec.leaf_to_side()          # one program: it reads the leaf stream's slabs too
+    if side_items:
+        _reduce_program(side_items)
+    if leaf_items:
+        with rec.leaf():
+            _reduce_program(leaf_items)
 
 
 def pack_conv_weight(w, Cout, Cin, KH, KW, wt_f=None, wt_d=None, *, transposed=False, wscale=1.0):
