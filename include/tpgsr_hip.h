@@ -129,6 +129,18 @@ int tpgsr_wgrad_splits(int M, int K, int Cout);
  * Only N, H, W, Cin, Cout, KH, KW, pads, OH, OW, terms and the loader-shape fields of `a` are read. */
 int tpgsr_wgrad_halo_plan(const tpgsr_conv_args* a, int* zsplits, long long* dy_bf_bytes);
 int tpgsr_conv_wgrad(const tpgsr_wgrad_args* a, void* stream);
+/* Several independent weight-gradient GEMMs in ONE launch (the ten of the text-prior generator's two BiLSTM layers, model/crnn/crnn.py:5-26:
+ * 25-65 us each alone -- start-up, not work).  items_dev: device-resident table; an item = the arguments of one tpgsr_conv_wgrad call plus
+ * what its launcher derives from them, filled on the host by tpgsr_conv_wgrad_batch_prepare (returns the loader variant `ld`, >= 0, when
+ * the call is a 1x1 geometry on the split-bf16 tile-loop kernel -- the only kind a batch takes; all items of a batch share `ld` and
+ * `terms`); blk0 = prefix sum of nblk over the preceding items, total_blocks = the full sum.  Results are those of the single launches,
+ * bit for bit (same workgroups, same slabs). */
+typedef struct tpgsr_wgrad_batch_item {
+  tpgsr_wgrad_args w;
+  int M, K, MB, blk0, nblk, reserved0, reserved1, reserved2;
+} tpgsr_wgrad_batch_item;
+int tpgsr_conv_wgrad_batch_prepare(const tpgsr_wgrad_args* w, tpgsr_wgrad_batch_item* item);
+int tpgsr_conv_wgrad_batch(const tpgsr_wgrad_batch_item* items_dev, int n, int total_blocks, int ld, int terms, void* stream);
 
 /* Deterministic second stage: dw (+)= sum_z part[z], written in the PyTorch parameter layout
  *   layout 0: conv / linear weight [Cout][Cin][KH][KW]

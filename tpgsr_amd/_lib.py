@@ -65,6 +65,10 @@ class SplitDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("K", ci), ("N", ci), ("ld", ci), ("kp", ci), ("blk0", ci), ("cin", ci)]
 
 
+class WgradBatchItem(C.Structure):
+    _fields_ = [("w", WgradArgs), ("M", ci), ("K", ci), ("MB", ci), ("blk0", ci), ("nblk", ci), ("reserved0", ci), ("reserved1", ci), ("reserved2", ci)]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [("offset", ll), ("H", ci), ("W", ci), ("xb_off", ci), ("xk_off", ci), ("kx", ci), ("yb_off", ci), ("yk_off", ci), ("ky", ci)]
 
@@ -107,6 +111,8 @@ _SIGS = {
     "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
     "tpgsr_wgrad_reduce_blocks": (ci, [ci, ci, ci]),
     "tpgsr_pack_blocks": (ci, [ci, ci, ci, ci, ci, ll]),
+    "tpgsr_conv_wgrad_batch_prepare": (ci, [C.POINTER(WgradArgs), C.POINTER(WgradBatchItem)]),
+    "tpgsr_conv_wgrad_batch": (ci, [vp, ci, ci, ci, ci, vp]),
     "tpgsr_wgrad_reduce_blocks2": (ci, [ci, ci, ci, ci, ci, ci, ci, ci]),
     "tpgsr_wgrad_reduce_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_compose_bwd_blocks": (ci, [ci, ci, ci]),
@@ -239,7 +245,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs, WgradBatchItem)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

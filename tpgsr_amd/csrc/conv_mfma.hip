@@ -618,6 +618,10 @@ static void wgrad_plan(long long M, int K, int Cout, int* Z, int* MB) {
   *MB = (int)mb;
 }
 
+/* (internal, for conv_xbf.hip's batched launch: the split count / pixels per split and the loader variant tpgsr_conv_wgrad uses) */
+extern "C" void tpgsr_wgrad_plan_host(long long M, int K, int Cout, int* Z, int* MB) { wgrad_plan(M, K, Cout, Z, MB); }
+extern "C" int tpgsr_loader_bits(const tpgsr_conv_args* a) { return loader_bits(a); }
+
 extern "C" int tpgsr_wgrad_splits(int M, int K, int Cout) {
   int Z, MB;
   wgrad_plan(M, K, Cout, &Z, &MB);

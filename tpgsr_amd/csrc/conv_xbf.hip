@@ -770,16 +770,19 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* plane, int lane, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+extern "C" void tpgsr_wgrad_plan_host(long long M, int K, int Cout, int* Z, int* MB);   // conv_mfma.hip
+extern "C" int tpgsr_loader_bits(const tpgsr_conv_args* a);
+
+// (bx of gx: this workgroup's index within ITS launch -- the whole grid, or one item's share of a batched launch)
 template <int LD, int T>
-__global__ __launch_bounds__(256) void conv_wgrad_xbf_kernel(tpgsr_wgrad_args w, int M, int K, int MB) {
-  __shared__ __attribute__((aligned(16))) unsigned char Am[T * XW_PLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Ym[T * XW_PLANE];
+__device__ __forceinline__ void conv_wgrad_xbf_body(const tpgsr_wgrad_args& w, const int M, const int K, const int MB, const unsigned bx,
+                                                    const unsigned gx, unsigned char* Am, unsigned char* Ym) {
   const tpgsr_conv_args& a = w.c;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wn = wave >> 1;
   const int nkb = (K + WK - 1) / WK, nnb = (a.Cout + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);       // k-block fastest: the k-blocks of one pixel split share an L2
+  const int tile = xcd_remap(bx, gx);       // k-block fastest: the k-blocks of one pixel split share an L2
   const int kblk = tile % nkb, nblk = (tile / nkb) % nnb, zblk = tile / (nkb * nnb);
   const int k0 = kblk * WK, n0 = nblk * BN;
   const int mbeg = zblk * MB;
@@ -904,6 +907,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_xbf_kernel(tpgsr_wgrad_args w,
       w.dbpart[(size_t)zblk * a.Cout + n0 + tid] = sdb;
     }
   }
+}
+
+template <int LD, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_xbf_kernel(tpgsr_wgrad_args w, int M, int K, int MB) {
+  __shared__ __attribute__((aligned(16))) unsigned char Am[T * XW_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Ym[T * XW_PLANE];
+  conv_wgrad_xbf_body<LD, T>(w, M, K, MB, blockIdx.x, gridDim.x, Am, Ym);
+}
+
+// Several INDEPENDENT weight-gradient GEMMs in one launch (a device-resident item table, like the pack / reduce programs).  The two
+// BiLSTM layers of the text-prior generator have ten of them -- 2 directions x (hidden side, input side) + the embedding, per layer --
+// over M = N T = 1248 rows each: a launch alone is 25-65 us of start-up, four splits of ten 32-row chunks and a slab write, and the ten
+// in a row were 335 us at the END of the training step, where the weight-gradient stream is the only one still running.  Together
+// they are ~2000 workgroups that fill the chip once.
+template <int LD, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_xbf_batch_kernel(const tpgsr_wgrad_batch_item* __restrict__ items, int n) {
+  __shared__ __attribute__((aligned(16))) unsigned char Am[T * XW_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Ym[T * XW_PLANE];
+  __shared__ int s_d;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;  // last item whose blk0 <= blockIdx.x
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    s_d = lo;
+  }
+  __syncthreads();
+  const tpgsr_wgrad_batch_item* it = items + s_d;
+  const tpgsr_wgrad_args w = it->w;
+  conv_wgrad_xbf_body<LD, T>(w, it->M, it->K, it->MB, blockIdx.x - (unsigned)it->blk0, (unsigned)it->nblk, Am, Ym);
+}
+
+/* host side of a batched launch: what tpgsr_conv_wgrad would launch for *w -- filled into *item (blk0 is the caller's prefix sum of nblk).
+ * Returns the loader variant (>= 0) when the launch is the tile-loop split-bf16 kernel's (1x1 geometry, terms > 0, 16-byte rows), which is
+ * what a batch is made of; TPGSR_ERR_ARG otherwise (the caller launches that one on its own). */
+extern "C" int tpgsr_conv_wgrad_batch_prepare(const tpgsr_wgrad_args* w, tpgsr_wgrad_batch_item* item) {
+  TPGSR_CHECK_ARG(w && item && w->dy && w->part, "tpgsr_conv_wgrad_batch_prepare: null pointer");
+  const tpgsr_conv_args* a = &w->c;
+  const long long M = (long long)a->N * a->OH * a->OW;
+  const int K = a->KH * a->KW * a->Cin;
+  const bool vecY = !w->dy_ps && (w->dy_ld & 3) == 0 && (w->dy_coff & 3) == 0 && w->dy_ld >= ((a->Cout + 3) & ~3) + w->dy_coff &&
+                    ((uintptr_t)w->dy & 15) == 0;
+  if (!(a->terms >= 1 && a->terms <= 3 && a->KH * a->KW == 1 && (a->Cin & 3) == 0 && vecY && M < (1ll << 31) &&
+        M * w->dy_ld * 4 <= 0x7fffffffll && a->wt_bf_cin == 0 && !w->dy_bf)) {
+    tpgsr_set_error("tpgsr_conv_wgrad_batch_prepare: not a tile-loop split-bf16 launch");
+    return TPGSR_ERR_ARG;
+  }
+  int Z, MB;
+  tpgsr_wgrad_plan_host(M, K, a->Cout, &Z, &MB);
+  if (w->zsplits > 0) {
+    Z = w->zsplits;
+    MB = cdiv(cdiv(M, 64), Z) * 64;
+  }
+  item->w = *w;
+  item->M = (int)M;
+  item->K = K;
+  item->MB = MB;
+  item->blk0 = 0;
+  item->nblk = cdiv(K, WK) * cdiv(a->Cout, BN) * Z;
+  return tpgsr_loader_bits(a);
+}
+
+extern "C" int tpgsr_conv_wgrad_batch(const tpgsr_wgrad_batch_item* items_dev, int n, int total_blocks, int ld, int terms, void* stream) {
+  TPGSR_CHECK_ARG(items_dev && n > 0 && total_blocks > 0 && terms >= 1 && terms <= 3, "tpgsr_conv_wgrad_batch: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(total_blocks);
+#define XBF_WGB_CASE(B)                                                                                                 \
+  case B:                                                                                                               \
+    if (terms == 1) hipLaunchKernelGGL((conv_wgrad_xbf_batch_kernel<B, 1>), grid, dim3(256), 0, st, items_dev, n);      \
+    else if (terms == 2) hipLaunchKernelGGL((conv_wgrad_xbf_batch_kernel<B, 2>), grid, dim3(256), 0, st, items_dev, n); \
+    else hipLaunchKernelGGL((conv_wgrad_xbf_batch_kernel<B, 3>), grid, dim3(256), 0, st, items_dev, n);                 \
+    break;
+  switch (ld) {
+    XBF_WGB_CASE(0) XBF_WGB_CASE(1) XBF_WGB_CASE(3)
+    default:
+      tpgsr_set_error("tpgsr_conv_wgrad_batch: unsupported loader combination %d", ld);
+      return TPGSR_ERR_ARG;
+  }
+#undef XBF_WGB_CASE
+  TPGSR_LAUNCH_CHECK("tpgsr_conv_wgrad_batch");
 }
 
 extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long M, int K, int Z, int MB, int ld, hipStream_t st) {

@@ -26,6 +26,7 @@ extern "C" int tpgsr_sizeof(int which) {
     case 5: return (int)sizeof(tpgsr_split_desc);
     case 6: return (int)sizeof(tpgsr_image_desc);
     case 7: return (int)sizeof(tpgsr_gru_wgrad_args);
+    case 8: return (int)sizeof(tpgsr_wgrad_batch_item);
     default: return -1;
   }
 }

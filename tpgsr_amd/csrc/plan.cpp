@@ -58,7 +58,7 @@ struct Entry {
 const std::unordered_map<std::string, Entry>& registry() {
   static const std::unordered_map<std::string, Entry> r = {
       TPGSR_REG_S(tpgsr_conv_fwd, tpgsr_conv_args), TPGSR_REG_S(tpgsr_conv_wgrad, tpgsr_wgrad_args),
-      TPGSR_REG(tpgsr_wgrad_reduce), TPGSR_REG(tpgsr_wgrad_reduce_program), TPGSR_REG(tpgsr_compose_bwd_program), TPGSR_REG(tpgsr_pack_conv_weight), TPGSR_REG(tpgsr_pack_tail_weight),
+      TPGSR_REG(tpgsr_wgrad_reduce), TPGSR_REG(tpgsr_wgrad_reduce_program), TPGSR_REG(tpgsr_conv_wgrad_batch), TPGSR_REG(tpgsr_compose_bwd_program), TPGSR_REG(tpgsr_pack_conv_weight), TPGSR_REG(tpgsr_pack_tail_weight),
       TPGSR_REG(tpgsr_pack_program), TPGSR_REG(tpgsr_mfma_probe), TPGSR_REG(tpgsr_copy), TPGSR_REG(tpgsr_zero),
       TPGSR_REG(tpgsr_bn_finalize), TPGSR_REG(tpgsr_bn_stats), TPGSR_REG(tpgsr_bn_bwd_reduce),
       TPGSR_REG(tpgsr_bn_bwd_finalize), TPGSR_REG(tpgsr_bn_bwd_apply), TPGSR_REG(tpgsr_affine_act),

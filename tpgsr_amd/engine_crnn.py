@@ -152,7 +152,10 @@ class LstmLayer:
         BatchNorm dx is the incoming gradient of"""
         eng, P, Gd, r = self.eng, self.eng.P, self.eng.G, self.r
         Hh, G4 = self.Hh, 4 * self.Hh
-        self.emb.wgrad(N, 1, T, out, de)
+        # (only with deferred slab reduces: every launch then has slab buffers of its own -- the five run concurrently)
+        batch = K.LSTM_WGRAD_BATCH and K.CONV_TERMS > 0 and K.deferring() and isinstance(self.emb, (ConvLayer, PaddedLinear))
+        if not batch:
+            self.emb.wgrad(N, 1, T, out, de)
         self.emb.dgrad(N, 1, T, de, dout)
         S = G4 // (32 * K.LSTM_BWD_KCHUNKS)                 # K-split of the recurrent gradient GEMM (K = 4 Hh)
         seq = K.LSTM_SEQ_BWD and Hh == 256 and N <= 64
@@ -171,21 +174,40 @@ class LstmLayer:
                 K.lstm_rec_gemm(a[0], a[1], T * 2 * G4, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], N, G4, Hh, S, dhc)
             K.lstm_step_bwd(G, Cst, dout, dhc if s > 0 else None, S, dcc, N, T, Hh, s)
         with K.side():     # weight gradients: leaves of the graph, on the side stream once the gate gradients are final
+            # the five GEMMs of the layer -- 2 directions x (hidden side, input side) + the embedding, M = N T rows each -- go out as ONE
+            # launch (tpgsr_conv_wgrad_batch; the input side of the first layer, behind the CNN's BatchNorm + ReLU loader, as a second):
+            # alone each is 25-65 us of start-up, and the ten of the two layers sit at the very end of the training step
+            wargs, reduces = [], []
+            if batch:
+                emb = self.emb
+                ge = ConvGeom(N, 1, T, emb.Cin, emb.Cout)
+                Z = K.wgrad_splits(ge.M, ge.K, ge.Cout)
+                part, dbp = eng.wgrad_buffers(Z * ge.K * ge.Cout, Z * ge.Cout)
+                dy_kw = dict(dy_ld=emb.Cp) if isinstance(emb, PaddedLinear) else {}
+                wargs.append(K.make_wgrad_args(K.make_conv_args(ge, out), de, part, dbp, **dy_kw))
+                reduces.append((part, dbp, Z, ge, Gd[emb.wname], Gd[emb.bname]))
             for d, suf in enumerate(("", "_reverse")):
                 sgn = 1 if d == 0 else -1
                 # hidden side: dW_hh[d] = dG[:, d]^T h_prev, db_hh[d] = colsum(dG[:, d])
                 gh_ = ConvGeom(N, 1, T, Hh, G4, 1, 1, 0, sgn, 1, T)
                 Z = K.wgrad_splits(gh_.M, gh_.K, G4)
                 part, dbp = eng.wgrad_buffers(Z * Hh * G4, Z * G4)
-                K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gh_, out, in_ld=2 * Hh, in_coff=d * Hh), G, part, dbp,
+                wargs.append(K.make_wgrad_args(K.make_conv_args(gh_, out, in_ld=2 * Hh, in_coff=d * Hh), G, part, dbp,
                                                dy_ld=2 * G4, dy_coff=d * G4))
-                K.wgrad_reduce(part, dbp, Z, gh_, Gd[r + "weight_hh_l0" + suf], Gd[r + "bias_hh_l0" + suf], accumulate=True)
+                reduces.append((part, dbp, Z, gh_, Gd[r + "weight_hh_l0" + suf], Gd[r + "bias_hh_l0" + suf]))
                 # input side
                 gi_ = ConvGeom(N, 1, T, self.Cin, G4)
                 Z = K.wgrad_splits(gi_.M, gi_.K, G4)
                 part, dbp = eng.wgrad_buffers(Z * self.Cin * G4, Z * G4)
-                K.conv_wgrad(K.make_wgrad_args(K.make_conv_args(gi_, x, **loader), G, part, dbp, dy_ld=2 * G4, dy_coff=d * G4))
-                K.wgrad_reduce(part, dbp, Z, gi_, Gd[r + "weight_ih_l0" + suf], Gd[r + "bias_ih_l0" + suf], accumulate=True)
+                wargs.append(K.make_wgrad_args(K.make_conv_args(gi_, x, **loader), G, part, dbp, dy_ld=2 * G4, dy_coff=d * G4))
+                reduces.append((part, dbp, Z, gi_, Gd[r + "weight_ih_l0" + suf], Gd[r + "bias_ih_l0" + suf]))
+            if batch:
+                K.conv_wgrad_batch(wargs)
+            else:
+                for w_ in wargs:
+                    K.conv_wgrad(w_)
+            for part, dbp, Z, g_, dw_, db_ in reduces:
+                K.wgrad_reduce(part, dbp, Z, g_, dw_, db_, accumulate=True)
         if dx is not None:
             K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, 2 * G4, self.Cin), G, self.wih_d, dx, bnb=dx_bnb))
 
@@ -308,7 +330,9 @@ class CRNNEngine(_EngineBase):
         fz = None                                 # BatchNorm-backward sums already left behind by the producer of `da`
         # side batches (K.side_batch_begin): 1 = both BiLSTMs' weight gradients behind one fork and conv6..conv3's (+ the early slab
         # reduce) behind another; 2 = conv2 / conv1 as well; conv0's stays on its own (it is the tail of the pass)
-        sbl = int(os.environ.get("TPGSR_SIDE_BATCH_CRNN", "1"))
+        # (default 0 since the BiLSTM layers' weight gradients are ONE launch each: with the weight-gradient stream no longer busy with ten
+        #  small GEMMs, holding conv6..conv3's back until conv3's data gradient is out only delays them -- C3 6.20 -> 6.05 ms per step)
+        sbl = int(os.environ.get("TPGSR_SIDE_BATCH_CRNN", "0"))
         sb = K.side_batch_begin() if sbl >= 1 else False
         for j in (1, 0):
             L = self.lstm[j]

@@ -665,6 +665,37 @@ def conv_wgrad(w: WgradArgs):
     _launch("tpgsr_conv_wgrad", C.byref(w))
 
 
+def conv_wgrad_batch(wargs):
+    """Several independent weight-gradient GEMMs (WgradArgs from make_wgrad_args) as ONE launch -- tpgsr_conv_wgrad_batch; launches the
+    batch does not take (not 1x1 / not on the split-bf16 tile-loop kernel, or a different loader variant than the first) go out singly."""
+    lib = _lib.load()
+    items, rest, key = [], [], None
+    for w in wargs:
+        it = _lib.WgradBatchItem()
+        ld = lib.tpgsr_conv_wgrad_batch_prepare(C.byref(w), C.byref(it))
+        k = (ld, w.c.terms)
+        if ld >= 0 and (key is None or k == key):
+            key = k
+            items.append(it)
+        else:
+            rest.append(w)
+    if len(items) < 2:
+        for w in wargs:
+            conv_wgrad(w)
+        return
+    arr = (_lib.WgradBatchItem * len(items))(*items)
+    blk = 0
+    for it in arr:
+        it.blk0 = blk
+        blk += it.nblk
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(torch.device("cpu") if DRYRUN else torch.device("cuda", torch.cuda.current_device()))
+    if _REC is not None:
+        _REC.keep.append(list(wargs))
+    _launch("tpgsr_conv_wgrad_batch", _p(table), len(items), blk, key[0], key[1])
+    if rest:
+        conv_wgrad_batch(rest)      # (another loader variant: a batch of its own, or a single launch)
+
+
 def deferring() -> bool:
     """True while recording a plan that batches its weight-gradient slab reduces into one launch (Plan.deferred)."""
     return _REC is not None and getattr(_REC, "deferred", None) is not None
@@ -921,6 +952,8 @@ def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
 # TPGSR_LSTM_SEQ=0 records the per-step launches (tpgsr_lstm_rec_gemm + tpgsr_lstm_step_{fwd,bwd}) instead.
 LSTM_SEQ = os.environ.get("TPGSR_LSTM_SEQ", "1") == "1"
 LSTM_SEQ_BWD = os.environ.get("TPGSR_LSTM_SEQ_BWD", "1" if LSTM_SEQ else "0") == "1"
+# the five weight-gradient GEMMs of a BidirectionalLSTM layer as one launch (tpgsr_conv_wgrad_batch); 0: five launches
+LSTM_WGRAD_BATCH = os.environ.get("TPGSR_LSTM_WGRAD_BATCH", "1") == "1"
 
 
 # fused recurrent projection + gate step (Hh == 256, N <= 64): one 32-workgroup launch per time step instead of a 128-workgroup
