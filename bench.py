@@ -132,13 +132,13 @@ def conv_family(nets):
     items = []
     for net in nets:
         for pl in net._engine()._plans.values():
-            for pname in ("pre", "fwd", "bwd", "bwd_b"):
+            for pname in ("pre", "fwd", "fwd_b", "bwd", "bwd_b"):
                 if pname not in pl:
                     continue
                 for name, fn, args, _sid in pl[pname].ops:
                     if name == "tpgsr_conv_fwd":
                         a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
-                        kind, terms = ("fwd" if pname != "bwd" else "dgrad"), (a.terms if (a.terms and a.wt_bf) else 0)
+                        kind, terms = ("dgrad" if pname.startswith("bwd") else "fwd"), (a.terms if (a.terms and a.wt_bf) else 0)
                     elif name == "tpgsr_conv_wgrad":
                         a = args[0]._obj.c
                         kind, terms = "wgrad", a.terms
@@ -506,7 +506,7 @@ def main():
     if rank == 0:
         ms = 1e3 * dt / args.steps
         value = B * world * args.steps / dt
-        n_launch = sum(len(pl[k]) for m in nets for pl in m._engine()._plans.values() for k in ("pre", "fwd", "bwd", "bwd_b") if k in pl)
+        n_launch = sum(len(pl[k]) for m in nets for pl in m._engine()._plans.values() for k in ("pack_late", "pre", "fwd", "fwd_b", "bwd", "bwd_b") if k in pl)
         out = {
             "metric": "training img/s (16x64->32x128, bs=%d/GPU), %s full train step" % (B, "TPGSR-TSRN" if cfg["tl"] else "TSRN"),
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

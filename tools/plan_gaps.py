@@ -33,7 +33,7 @@ def all_plans(nets):
         eng = net._engine()
         role = getattr(eng, "role", "")
         for j, (key, pl) in enumerate(eng._plans.items()):
-            for pname in ("pre", "fwd", "bwd", "bwd_b", "dgray"):
+            for pname in ("pack_late", "pre", "fwd", "fwd_b", "bwd", "bwd_b", "dgray"):
                 if pname in pl and pl[pname]._native:
                     out.append((f"{type(net).__name__}{'(' + role + ')' if role else ''}.{pname}#{j}", pl[pname]))
     return out

@@ -525,7 +525,8 @@ class _EngineBase:
 
     def add_pack(self, src, dst_f, dst_d, Cout=0, Cin=0, KH=1, KW=1, kind=0, f_ld=0, f_coff=0, wscale=1.0, src2=None, src3=None,
                  numel=None, d_ld=0, cin_ld=0):
-        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld))
+        self._pack.append((src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld,
+                           getattr(self, "_pack_group", 0)))
 
     def register_operand(self, *tensors, cins=None):
         """fp32 MFMA operands [K][ld] packed by the pack program: get a bf16 split twin when the bf16 matrix-core path is on.
@@ -536,9 +537,14 @@ class _EngineBase:
                 assert t.dim() == 2 and t.is_contiguous()
                 self._operands.append(t)
                 t._tpgsr_cin = K.block_order_cin(t.shape[0], cins[i] if cins else 0)
+                t._tpgsr_group = getattr(self, "_pack_group", 0)
 
+    # Pack / split tables per GROUP (engine attribute `_pack_group` while the layers are built; 0 unless a network says otherwise): the
+    # text-prior generator packs its first three convolutions' operands on the caller's stream and everything behind them -- 96 % of its
+    # parameters -- on another stream while those convolutions run (CRNNEngine; pack_group()).
     def _finish_split_table(self):
         from ._lib import SplitDesc, load
+        self._split_tabs = {}
         self._split_n = 0
         ops, seen = [], set()
         for t in self._operands:
@@ -548,48 +554,54 @@ class _EngineBase:
         if K.POLICY == "f32" or not ops:
             return
         lib = load()
-        arr = (SplitDesc * len(ops))()
-        blk = 0
         self._split_keep = []
-        for d, t in zip(arr, ops):
-            Kd, N = t.shape
-            kp = (Kd + 31) // 32 * 32
-            twin = torch.zeros(3 * ((N + 31) // 32 * 32) * kp, dtype=torch.bfloat16, device=self.device)
-            cin = getattr(t, "_tpgsr_cin", 0)
-            K.register_bf_twin(t, twin, kp, cin)
-            d.src, d.dst, d.K, d.N, d.ld, d.kp, d.blk0, d.cin = t.data_ptr(), twin.data_ptr(), Kd, N, N, kp, blk, cin
-            blk += lib.tpgsr_split_bf_blocks(Kd, N)
-            self._split_keep += [t, twin]
-        self._split_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        self._split_n, self._split_blocks = len(ops), blk
+        for grp in sorted({getattr(t, "_tpgsr_group", 0) for t in ops}):
+            sel = [t for t in ops if getattr(t, "_tpgsr_group", 0) == grp]
+            arr = (SplitDesc * len(sel))()
+            blk = 0
+            for d, t in zip(arr, sel):
+                Kd, N = t.shape
+                kp = (Kd + 31) // 32 * 32
+                twin = torch.zeros(3 * ((N + 31) // 32 * 32) * kp, dtype=torch.bfloat16, device=self.device)
+                cin = getattr(t, "_tpgsr_cin", 0)
+                K.register_bf_twin(t, twin, kp, cin)
+                d.src, d.dst, d.K, d.N, d.ld, d.kp, d.blk0, d.cin = t.data_ptr(), twin.data_ptr(), Kd, N, N, kp, blk, cin
+                blk += lib.tpgsr_split_bf_blocks(Kd, N)
+                self._split_keep += [t, twin]
+            self._split_tabs[grp] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(sel), blk)
+        self._split_n = len(ops)
 
     def _finish_pack_table(self):
         from ._lib import load
         lib = load()
-        n = len(self._pack)
-        arr = (PackDesc * n)()
-        blk = 0
+        self._pack_tabs = {}
         self._pack_keep = []
-        for i, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld) in enumerate(self._pack):
-            d = arr[i]
-            d.src, d.dst_f = src.data_ptr(), dst_f.data_ptr()
-            d.dst_d = dst_d.data_ptr() if dst_d is not None else None
-            d.src2 = src2.data_ptr() if src2 is not None else None
-            d.src3 = src3.data_ptr() if src3 is not None else None
-            d.Cout, d.Cin, d.KH, d.KW, d.kind, d.f_ld, d.f_coff, d.wscale = Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale
-            d.d_ld, d.cin_ld = d_ld, cin_ld
-            cnt = src.numel() if numel is None else numel
-            d.numel, d.blk0 = cnt, blk
-            blk += lib.tpgsr_pack_blocks(kind, Cout, Cin, KH, KW, cnt)
-            self._pack_keep += [src, dst_f, dst_d, src2, src3]
-        raw = bytes(arr)
-        self._pack_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-        self._pack_n, self._pack_blocks = n, blk
+        for grp in sorted({e[16] for e in self._pack}):
+            sel = [e for e in self._pack if e[16] == grp]
+            arr = (PackDesc * len(sel))()
+            blk = 0
+            for d, (src, dst_f, dst_d, Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale, src2, src3, numel, d_ld, cin_ld, _g) in zip(arr, sel):
+                d.src, d.dst_f = src.data_ptr(), dst_f.data_ptr()
+                d.dst_d = dst_d.data_ptr() if dst_d is not None else None
+                d.src2 = src2.data_ptr() if src2 is not None else None
+                d.src3 = src3.data_ptr() if src3 is not None else None
+                d.Cout, d.Cin, d.KH, d.KW, d.kind, d.f_ld, d.f_coff, d.wscale = Cout, Cin, KH, KW, kind, f_ld, f_coff, wscale
+                d.d_ld, d.cin_ld = d_ld, cin_ld
+                cnt = src.numel() if numel is None else numel
+                d.numel, d.blk0 = cnt, blk
+                blk += lib.tpgsr_pack_blocks(kind, Cout, Cin, KH, KW, cnt)
+                self._pack_keep += [src, dst_f, dst_d, src2, src3]
+            self._pack_tabs[grp] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(sel), blk)
+
+    def pack_group(self, grp):
+        if grp in self._pack_tabs:
+            K.pack_program(*self._pack_tabs[grp])
+        if grp in self._split_tabs:
+            K.split_bf_program(*self._split_tabs[grp])
 
     def pack_all(self):
-        K.pack_program(self._pack_dev, self._pack_n, self._pack_blocks)
-        if self._split_n:
-            K.split_bf_program(self._split_dev, self._split_n, self._split_blocks)
+        for grp in sorted(set(self._pack_tabs) | set(self._split_tabs)):
+            self.pack_group(grp)
 
     # Training-mode plans re-pack their operands from the parameters at the start of every forward pass (Adam has just changed them).
     # An EVAL-mode network -- the frozen teacher recogniser of the TPGSR step, everything under TextSREvaluator -- keeps its

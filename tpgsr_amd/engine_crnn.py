@@ -217,11 +217,15 @@ class CRNNEngine(_EngineBase):
     # (kernel, stride, padding) of pooling0..3 (crnn.py:56-66); None = no pooling after that conv
     POOLS = {0: ((2, 2), (2, 2), (0, 0)), 1: ((2, 2), (2, 2), (0, 0)), 3: ((2, 2), (2, 1), (0, 1)), 5: ((2, 2), (2, 1), (0, 1))}
     BN_AT = (2, 4, 6)
+    EARLY_CONVS = 3          # convolutions of pack group 0 = the part of the forward plan in front of the cut (TPGSR_CRNN_PACK_SPLIT=0: no cut)
 
     def _build_layers(self):
         self.convs, self.bns = [], {}
         for i in range(7):
             k, pad = (3, 1) if i < 6 else (2, 0)
+            # pack group 0: conv0..conv2 (0.37 M parameters), packed at the start of the forward plan; group 1: everything behind them
+            # (8 M), packed by a plan of its own -- a train step runs it on another stream while conv0..conv2 execute (forward(late_stream=))
+            self._pack_group = 0 if i < self.EARLY_CONVS else 1
             if i == 0:
                 self.convs.append(Conv0Im2col(self, "cnn.conv0.weight", "cnn.conv0.bias"))
             else:
@@ -229,6 +233,7 @@ class CRNNEngine(_EngineBase):
             if i in self.BN_AT:
                 self.bns[i] = BNLayer(self, f"cnn.batchnorm{i}")
         self.lstm = [LstmLayer(self, "rnn.0"), LstmLayer(self, "rnn.1")]
+        self._pack_group = 0
         self.nclass = self.P["rnn.1.embedding.weight"].shape[0]
 
     def _dims(self):
@@ -252,7 +257,9 @@ class CRNNEngine(_EngineBase):
 
     def _record(self, N, training, ws, final):
         fwd, bwd, bwd_b, dgp, pack = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_bwd_b"), Plan("crnn_dgray"), Plan("crnn_pack")
-        fwd.final = bwd.final = bwd_b.final = dgp.final = pack.final = final
+        fwd_b, pack_late = Plan("crnn_fwd_b"), Plan("crnn_pack_late")
+        fwd.final = bwd.final = bwd_b.final = dgp.final = pack.final = fwd_b.final = pack_late.final = final
+        split_pack = training and os.environ.get("TPGSR_CRNN_PACK_SPLIT", "1") != "0"
         # weight gradients on the side stream + one batched slab reduce, as in TSRNEngine (every buffer a weight-gradient
         # launch reads -- ds{i}, saved activations, the LSTM gate gradients after the time loop -- is written once per pass)
         bwd.overlap = bwd_b.overlap = os.environ.get("TPGSR_OVERLAP_WGRAD", "1") != "0"
@@ -264,8 +271,11 @@ class CRNNEngine(_EngineBase):
         if not training:     # eval mode (the frozen teacher, evaluation): pack + split only when the parameters changed (pack_if_stale)
             with recording(pack):
                 self.pack_all()
+        if split_pack:
+            with recording(pack_late):
+                self.pack_group(1)
         with recording(fwd), K.conv_terms(K.terms_for(getattr(self, "role", "tpg"), "fwd")):
-            self._record_fwd(N, training, ws)
+            self._record_fwd(N, training, ws, cut_to=fwd_b if split_pack else None)
         if training:
             with recording(bwd), K.conv_terms(K.terms_for("tpg", "bwd")):
                 # the pass is recorded as TWO plans, cut behind the early slab reduce: every gradient from conv3 to the end of the
@@ -280,14 +290,21 @@ class CRNNEngine(_EngineBase):
         out = dict(fwd=fwd, bwd=bwd, dgray=dgp, pack=pack, ws=ws)
         if len(bwd_b):
             out["bwd_b"] = bwd_b
+        if split_pack:
+            out["fwd_b"], out["pack_late"] = fwd_b, pack_late
         return out
 
-    def _record_fwd(self, N, training, ws):
+    def _record_fwd(self, N, training, ws, cut_to=None):
         if training:
-            self.pack_all()
+            if cut_to is not None:
+                self.pack_group(0)       # (group 1: the plan `pack_late`, run before the second half)
+            else:
+                self.pack_all()
         dims = self._dims()
         cur, loader = K.DynPtr("gray"), {}        # conv0's im2col reads the caller's tensor directly (patched per call)
         for i, conv in enumerate(self.convs):
+            if cut_to is not None and i == self.EARLY_CONVS:
+                K.continue_in(cut_to)        # everything from here on reads operands of pack group 1
             (h, w), (oh, ow), (ph, pw) = dims[i]
             s = ws(f"s{i}", N * oh * ow, conv.Cout)
             bn = self.bns.get(i)
@@ -400,8 +417,11 @@ class CRNNEngine(_EngineBase):
         self.convs[0].dgrad(N, h, w, ws.t["ds0"], dcol, K.DynPtr("dgray"))
 
     # ---- execution ----------------------------------------------------------------------------------------------
-    def forward(self, gray: torch.Tensor, training: bool, slot: int = 0) -> torch.Tensor:
-        """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major; the module returns the (T, N, C) view)"""
+    def forward(self, gray: torch.Tensor, training: bool, slot: int = 0, late_stream=None, after_late=None) -> torch.Tensor:
+        """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major; the module returns the (T, N, C) view).
+        late_stream (training): the stream the operands behind conv2 are packed on, next to conv0..conv2 on the caller's stream (which
+        waits for it before conv3); None: everything in order on the caller's stream.  after_late(): called once that packing is enqueued
+        (or right away when there is none) -- a train step queues the SR network's prologue behind it on the same stream"""
         if not gray.is_cuda and not K.DRYRUN:
             raise RuntimeError("tpgsr_amd runs on the GPU only (no CPU fallback): move the module and inputs to cuda")
         if gray.dim() != 4 or gray.shape[1] != 1 or tuple(gray.shape[2:]) != self.IMG_HW:
@@ -413,10 +433,28 @@ class CRNNEngine(_EngineBase):
         logits = torch.empty(N, self.T, self.nclass, dtype=F32, device=gray.device)
         fwd = pl["fwd"]
         fwd.set_ptr("gray", gray.data_ptr())
-        fwd.set_ptr("logits", logits.data_ptr())
-        if not training:
-            self.pack_if_stale(pl["pack"])
-        fwd.run()
+        if "fwd_b" in pl:
+            cur, ev = K.current_stream(), None
+            if late_stream is not None and late_stream is not cur:
+                K.order(late_stream, cur)        # (the previous step's optimiser wrote the parameters on the caller's stream)
+                with K.stream_ctx(late_stream):
+                    pl["pack_late"].run()
+                ev = K.event_record(late_stream)
+            else:
+                pl["pack_late"].run()
+            if after_late is not None:
+                after_late()
+            fwd.run()
+            K.event_wait(cur, ev)
+            pl["fwd_b"].set_ptr("logits", logits.data_ptr())
+            pl["fwd_b"].run()
+        else:
+            if after_late is not None:
+                after_late()
+            fwd.set_ptr("logits", logits.data_ptr())
+            if not training:
+                self.pack_if_stale(pl["pack"])
+            fwd.run()
         if training:
             self.note_packed()
             self._pending_batches += 1

@@ -112,8 +112,11 @@ class FunctionalEngine:
         return out
 
     # ---- the engine protocol --------------------------------------------------------------------------------------------------------
-    def forward(self, gray: torch.Tensor, training: bool, slot: int = 0) -> torch.Tensor:
-        """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major, like CRNNEngine.forward)"""
+    def forward(self, gray: torch.Tensor, training: bool, slot: int = 0, late_stream=None, after_late=None) -> torch.Tensor:
+        """gray (N, 1, 32, 100) -> logits [N][T][nclass] (batch-major, like CRNNEngine.forward; late_stream / after_late: CRNNEngine's
+        protocol -- nothing is packed apart here, the callback runs first)"""
+        if after_late is not None:
+            after_late()
         if bool(self.module.training) != bool(training):
             raise RuntimeError(f"{type(self.module).__name__}: forward(training={training}) on a module in "
                                f"{'train' if self.module.training else 'eval'}() mode")

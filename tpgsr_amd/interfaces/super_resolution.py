@@ -263,12 +263,15 @@ class TPGSRTrainStep:
         for i in range(self.stu_iter):
             stu = self.stu[0 if self.tpg_share else i]
             srm = self.sr[0 if self.sr_share else i]
-            if pre_side:
+            K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
+
+            def sr_prologue(srm=srm, i=i):
                 K.order(side, main)
                 with K.stream_ctx(side):
                     srm._engine().forward_pre(lr_img, True, slot=i, defer_join=self._defer_join)
-            K.bicubic_gray_fwd(cascade, N, C, ch, cw, 32, 100, st["gray"][i])
-            logits = stu._engine().forward(st["gray"][i], True, slot=i)
+            # the generator packs the operands behind its third convolution on the weight-gradient stream too (next to conv0..conv2 on this
+            # one) and queues the SR prologue behind that packing
+            logits = stu._engine().forward(st["gray"][i], True, slot=i, late_stream=side, after_late=sr_prologue if pre_side else None)
             self._mark(f"student{i} fwd")
             if i == 0:
                 K.order(main, aux)              # the teacher's distribution q is needed from here on

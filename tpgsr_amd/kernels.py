@@ -151,6 +151,26 @@ def order(dst, src):
         check(_lib.load().tpgsr_plan_fuzz_point(dst.cuda_stream), "tpgsr_plan_fuzz_point")
 
 
+def event_record(stream):
+    """an event at the current tail of `stream` (None under the serial schedule / dry run: program order is the order)"""
+    if SERIAL or DRYRUN:
+        return None
+    if FUZZ:
+        check(_lib.load().tpgsr_plan_fuzz_point(stream.cuda_stream), "tpgsr_plan_fuzz_point")
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+def event_wait(stream, ev):
+    """`stream` waits for an event_record() event (and for nothing enqueued behind it on the recording stream)"""
+    if ev is None:
+        return
+    stream.wait_event(ev)
+    if FUZZ:
+        check(_lib.load().tpgsr_plan_fuzz_point(stream.cuda_stream), "tpgsr_plan_fuzz_point")
+
+
 def parse_cu_mask(spec: str):
     """'0xffff...': hex bit mask (bit i = CU i); 'N' or 'N/S': N CUs, every S-th (default: the first N)"""
     if spec.lower().startswith("0x"):
