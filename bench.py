@@ -135,7 +135,17 @@ def conv_family(nets):
             for pname in ("pre", "fwd", "fwd_b", "bwd", "bwd_b"):
                 if pname not in pl:
                     continue
-                for name, fn, args, _sid in pl[pname].ops:
+                for oi, (name, fn, args, _sid) in enumerate(pl[pname].ops):
+                    if name == "tpgsr_conv_wgrad_batch":
+                        # several independent 1x1 weight gradients in one launch (the BiLSTM layers'): FLOPs / bytes of its items
+                        ws = pl[pname].meta.get(oi)
+                        if ws:
+                            c0 = ws[0].c
+                            fl = sum(2.0 * w.c.N * w.c.OH * w.c.OW * w.c.Cin * w.c.Cout for w in ws)
+                            by = sum(4.0 * w.c.N * w.c.OH * w.c.OW * (w.c.Cin + w.c.Cout) for w in ws)
+                            items.append(dict(kind="wgrad", terms=c0.terms, shape=(c0.N, c0.H, c0.W, c0.Cin, c0.Cout, 1, 1),
+                                              label=f"{len(ws)} GEMMs of a BiLSTM layer in one launch", flops=fl, bytes=by, fn=fn, args=args))
+                        continue
                     if name == "tpgsr_conv_fwd":
                         a = args[0]._obj          # the ConvArgs struct behind the recorded ctypes.byref()
                         kind, terms = ("dgrad" if pname.startswith("bwd") else "fwd"), (a.terms if (a.terms and a.wt_bf) else 0)

@@ -9,8 +9,10 @@ import json
 import sys
 from collections import defaultdict
 
-CLASSES = [("conv fwd/dgrad (halo)", "conv_halo_xbf_kernel"), ("conv fwd/dgrad (tile loop)", "conv_fwd_xbf_kernel"),
-           ("conv wgrad", "conv_wgrad"), ("dy_split", "dy_split_kernel"), ("wgrad slab reduce", "wgrad_reduce_program"),
+CLASSES = [("conv fwd/dgrad (halo)", "conv_halo_xbf_kernel"), ("conv fwd/dgrad (halo)", "conv_halo3_xbf_kernel"),
+           ("conv fwd/dgrad (tile loop)", "conv_fwd_xbf_kernel"), ("conv fwd/dgrad (tile loop)", "conv_panel_xbf_kernel"),
+           ("conv fwd/dgrad (tile loop)", "conv_fwd_kernel"),
+           ("conv wgrad", "conv_wgrad"), ("conv wgrad", "gru_wgrad_kernel"), ("dy_split", "dy_split_kernel"), ("wgrad slab reduce", "wgrad_reduce_program"),
            ("BiGRU", "bigru_"), ("BiLSTM", "lstm_"), ("BatchNorm", "bn_"), ("optimiser", "adam_step")]
 
 

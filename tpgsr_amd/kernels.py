@@ -239,6 +239,7 @@ class Plan:
         self.name = name
         self.ops = []      # [name, cfunc, [args...], stream id]; cfunc None: "fork" / "join" / "edge" (args = (src, dst)) stream dependencies
         self.keep = []     # tensors / arg structs referenced by raw pointer
+        self.meta = {}     # op index -> what a table-driven launch consists of (bench.py's launch census reads it)
         self.dyn = {}      # key -> [(op index, arg index)]
         self.sid = 0       # stream the next recorded launch goes to: 0 = the caller's stream, 1 = side stream, 2 = leaf stream
         self.forks = 0
@@ -711,6 +712,8 @@ def conv_wgrad_batch(wargs):
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(torch.device("cpu") if DRYRUN else torch.device("cuda", torch.cuda.current_device()))
     if _REC is not None:
         _REC.keep.append(list(wargs))
+        if not (_REC.hold is not None and _REC.sid == 1):
+            _REC.meta[len(_REC.ops)] = [it.w for it in arr]
     _launch("tpgsr_conv_wgrad_batch", _p(table), len(items), blk, key[0], key[1])
     if rest:
         conv_wgrad_batch(rest)      # (another loader variant: a batch of its own, or a single launch)
