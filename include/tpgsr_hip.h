@@ -100,6 +100,30 @@ typedef struct {
   int bnb_store_dz;       /* 1: `out` receives dz instead of da.  With bn_partial NULL this is a plain activation backward on the
                              way out -- out = da * act'(y * scale + shift), scale / shift optional (1 / 0) -- which is how the mish
                              in front of the tail convolution (model/tsrn.py:39,159) is differentiated without a launch of its own */
+  /* --- BatchNorm FINALIZE by the launch itself (fin_mode != 0; needs bn_partial).  What follows a statistics-producing convolution in
+   *     the reference -- nn.BatchNorm2d's batch mean / variance (forward) or batch_norm_backward's coefficients (backward) -- is a
+   *     reduction of bn_partial's ceil(M / 64) rows: a 3 us kernel behind a 5 us launch boundary, 36 times per C3 step.  With fin_mode
+   *     set tpgsr_conv_fwd guarantees it has run when the call's work is done: kernels that can (the whole-CU halo kernel) let their
+   *     LAST workgroup do it -- partial rows by write-through stores, one relaxed agent-scope ticket per workgroup, the last one reads
+   *     the rows back with L1-bypassing loads and sums them in a FIXED order, so the result does not depend on which workgroup it was --
+   *     for every other kernel the launcher appends tpgsr_bn_finalize / tpgsr_bn_bwd_finalize on the same stream.
+   *     mode 1 (forward):  scale / shift / save_mean / save_rstd (+ running statistics) as tpgsr_bn_finalize, count = M
+   *     mode 2 (backward): dgamma += sum dz xhat, dbeta += sum dz, coef [3][Cout] as tpgsr_bn_bwd_finalize (mean / rstd = bnb_mean / bnb_rstd) --- */
+  int fin_mode;
+  int fin_accumulate;        /* mode 2: 1 = add to dgamma / dbeta */
+  long long fin_count;       /* elements per channel the statistics were taken over */
+  int* fin_counter;          /* one zero-initialised int of device memory per BatchNorm layer; left at zero */
+  const float* fin_gamma;    /* [Cout] */
+  const float* fin_beta;     /* mode 1 */
+  const float* fin_bias;     /* mode 1: the convolution's bias when it is NOT part of `out` already (mean shift), or NULL */
+  float* fin_scale;          /* mode 1: [Cout] folded scale;    mode 2: coef [3][Cout] */
+  float* fin_shift;          /* mode 1: [Cout] folded shift;    mode 2: dgamma [Cout] or NULL */
+  float* fin_mean;           /* mode 1: save_mean [Cout] or NULL; mode 2: dbeta [Cout] or NULL */
+  float* fin_rstd;           /* mode 1: save_rstd [Cout] or NULL */
+  float* fin_rm;             /* mode 1: running_mean / running_var [Cout] or NULL */
+  float* fin_rv;
+  float fin_momentum;
+  float fin_eps;
 } tpgsr_conv_args;
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);

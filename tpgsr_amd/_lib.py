@@ -31,7 +31,10 @@ class ConvArgs(C.Structure):
                 ("out_ld", ci), ("out_coff", ci), ("out_act", ci), ("out_ps", ci),
                 ("in_b", vp), ("cin_a", ci), ("in_b_ld", ci), ("in_dil_w", ci), ("wt_ld", ci), ("wt_coff", ci), ("stride_w", ci),
                 ("terms", ci), ("kp", ci), ("wt_bf", vp), ("wt_bf_cin", ci), ("reserved0", ci),
-                ("bnb_y", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_act", ci), ("bnb_store_dz", ci)]
+                ("bnb_y", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_act", ci), ("bnb_store_dz", ci),
+                ("fin_mode", ci), ("fin_accumulate", ci), ("fin_count", ll), ("fin_counter", vp), ("fin_gamma", vp), ("fin_beta", vp),
+                ("fin_bias", vp), ("fin_scale", vp), ("fin_shift", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_rm", vp), ("fin_rv", vp),
+                ("fin_momentum", cf), ("fin_eps", cf)]
 
 
 class WgradArgs(C.Structure):

@@ -158,9 +158,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
       if (!item(PN{}, P0{})) break;
     }
     __syncthreads();        // the final barrier (the consumers' last statistics flush)
-    return;
+    goto fin_tail;
   }
 
+  {
   // ------------------------------- consumers -------------------------------
   const int wm = wave & 1, wn = wave >> 1;
   const int wrows = a.wt_ld > 0 ? a.wt_ld : a.Cout;
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
     if (pend_mblk >= 0) {
 #pragma unroll
       for (int m = 0; m < H3_TM; ++m)
-        if ((pend_mblk + m) * 64 < M) xbf_bn_flush<1, 1>(a, M, pend_n0, pend_mblk + m, tid, red_base + (((ndone - 1) & 1) * H3_TM + m) * 256);
+        if ((pend_mblk + m) * 64 < M)
+          xbf_bn_flush<1, 1>(a, M, pend_n0, pend_mblk + m, tid, red_base + (((ndone - 1) & 1) * H3_TM + m) * 256, a.fin_mode != 0);
       pend_mblk = -1;
     }
   };
@@ -516,6 +518,21 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
   }
   __syncthreads();            // the final barrier
   flush_pending();
+  }
+fin_tail:
+  // BatchNorm finalize by the LAST workgroup (tpgsr_conv_args.fin_mode): this workgroup's partial rows have left as write-through
+  // stores; once they are acknowledged it draws a ticket, and whoever draws the last one reduces all rows (conv_xbf_common.h)
+  if (a.fin_mode) {
+    __shared__ int s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket == (int)gridDim.x - 1) {
+      xbf_fin_last(a, M, tid, 512, reinterpret_cast<double*>(hsm));
+      if (tid == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 /* upper bound of the halo length of any run of 64 * H3_TM consecutive output pixels (cf. halo_capacity in conv_xbf.hip) */
@@ -525,6 +542,8 @@ static int halo3_capacity(const tpgsr_conv_args* a) {
   const int img_wraps = (ohw % P == 0) ? 0 : (P - 1) / ohw + 1;
   return P - 1 + row_wraps * (a->KW - 1) + img_wraps * (a->KH - 1) * Wp + (a->KH - 1) * Wp + a->KW;
 }
+
+extern "C" void tpgsr_conv_fin_fused_mark(void);      // conv_mfma.hip
 
 extern "C" int tpgsr_halo3_trace(unsigned long long* buf) {   // buf: 8 * 8 * 256 uint64 of device memory, or nullptr to switch off
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_halo3_trace), &buf, sizeof(buf)) != hipSuccess) {
@@ -597,5 +616,6 @@ extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M
     tpgsr_set_error("tpgsr_conv_fwd(halo3): launch failed: %s", hipGetErrorString(hipGetLastError()));
     return TPGSR_ERR_LAUNCH;
   }
+  if (a->fin_mode) tpgsr_conv_fin_fused_mark();      // this kernel's last workgroup finalizes the BatchNorm (conv_mfma.hip: no extra launch)
   return 1;
 }

@@ -104,6 +104,11 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned o
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off_bytes, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// (sc1: served by the L2 / fabric, never by this CU's vector L1 -- data another workgroup wrote through during this launch)
+__device__ __forceinline__ float4 buf_load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned off_bytes) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off_bytes, 0, 16);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off_bytes) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off_bytes, 0, 0));
 }

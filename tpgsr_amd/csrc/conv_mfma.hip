@@ -350,7 +350,36 @@ static int loader_bits(const tpgsr_conv_args* a) {
   return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0);
 }
 
+// set by a launcher whose kernel finalizes the BatchNorm itself (tpgsr_conv_args.fin_mode): per host thread, valid for the current call
+thread_local int g_tpgsr_fin_fused = 0;
+extern "C" void tpgsr_conv_fin_fused_mark(void) { g_tpgsr_fin_fused = 1; }
+extern "C" int tpgsr_bn_finalize(const float* partial, int nblk, int C, long long count, const float* conv_bias, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps, int eval,
+                                 float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+extern "C" int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long long count, const float* gamma, const float* save_mean,
+                                     const float* save_rstd, float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
+static int conv_fwd_impl(const tpgsr_conv_args* a, void* stream);
+
 extern "C" int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream) {
+  if (!a || !a->fin_mode) return conv_fwd_impl(a, stream);
+  TPGSR_CHECK_ARG((a->fin_mode == 1 || a->fin_mode == 2) && a->bn_partial && a->fin_counter && a->fin_gamma && a->fin_scale && a->fin_count > 0,
+                  "tpgsr_conv_fwd: fin_mode %d needs bn_partial, fin_counter, fin_gamma, fin_scale, fin_count", a->fin_mode);
+  TPGSR_CHECK_ARG(a->fin_mode == 1 ? (a->fin_beta && a->fin_shift && !a->bnb_y) : (a->bnb_y && a->bnb_mean && a->bnb_rstd),
+                  "tpgsr_conv_fwd: fin_mode 1 goes with forward statistics (fin_beta, fin_shift), fin_mode 2 with the BatchNorm-backward epilogue");
+  g_tpgsr_fin_fused = 0;
+  const int rc = conv_fwd_impl(a, stream);
+  if (rc || g_tpgsr_fin_fused) return rc;
+  // the kernel that took the launch does not finalize: the reduction as a launch of its own, as before
+  const long long M = (long long)a->N * a->OH * a->OW;
+  const int nblk = (int)cdiv(M, 64);
+  if (a->fin_mode == 1)
+    return tpgsr_bn_finalize(a->bn_partial, nblk, a->Cout, a->fin_count, a->fin_bias, a->fin_gamma, a->fin_beta, a->fin_rm, a->fin_rv,
+                             a->fin_momentum, a->fin_eps, 0, a->fin_scale, a->fin_shift, a->fin_mean, a->fin_rstd, stream);
+  return tpgsr_bn_bwd_finalize(a->bn_partial, nblk, a->Cout, a->fin_count, a->fin_gamma, a->bnb_mean, a->bnb_rstd, a->fin_shift, a->fin_mean,
+                               a->fin_accumulate, a->fin_scale, stream);
+}
+
+static int conv_fwd_impl(const tpgsr_conv_args* a, void* stream) {
   int rc = check_conv_args(a, "tpgsr_conv_fwd");
   if (rc) return rc;
   TPGSR_CHECK_ARG(a->wt && a->out, "tpgsr_conv_fwd: null weight/output");

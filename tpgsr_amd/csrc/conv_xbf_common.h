@@ -209,8 +209,11 @@ __device__ __forceinline__ void xbf_store_tile_wide(const tpgsr_conv_args& a, fl
 }
 
 // after a barrier: statistics per 64-pixel row block (the layout bn_finalize expects) out of the wave rows' partials
+// (write_through: the rows leave as agent-scope relaxed atomic stores = `sc1` write-through -- for a launch whose LAST workgroup reads
+//  every row back, tpgsr_conv_args.fin_mode: per-XCD L2s are not coherent with each other)
 template <int WMB, int WNB>
-__device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, int n0, int mblk, int tid, const float* red) {
+__device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, int n0, int mblk, int tid, const float* red,
+                                             const bool write_through = false) {
   constexpr int BNT = 64 * WNB;
   // WMB = 1: the two wave rows together are the one 64-pixel block; WMB = 2: each wave row is a block of its own
   for (int e = tid; e < BNT * WMB; e += 256) {
@@ -218,14 +221,87 @@ __device__ __forceinline__ void xbf_bn_flush(const tpgsr_conv_args& a, int M, in
     const long long rb64 = (long long)mblk * WMB + blk;
     if (n0 + c < a.Cout && rb64 * 64 < M) {
       float* dst = a.bn_partial + (size_t)rb64 * 2 * a.Cout;
+      float v0, v1;
       if (WMB == 1) {
-        dst[n0 + c] = red[0 * BNT + c] + red[2 * BNT + c];
-        dst[a.Cout + n0 + c] = red[1 * BNT + c] + red[3 * BNT + c];
+        v0 = red[0 * BNT + c] + red[2 * BNT + c];
+        v1 = red[1 * BNT + c] + red[3 * BNT + c];
       } else {
-        dst[n0 + c] = red[(blk * 2 + 0) * BNT + c];
-        dst[a.Cout + n0 + c] = red[(blk * 2 + 1) * BNT + c];
+        v0 = red[(blk * 2 + 0) * BNT + c];
+        v1 = red[(blk * 2 + 1) * BNT + c];
+      }
+      if (write_through) {
+        __hip_atomic_store(dst + n0 + c, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + a.Cout + n0 + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        dst[n0 + c] = v0;
+        dst[a.Cout + n0 + c] = v1;
       }
     }
+  }
+}
+
+// BatchNorm finalize by the last workgroup of a launch (tpgsr_conv_args.fin_mode): called by ALL `nthreads` threads (a multiple of 64, >= 256)
+// of the workgroup that drew the last ticket, behind a barrier; `scr` = 33 KB of LDS nobody reads any more.  64 channels at a time:
+// thread (row lane rl = tid / 16, channel quad q = tid % 16) sums rows rl, rl + RL, ... of its four channels in fp64 from 16-byte
+// L1-bypassing loads (the rows were written through by other workgroups, possibly on other XCDs), the RL partial sums per channel
+// are added in lane order.  The order of the additions depends on (nblk, nthreads) only: every run gives the same bits.
+__device__ __forceinline__ void xbf_fin_last(const tpgsr_conv_args& a, const int M, const int tid, const int nthreads, double* scr) {
+  const int C = a.Cout, nblk = (M + 63) >> 6;
+  const int RL = nthreads >> 4, rl = tid >> 4, q = tid & 15;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bn_partial, (size_t)nblk * 2 * C);
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    const int cq = c0 + q * 4;
+    if (cq < C) {
+      for (int b = rl; b < nblk; b += RL) {
+        const float4 u = buf_load4_sc1(rs, ((unsigned)(b * 2 + 0) * (unsigned)C + (unsigned)cq) * 4u);
+        const float4 v = buf_load4_sc1(rs, ((unsigned)(b * 2 + 1) * (unsigned)C + (unsigned)cq) * 4u);
+        s[0] += (double)u.x; s[1] += (double)u.y; s[2] += (double)u.z; s[3] += (double)u.w;
+        ss[0] += (double)v.x; ss[1] += (double)v.y; ss[2] += (double)v.z; ss[3] += (double)v.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      scr[(rl * 64 + q * 4 + i) * 2 + 0] = s[i];
+      scr[(rl * 64 + q * 4 + i) * 2 + 1] = ss[i];
+    }
+    __syncthreads();
+    if (tid < 64 && c0 + tid < C) {
+      const int c = c0 + tid;
+      double S = 0.0, SS = 0.0;
+      for (int r = 0; r < RL; ++r) {
+        S += scr[(r * 64 + tid) * 2 + 0];
+        SS += scr[(r * 64 + tid) * 2 + 1];
+      }
+      const double count = (double)a.fin_count;
+      if (a.fin_mode == 1) {          // == bn_finalize_kernel (elementwise.hip)
+        const double mean_raw = S / count;
+        double var = SS / count - mean_raw * mean_raw;
+        if (var < 0.0) var = 0.0;
+        const double mean = mean_raw + (a.fin_bias ? (double)a.fin_bias[c] : 0.0);
+        const double rstd = 1.0 / sqrt(var + (double)a.fin_eps);
+        const double g = (double)a.fin_gamma[c];
+        a.fin_scale[c] = (float)(g * rstd);
+        a.fin_shift[c] = (float)((double)a.fin_beta[c] - mean * g * rstd);
+        if (a.fin_mean) a.fin_mean[c] = (float)mean;
+        if (a.fin_rstd) a.fin_rstd[c] = (float)rstd;
+        if (a.fin_rm) {
+          const double unbiased = a.fin_count > 1 ? var * count / (count - 1.0) : var;
+          const double mom = (double)a.fin_momentum;
+          a.fin_rm[c] = (float)((1.0 - mom) * (double)a.fin_rm[c] + mom * mean);
+          a.fin_rv[c] = (float)((1.0 - mom) * (double)a.fin_rv[c] + mom * unbiased);
+        }
+      } else {                        // == bn_bwd_finalize_kernel
+        if (a.fin_shift) a.fin_shift[c] = a.fin_accumulate ? a.fin_shift[c] + (float)SS : (float)SS;       // dgamma
+        if (a.fin_mean) a.fin_mean[c] = a.fin_accumulate ? a.fin_mean[c] + (float)S : (float)S;          // dbeta
+        const double rstd = (double)a.bnb_rstd[c], mu = (double)a.bnb_mean[c], g = (double)a.fin_gamma[c];
+        const double mdz = S / count, mdzx = SS / count, k0 = g * rstd;
+        a.fin_scale[c] = (float)k0;
+        a.fin_scale[C + c] = (float)(-k0 * mdzx * rstd);
+        a.fin_scale[2 * C + c] = (float)(-k0 * (mdz - mu * rstd * mdzx));
+      }
+    }
+    __syncthreads();
   }
 }
 // stage: 1024 floats of LDS per wave behind `red`'s 4 x 64 WNB floats (nullptr: four-byte stores)

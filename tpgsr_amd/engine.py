@@ -228,6 +228,9 @@ class BNLayer:
         self.pad_to = max(C_, pad_to)
         eng._bn_layers.append(self)
         self.scale = self.shift = self.save_mean = self.save_rstd = self.coef = None   # bound per plan by use(ws)
+        # ticket counters of the convolution launches that finalize this BatchNorm themselves (forward / backward; left at zero by the
+        # last workgroup; launches sharing one never overlap: they are the same layer's, in stream order)
+        self.tickets = torch.zeros(2, dtype=torch.int32, device=eng.device)
 
     def use(self, ws):
         """Batch statistics / folded scale+shift belong to ONE forward: they live in the plan's workspace (a network
@@ -254,6 +257,14 @@ class BNLayer:
             K.bn_finalize(None, 0, self.C, 0, None, self.gamma, self.beta, self.rm, self.rv, self.scale, self.shift,
                           eval_mode=True)
 
+    def fin(self, M, conv_bias):
+        """kwargs (`bn_fin=`) for the training-mode convolution that leaves this BatchNorm's statistics in partial(M): the launch
+        finalizes them itself (then finalize() is NOT recorded), or None when that is switched off / the fp32 kernels run"""
+        if not K.bn_fin_fused():
+            return None
+        return dict(mode=1, count=M, counter=self.tickets[0:1], gamma=self.gamma, beta=self.beta, bias=conv_bias, scale=self.scale,
+                    shift=self.shift, save_mean=self.save_mean, save_rstd=self.save_rstd, running_mean=self.rm, running_var=self.rv)
+
     @property
     def loader(self):
         return dict(in_scale=self.scale, in_shift=self.shift)
@@ -266,7 +277,11 @@ class BNLayer:
             return None
         nblk = (M + 63) // 64
         part = self.eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
-        return dict(y=y, mean=self.save_mean, rstd=self.save_rstd, scale=self.scale, shift=self.shift, act=act, partial=part)
+        d = dict(y=y, mean=self.save_mean, rstd=self.save_rstd, scale=self.scale, shift=self.shift, act=act, partial=part)
+        if K.bn_fin_fused():       # the producing launch also reduces the sums (backward(..., fused=) then records the apply only)
+            d["fin"] = dict(mode=2, count=M, counter=self.tickets[1:2], gamma=self.gamma, coef=self.coef,
+                            dgamma=self.eng.G[self.prefix + ".weight"], dbeta=self.eng.G[self.prefix + ".bias"], accumulate=True)
+        return d
 
     def backward(self, da, da2, y, M, act, dy, fused=None):
         """dy = dL/d(pre-BN y) from da (+da2) = dL/d act(BN(y)); accumulates dgamma/dbeta into the arena.
@@ -275,6 +290,9 @@ class BNLayer:
         if fused is not None:
             assert da2 is None and fused["y"] is y and fused["act"] == act
             nblk, part = (M + 63) // 64, fused["partial"]
+            if fused.get("fin") is not None and K.BN_FIN_FUSE:      # finalized by the producing launch
+                K.bn_bwd_apply(da, da2, y, M, self.C, self.scale, self.shift, act, self.coef, dy)
+                return
         else:
             nblk = min(1024, max(1, M // 64))
             part = eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
@@ -809,12 +827,16 @@ class TSRNEngine(_EngineBase):
             gt1 = ws(t + "gt1", P1, 256) if training else None      # GRU gate values, kept for back-propagation
             gt2 = ws(t + "gt2", P1, 256) if training else None
             part, _ = L["bn1"].partial(P1)
-            L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None)
-            L["bn1"].finalize(P1, L["conv1"].b, training)
+            fin = L["bn1"].fin(P1, L["conv1"].b) if training else None      # finalized by the convolution's own launch
+            L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None, bn_fin=fin)
+            if fin is None:
+                L["bn1"].finalize(P1, L["conv1"].b, training)
             a1 = ws(t + "a1", P1, Cc)                   # mish(bn1(y1)) once: a 3x3 consumer would re-apply it 9x per element
             K.affine_act(y1, P1, Cc, L["bn1"].scale, L["bn1"].shift, "mish", a1)
-            L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None)
-            L["bn2"].finalize(P1, L["conv2"].b, training)
+            fin = L["bn2"].fin(P1, L["conv2"].b) if training else None
+            L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None, bn_fin=fin)
+            if fin is None:
+                L["bn2"].finalize(P1, L["conv2"].b, training)
             if self.tl:   # torch.cat([bn2(y2), text strip], 1) inside the 1x1 conv's loader (model/tsrn.py:419-423)
                 L["gru1"].fwd(N, H, W, y2, gi1, h1, gt1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
             else:
@@ -823,8 +845,10 @@ class TSRNEngine(_EngineBase):
             cur = out
         y7 = ws("y7", P1, Cc)
         part, _ = self.bn7.partial(P1)
-        self.conv7.fwd(N, H, W, cur, y7, bn_partial=part if training else None)
-        self.bn7.finalize(P1, self.conv7.b, training)
+        fin = self.bn7.fin(P1, self.conv7.b) if training else None
+        self.conv7.fwd(N, H, W, cur, y7, bn_partial=part if training else None, bn_fin=fin)
+        if fin is None:
+            self.bn7.finalize(P1, self.conv7.b, training)
         ups = ws("ups", 4 * P1, Cc)                      # pre-mish, pixel-shuffled [N][2H][2W][C]
         self.up.fwd(N, H, W, y7, ups, in2=b1, out_ps=True, **self.bn7.loader)
         mu = ws("mups", 4 * P1, Cc)                      # mish(ups) once (the 9-tap tail conv and its wgrad both read it)

@@ -309,11 +309,13 @@ class CRNNEngine(_EngineBase):
             s = ws(f"s{i}", N * oh * ow, conv.Cout)
             bn = self.bns.get(i)
             part = bn.partial(N * oh * ow)[0] if (bn and training) else None
+            fin = None
             if i == 0:
                 conv.fwd(N, h, w, cur, ws("col0", N * h * w, 12), s)
             else:
-                conv.fwd(N, h, w, cur, s, bn_partial=part, **loader)
-            if bn:
+                fin = bn.fin(N * oh * ow, conv.b) if (bn and training) else None      # finalized by the convolution's own launch
+                conv.fwd(N, h, w, cur, s, bn_partial=part, bn_fin=fin, **loader)
+            if bn and fin is None:
                 bn.finalize(N * oh * ow, conv.b, training)
             if i in self.POOLS:
                 k, st, pd = self.POOLS[i]

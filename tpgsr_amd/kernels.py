@@ -568,9 +568,11 @@ class ConvGeom:
 
 def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, in_scale=None, in_shift=None, in_act=None,
                    in_ps=False, in_ld=None, in_coff=0, in2_ld=None, out_act=None, out_ps=False, out_ld=None, out_coff=0,
-                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1, bnb=None) -> ConvArgs:
+                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1, bnb=None, bn_fin=None) -> ConvArgs:
     """`bnb` (a dict from engine.BNLayer.fuse_stats): this convolution produces the gradient that enters a BatchNorm's backward pass --
-    its epilogue also writes that BatchNorm's two reduction sums per 64-pixel row block (tpgsr_conv_args.bnb_y)"""
+    its epilogue also writes that BatchNorm's two reduction sums per 64-pixel row block (tpgsr_conv_args.bnb_y).
+    `bn_fin` (a dict from engine.BNLayer.fin / fuse_stats(...)["fin"]): the launch also FINALIZES the BatchNorm whose statistics it
+    leaves in bn_partial -- by its last workgroup where the kernel can, by an appended launch otherwise (tpgsr_conv_args.fin_mode)"""
     a = ConvArgs()
     a.in_, a.in2, a.in_scale, a.in_shift = _p(inp), _p(in2), _p(in_scale), _p(in_shift)
     a.wt, a.bias, a.out, a.bn_partial = _p(wt), _p(bias), _p(out), _p(bn_partial)
@@ -609,7 +611,32 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
         a.bnb_y, a.bnb_mean, a.bnb_rstd = _p(bnb["y"]), _p(bnb.get("mean")), _p(bnb.get("rstd"))
         a.bnb_scale, a.bnb_shift, a.bnb_act = _p(bnb.get("scale")), _p(bnb.get("shift")), act_code(bnb["act"])
         a.bnb_store_dz = int(bool(bnb.get("store_dz", False)))   # without "partial": a plain activation backward on the way out
+        if bn_fin is None:
+            bn_fin = bnb.get("fin")
+    if bn_fin is not None and BN_FIN_FUSE:
+        f = bn_fin
+        a.fin_mode, a.fin_count, a.fin_counter, a.fin_gamma = f["mode"], f["count"], _p(f["counter"]), _p(f["gamma"])
+        if f["mode"] == 1:
+            a.fin_beta, a.fin_bias = _p(f["beta"]), _p(f.get("bias"))
+            a.fin_scale, a.fin_shift, a.fin_mean, a.fin_rstd = _p(f["scale"]), _p(f["shift"]), _p(f.get("save_mean")), _p(f.get("save_rstd"))
+            a.fin_rm, a.fin_rv = _p(f.get("running_mean")), _p(f.get("running_var"))
+            a.fin_momentum, a.fin_eps = f.get("momentum", 0.1), f.get("eps", 1e-5)
+        else:
+            a.fin_scale, a.fin_shift, a.fin_mean = _p(f["coef"]), _p(f.get("dgamma")), _p(f.get("dbeta"))
+            a.fin_accumulate = int(bool(f.get("accumulate", True)))
     return a
+
+
+# BatchNorm finalize (forward statistics -> scale / shift; backward sums -> dgamma / dbeta / coefficients) as part of the convolution
+# launch that produces the partial sums: TPGSR_BN_FIN_FUSE=1.  OFF by default -- measured slower (C3 6.19 vs 6.08 ms per step,
+# profiles/r04aa_bn_fin_fuse_ab.md): the last workgroup of the whole-CU kernel reduces 393 KB of partial rows alone, through
+# L1-bypassing loads of write-through data, in ~14 us; the separate launch spreads the same reduction over 64 workgroups and costs
+# ~8 us including its launch boundary.  Correct and tested either way (tests/test_bn_fin_fuse_gpu.py).
+BN_FIN_FUSE = os.environ.get("TPGSR_BN_FIN_FUSE", "0") == "1"
+
+
+def bn_fin_fused() -> bool:
+    return bool(BN_FIN_FUSE and CONV_TERMS)
 
 
 # BatchNorm-backward reduction fused into the producing data-gradient convolution (TPGSR_BNB_FUSE=0: its own launch, as before)
