@@ -1,7 +1,8 @@
 #!/bin/bash
 # One gpurun call = tests + bench lines + kernel-trace profile (outputs under gpurun_out/$TAG, merged back by gpurun).
 # usage: tools/gpu_run.sh TAG [what...]   what in: tests tests_all bench_c3 bench_c2 bench_c5 bench_eval bench_opt ab_c3 plan_gaps prof_c3 prof_c2
-#        smoke, t:FILE,FILE,... (pytest on the named test files), or any other (quoted, space-free) word = a shell command.
+#        smoke, t:FILE,FILE,... (pytest on the named test files), x:CMD (a shell command, '+' for spaces: x:python+tools/lab/one_conv.py;
+#        stdin is /dev/null and the limit X_TIMEOUT, default 300 s -- a bare `python` once sat on stdin for the whole 900 s of a call).
 # Environment: PYTEST_ARGS (extra pytest flags), BENCH_ARGS (extra bench.py flags, e.g. "--no-traffic --alt-prec none"),
 #              AB_ENV ("NAME=a NAME=b ...": ab_c3 runs the C3 bench once per setting, interleaved on this one box).
 # This replaces the per-experiment scripts of rounds 2-4 (tools/lab/r0*.sh, no longer tracked): an experiment is one line of these words.
@@ -38,6 +39,7 @@ for w in $WHAT; do
     prof_c2)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_c2 -o c2 -- python $GRAFT_REPO_ROOT/bench.py --config c2 --steps 25 --warmup 5 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/$OUT/prof_c2.log 2>&1); echo "prof_c2 rc=$?" | tee -a $OUT/summary.txt
               DB=$(find $OUT/prof_c2 -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocpd_summary.py $DB $OUT/kernel_stats_c2.md > /dev/null; head -20 $OUT/kernel_stats_c2.md; find $OUT/prof_c2 -name "*.db" -size +30M -delete ;;
     smoke)    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt; tail -2 $OUT/smoke.log ;;
-    *)        timeout 900 bash -c "$w" > $OUT/custom.log 2>&1; echo "custom rc=$?" | tee -a $OUT/summary.txt; tail -30 $OUT/custom.log ;;
+    x:*)      timeout ${X_TIMEOUT:-300} bash -c "$(echo ${w#x:} | tr '+' ' ')" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" | tee -a $OUT/summary.txt; tail -40 $OUT/custom.log ;;
+    *)        echo "unknown word '$w' (a shell command goes in as x:CMD with '+' for spaces: the words of \$@ are split)" | tee -a $OUT/summary.txt ;;
   esac
 done

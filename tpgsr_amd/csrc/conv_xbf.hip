@@ -1058,10 +1058,40 @@ __global__ __launch_bounds__(256) void dy_split_kernel(const float* __restrict__
   }
 }
 
+// Division of a 31-bit numerator by a launch constant as multiply-high + shift (Granlund-Montgomery, round-up form): the halo kernels turn a
+// tile index into (image, row, column) with four to six integer divisions per tile and thread, ~30 VALU instructions each on this ISA --
+// tools/lab/wgh_probe.py: with every load, store and MFMA of the halo weight-gradient kernel switched off, a tile still took 1.65 us.
+struct FastDiv {
+  unsigned mul, sh;
+};
+static FastDiv fastdiv_make(unsigned d) {
+  FastDiv f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.sh = l;
+  f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  return f;
+}
+__device__ __forceinline__ int fastdiv(int n, const FastDiv f) {      // 0 <= n < 2^31
+  const unsigned t = __umulhi((unsigned)n, f.mul);
+  return (int)((t + (unsigned)n) >> f.sh);
+}
+struct HaloDivs {
+  FastDiv ohw, ow, hpwp, wp;
+};
+
+// LAB ONLY (tools/lab/wgh_probe.py): bit 0 = consumers skip their fragment reads + MFMAs, bit 1 = producers issue no global loads after
+// the first tile, bit 2 = producers skip the prologue / split / LDS stores.  Results are garbage with any bit set.
+__device__ int g_wgh_dbg = 0;
+extern "C" int tpgsr_wgh_debug(int bits) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wgh_dbg), &bits, sizeof(bits)) == hipSuccess ? 0 : TPGSR_ERR_LAUNCH;
+}
+
 template <int LD, int T, int NE>
-__global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_args w, int M, int Lcap, int Z) {
+__global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_args w, int M, int Lcap, int Z, HaloDivs dv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];   // [2 buffers][T][Lcap entries][64 B], then [2][64] entry table
   const tpgsr_conv_args& a = w.c;
+  const int dbg = __builtin_amdgcn_readfirstlane(g_wgh_dbg);
   const int PLANE = Lcap * 64, BUF = T * PLANE;
   int* etab = reinterpret_cast<int*>(hsm + 2 * BUF);
   const int tid = threadIdx.x;
@@ -1076,7 +1106,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
   const int Hp = a.OH + a.KH - 1, Wp = a.OW + a.KW - 1, ohw = a.OH * a.OW;
   const int K = taps * a.Cin;
   auto qbase = [&](int m) __attribute__((always_inline)) {
-    const int n = m / ohw, r = m - n * ohw, oh = r / a.OW;
+    const int n = fastdiv(m, dv.ohw), r = m - n * ohw, oh = fastdiv(r, dv.ow);
     return (n * Hp + oh) * Wp + (r - oh * a.OW);
   };
 
@@ -1098,9 +1128,9 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
       q0 = qbase(m0);
       const int L = qbase(min(m0 + 63, M - 1)) - q0 + (a.KH - 1) * Wp + a.KW;
       const int q = q0 + er;
-      int n = q / (Hp * Wp);
+      int n = fastdiv(q, dv.hpwp);
       const int rem = q - n * (Hp * Wp);
-      int r = rem / Wp, sx = rem - r * Wp;
+      int r = fastdiv(rem, dv.wp), sx = rem - r * Wp;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const int ih = r - a.pad_h, iw = sx - a.pad_w;
@@ -1163,8 +1193,8 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
         const bool more = t + 1 < t_end;
         if (!DB) load_item(cur_tag, t);
         if (more) decode_tile(t + 1);
-        if (DB && more) load_item(nxt_tag, t + 1);
-        store_item(cur_tag, j);
+        if (DB && more && !(dbg & 2)) load_item(nxt_tag, t + 1);
+        if (!(dbg & 4)) store_item(cur_tag, j);
         __syncthreads();      // barrier j: tile j is in LDS, and the consumers are done with tile j - 1
         ++j;
         ++t;
@@ -1273,10 +1303,12 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
         }
       }
     };
-    step(I0{}, 0, t * 4 + 0);
-    step(I1{}, 1, t * 4 + 1);
-    step(I0{}, 2, t * 4 + 2);
-    step(I1{}, 3, t * 4 + 3);
+    if (!(dbg & 1)) {
+      step(I0{}, 0, t * 4 + 0);
+      step(I1{}, 1, t * 4 + 1);
+      step(I0{}, 2, t * 4 + 2);
+      step(I1{}, 3, t * 4 + 3);
+    }
   }
 
   // ---- the split's slab: rows k = tap Cin + cc 32 + row, columns n0 + wn 32 + (lane & 31) ----
@@ -1392,7 +1424,9 @@ extern "C" int tpgsr_conv_wgrad_halo_launch(const tpgsr_wgrad_args* w, long long
   dim3 grid((unsigned)((a->Cin >> 5) * cdiv(a->Cout, 64) * Z));
   int Mi = (int)M, Lc = Lcap, Zi = Z;
   tpgsr_wgrad_args args = *w;
-  void* params[] = {&args, &Mi, &Lc, &Zi};
+  const int Hp_ = a->OH + a->KH - 1, Wp_ = a->OW + a->KW - 1;
+  HaloDivs dv = {fastdiv_make((unsigned)(a->OH * a->OW)), fastdiv_make((unsigned)a->OW), fastdiv_make((unsigned)(Hp_ * Wp_)), fastdiv_make((unsigned)Wp_)};
+  void* params[] = {&args, &Mi, &Lc, &Zi, &dv};
   if (hipLaunchKernel(fn, grid, dim3(768), params, lds, st) != hipSuccess) {
     tpgsr_set_error("tpgsr_conv_wgrad(halo): launch failed: %s", hipGetErrorString(hipGetLastError()));
     return TPGSR_ERR_LAUNCH;
