@@ -1127,25 +1127,28 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
       const int m0 = t * 64;
       q0 = qbase(m0);
       const int L = qbase(min(m0 + 63, M - 1)) - q0 + (a.KH - 1) * Wp + a.KW;
-      const int q = q0 + er;
+      // this thread's NE CONSECUTIVE entries er * NE ..: walking the padded index space one entry at a time is one compare per entry and
+      // the pixel index runs along (the stride-32 walk needed four wrap steps and two multiplies per entry: with every load, store and
+      // MFMA of this kernel switched off a tile still took 1.45 us, profiles/r04ae_wgrad_halo_probe.md)
+      const int q = q0 + er * NE;
       int n = fastdiv(q, dv.hpwp);
       const int rem = q - n * (Hp * Wp);
       int r = fastdiv(rem, dv.wp), sx = rem - r * Wp;
+      int rowbase = (n * a.H + r - a.pad_h) * a.W - a.pad_w;      // pixel index of (n, r - pad_h, 0 - pad_w + sx) = rowbase + sx
+      const int img_step = (Hp - a.H) * a.W;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const int ih = r - a.pad_h, iw = sx - a.pad_w;
         const bool in = n < a.N && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        hpix[i] = 32 * i + er < L ? (in ? (n * a.H + ih) * a.W + iw : -1) : -2;
-        sx += 32;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          const bool c1 = sx >= Wp;
-          sx -= c1 ? Wp : 0;
-          r += c1 ? 1 : 0;
-          const bool c2 = r >= Hp;
-          r -= c2 ? Hp : 0;
-          n += c2 ? 1 : 0;
-        }
+        hpix[i] = er * NE + i < L ? (in ? rowbase + sx : -1) : -2;
+        const bool c1 = ++sx >= Wp;
+        sx = c1 ? 0 : sx;
+        r += c1 ? 1 : 0;
+        rowbase += c1 ? a.W : 0;
+        const bool c2 = r >= Hp;
+        r = c2 ? 0 : r;
+        n += c2 ? 1 : 0;
+        rowbase -= c2 ? img_step : 0;
       }
     };
     constexpr bool DB = !(LD & 4);
@@ -1174,7 +1177,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_arg
         const float4 v = finish_a<LD>(a, hr[S][i], qs, qt);
         uint2 h[T];
         split4<T>(v, h);
-        const int e = 32 * i + er;
+        const int e = er * NE + i;
         const int off = e * 64 + (((aq >> 1) ^ ((e >> 2) & 3)) << 4) + (aq & 1) * 8;
         if (part) {
 #pragma unroll
