@@ -152,10 +152,8 @@ int tpgsr_wgrad_splits(int M, int K, int Cout);
 /* 1 + (*zsplits, *dy_bf_bytes) when the geometry (and a->terms > 0) suits the halo weight-gradient kernel, else 0.
  * Only N, H, W, Cin, Cout, KH, KW, pads, OH, OW, terms and the loader-shape fields of `a` are read. */
 int tpgsr_wgrad_halo_plan(const tpgsr_conv_args* a, int* zsplits, long long* dy_bf_bytes);
-/* LAB ONLY (tools/lab/wgh_probe.py): switch parts of the halo weight-gradient kernel off to see where a tile's time goes -- bit 0 the
- * consumers' fragment reads + MFMAs, bit 1 the producers' global loads after the first tile, bit 2 their split + LDS stores.  Results are
- * garbage with any bit set; 0 restores the kernel. */
-int tpgsr_wgh_debug(int bits);
+/* (tpgsr_wgh_debug, the lab switch that turned parts of the halo weight-gradient kernel off, exists only in -DTPGSR_LAB builds of
+ * csrc/conv_xbf.hip: tools/lab/wgh_probe.py) */
 int tpgsr_conv_wgrad(const tpgsr_wgrad_args* a, void* stream);
 /* Several independent weight-gradient GEMMs in ONE launch (the ten of the text-prior generator's two BiLSTM layers, model/crnn/crnn.py:5-26:
  * 25-65 us each alone -- start-up, not work).  items_dev: device-resident table; an item = the arguments of one tpgsr_conv_wgrad call plus
@@ -196,7 +194,6 @@ typedef struct tpgsr_wgrad_reduce_desc {
                              KH*KW*cin_ld) belong to a zero-padded operand and are skipped */
   int reserved;
 } tpgsr_wgrad_reduce_desc;
-int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias);
 /* workgroups ONE descriptor takes: layout-0 weights are reduced in 2-D tiles (all taps of 32 / taps input channels x 32 output
  * channels) and written transposed, so the count depends on the parameter's shape -- a program's blk0 offsets are built from this */
 int tpgsr_wgrad_reduce_blocks2(int K, int Cin, int Cout, int KH, int KW, int layout, int cin_ld, int has_bias);

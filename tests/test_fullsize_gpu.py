@@ -101,6 +101,17 @@ def test_c3_bs48_step0_vs_oracle():
     assert (ts.last_p.cpu().permute(1, 0, 2) - ref["priors"][0]).abs().max() < 1e-5
 
 
+def argmax_mismatches(p, p_ref):
+    """(number of positions whose arg-max class differs, the oracle's top-1 - top-2 probability margin at the worst of them): a
+    mismatch with a margin far above rounding noise is a real disagreement, one at a margin of 1e-7 a tie the oracle itself breaks by
+    rounding -- printed so a failure says which it is"""
+    bad = p.argmax(-1) != p_ref.argmax(-1)
+    if not bool(bad.any()):
+        return 0, 0.0
+    top2 = p_ref.topk(2, -1).values
+    return int(bad.sum()), float((top2[..., 0] - top2[..., 1])[bad].max())
+
+
 def test_c5_shape_stu_iter3_sr_share_bs32_vs_oracle():
     """BASELINE configs[4] per rank: stu_iter 3, sr_share (one SR net, three forwards / backwards per step), three student
     recognisers, bs 32, STN on.  (The 'ASTER prior' of the config text has no reference implementation -- SURVEY 2a -- so
@@ -117,17 +128,21 @@ def test_c5_shape_stu_iter3_sr_share_bs32_vs_oracle():
     ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=3, sr_share=True, tpg_share=False)
     gn = ts.opt.grad_norm(sr).item()
     dpsnr = abs(_psnr(ts.last_sr, hr) - _psnr(ref["sr"], hr))
-    am = ts.last_p.cpu().permute(1, 0, 2).argmax(-1)                 # last stage's prior
-    am_ref = ref["priors"][2].argmax(-1)
-    mism = (am != am_ref).sum().item()
+    mism, margins = [], []
+    for i in range(3):                                               # every stage's prior
+        m_i, worst_i = argmax_mismatches(ts._static["p"][i].cpu().permute(1, 0, 2), ref["priors"][i])
+        mism.append(m_i)
+        margins.append(worst_i)
+    numel = ref["priors"][0].argmax(-1).numel()
     print(f"C5-shape bs32: loss {loss.item():.6f} vs {ref['loss'].item():.6f}; SR grad norm {gn:.4f} vs "
-          f"{float(ref['grad_norms'][0]):.4f}; dPSNR {dpsnr:.2e} dB; last-stage arg-max mismatches {mism} / {am.numel()}")
+          f"{float(ref['grad_norms'][0]):.4f}; dPSNR {dpsnr:.2e} dB; arg-max mismatches per stage {mism} / {numel} "
+          f"(oracle top-2 margin at the mismatches: {margins})")
     assert abs(loss.item() - ref["loss"].item()) < 5e-4 * ref["loss"].item()
     assert abs(gn - float(ref["grad_norms"][0])) < 2e-2 * float(ref["grad_norms"][0])
     assert dpsnr < 1e-3
-    # stage 0 sees the LR image only: its prior must match exactly; later stages read the previous SR image (through the
-    # ill-conditioned TPS resampling), where a near-tie may flip: at most 0.5 % of the positions
-    assert mism <= am.numel() // 200
+    # north_star: IDENTICAL arg-max text priors -- in every stage, also the later ones that read the previous SR image through the
+    # ill-conditioned TPS resampling.  (Rounds 1-4 allowed 0.5 % there; the measured count was always 0.)
+    assert mism == [0, 0, 0], (mism, margins)
     # determinism of the cascade (the bicubic adjoint is a gather): a second replica gives bitwise the same step
     sr2, stus2, teacher2, *_ = _tpgsr(3, seeds=(21, 22, 23))
     ts2 = TPGSRTrainStep([sr2], stus2, teacher2, stu_iter=3, sr_share=True, tpg_share=False)

@@ -524,6 +524,18 @@ def test_tps_and_grid_sample(golden_dir):
     F.grid_sample(ir, gr, align_corners=False).backward(gy)
     assert relerr(from_nhwc(din, N, H, W, C), ir.grad) < 1e-5
     assert relerr(dgrid.cpu().reshape(N, H, W, 2), gr.grad) < 1e-5
+    # the image gradient is a gather in a fixed order since round 5 (it was the library's last float atomicAdd): bitwise repeatable,
+    # also next to a co-running kernel, and it overwrites whatever was in the buffer (no memset, no accumulation)
+    first = din.clone()
+    side = torch.cuda.Stream()
+    junk = torch.randn(1 << 22, device=DEV)
+    for it in range(50):
+        din.fill_(float(it))
+        with torch.cuda.stream(side):
+            junk.mul_(1.0001)
+        k.grid_sample_bwd(xin, grid, gyd, N, H, W, C, H, W, False, din, None)
+        assert torch.equal(din, first), it
+    torch.cuda.synchronize()
     # align_corners=True (the authors' torch 1.2 behaviour) against ATen
     ref = F.grid_sample(img, grid.cpu().reshape(N, H, W, 2), align_corners=True)
     k.grid_sample_fwd(xin, grid, N, H, W, C, H, W, True, out)

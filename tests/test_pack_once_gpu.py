@@ -85,3 +85,42 @@ def test_train_then_eval_sees_the_updated_parameters():
         e2 = fresh(lr).clone()
     assert not torch.equal(e0, e1)
     assert torch.equal(e1, e2)
+
+
+def test_graph_replay_then_eval_sees_the_updated_parameters():
+    """a hipGraph replay runs the captured Adam and bumps no counter by itself -- capture, eval (packs, stores the key),
+    replay x N, eval again must see the parameters the LAST replay left, not the operands packed one optimiser step earlier"""
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    from tpgsr_amd.model import tsrn
+    sd = O.recipe_state_dict(O.tsrn_spec(STN=False, mask=True, srb_nums=2), 78)
+    net = tsrn.TSRN(STN=False, mask=True, srb_nums=2)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    lr, hr = O.synthetic_batch(4, 9)
+    lr, hr = lr.to(DEV), hr.to(DEV)
+    ts = TSRNTrainStep(net)
+    ts.capture(lr, hr, warmup=1)
+    net.eval()
+    with torch.no_grad():
+        e0 = net(lr).clone()                  # packs the operands of the post-warm-up parameters
+    net.train()
+    for _ in range(3):
+        ts.replay()
+    net.eval()
+    with torch.no_grad():
+        e1 = net(lr).clone()
+    # a fresh network holding the same state (packs from scratch) is the truth
+    fresh = tsrn.TSRN(STN=False, mask=True, srb_nums=2)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        e2 = fresh(lr).clone()
+    assert not torch.equal(e0, e1)
+    assert torch.equal(e1, e2)
+    # invalidate_packed(): a write through `p.data` bumps no version counter -- the documented call makes the next forward re-pack
+    with torch.no_grad():
+        next(net.parameters()).data.mul_(1.5)
+        stale = net(lr).clone()
+        net._engine().invalidate_packed()
+        fresh_out = net(lr).clone()
+    assert torch.equal(stale, e1) and not torch.equal(fresh_out, e1)

@@ -27,7 +27,7 @@ def x2():
 
 def test_c5_shape_cascade_under_x2_holds_the_gates(x2):
     """stu_iter 3, sr_share, three students, bs 32: later-stage students read an SR image the two-term SR network produced.
-    |dPSNR| < 1e-3 dB on the last SR image, stage-0 arg-max priors identical, later stages within the 0.5 % the x3 test allows."""
+    Against the ORACLE: |dPSNR| < 1e-3 dB on the last SR image, arg-max priors identical in all three stages."""
     import test_fullsize_gpu as T
     from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
     T._threads()
@@ -40,16 +40,17 @@ def test_c5_shape_cascade_under_x2_holds_the_gates(x2):
     opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
     ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=3, sr_share=True, tpg_share=False)
     dpsnr = abs(T._psnr(ts.last_sr, hr) - T._psnr(ref["sr"], hr))
-    mism = []
+    mism, margins = [], []
     for i in range(3):
         am = ts._static["p"][i].cpu().permute(1, 0, 2).argmax(-1)
-        mism.append(int((am != ref["priors"][i].argmax(-1)).sum()))
+        m_i, worst_i = T.argmax_mismatches(ts._static["p"][i].cpu().permute(1, 0, 2), ref["priors"][i])
+        mism.append(m_i)
+        margins.append(worst_i)
     gn, gn_ref = ts.opt.grad_norm(sr).item(), float(ref["grad_norms"][0])
     print(f"C5-shape bs32 x2: loss {loss.item():.6f} vs {ref['loss'].item():.6f}; |dPSNR| {dpsnr:.3e} dB; arg-max mismatches per stage "
           f"{mism} / {am.numel()}; SR grad norm {gn:.4f} vs {gn_ref:.4f}")
     assert dpsnr < 1e-3
-    assert mism[0] == 0
-    assert max(mism[1:]) <= am.numel() // 200
+    assert mism == [0, 0, 0], (mism, margins)       # north_star: identical arg-max priors, in every stage of the cascade
     assert abs(loss.item() - ref["loss"].item()) < 5e-4 * ref["loss"].item()
     assert abs(gn - gn_ref) < 2e-2 * gn_ref
 
@@ -108,7 +109,7 @@ def test_trajectory_nostn_under_x2_vs_reference_losses(x2, golden_dir):
     assert abs(psnr - float(t["psnr_final"])) < 1e-2
 
 
-def test_sr_gradients_elementwise_under_x2():
+def test_sr_gradients_elementwise_under_x2(x2):
     """TSRN_TL without STN, every parameter gradient and the text-prior gradient against oracle autograd under x2.  Bound: 4e-3
     relative L2 per tensor (fp32-equivalent path: 2e-3, tests/test_tsrn_gpu.py) -- the two-term split drops <= 3 * 2^-18 of a product,
     which lands below the accumulation-order noise of an fp32 GEMM for these reductions (tests/test_policy_x2_gpu.py)."""

@@ -202,6 +202,74 @@ def test_stn_stage_by_stage_vs_oracle():
     assert e_src < 5e-5 and e_xr2 < 2e-3
 
 
+def test_tsrn_same_grid_elementwise_vs_oracle():
+    """With the STN ON, element-wise -- the check the conditioning of the TPS system otherwise forbids (source
+    coordinates that differ by 1e-5 move SR pixels by 2e-3).  The oracle is fed the BUILD'S OWN sampling grid as a leaf:
+      stage B (everything downstream of the grid): rectified image, SR image, loss, every non-STN parameter gradient and the
+              gradient with respect to the grid -- element-wise, at the no-STN tolerances;
+      stage A (the STN head): the oracle's head + TPS back-propagate the grid gradient of stage B; control-point gradient
+              element-wise, the head's parameter gradients per tensor (five max-pools: NOISE applies)."""
+    import torch.nn.functional as F
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    net, sd = _build(stn=True, seed=303)
+    lr, hr = O.synthetic_batch(3, 17)
+    net.train()
+    sr = net(lr.to(DEV))
+    loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.to(DEV)).mean() * 100
+    loss.backward()
+    torch.cuda.synchronize()
+    eng = net._engine()
+    ws = next(pl["ws"].t for key, pl in eng._plans.items() if key[3] and "stn_dgrid" in pl["ws"].t)
+    N, H, W = 3, 16, 64
+    grid_b = ws["stn_grid"].cpu().reshape(N, H, W, 2).clone()
+    # ---- stage B: the oracle downstream of OUR grid
+    p = O.as_params(sd)
+    gl = grid_b.clone().requires_grad_(True)
+    xr = F.grid_sample(lr, gl, mode="bilinear", padding_mode="zeros", align_corners=False)
+    y = O.tsrn_forward(p, xr, training=True, stn=False)
+    loss_ref = O.image_loss(y, hr).mean() * 100
+    loss_ref.backward()
+    e_xr = (ws["xr"].cpu().reshape(N, H, W, 4).permute(0, 3, 1, 2) - xr.detach()).abs().max().item()
+    e_sr = (sr.detach().cpu() - y.detach()).abs().max().item()
+    gmax = max(v.grad.norm().item() for v in p.values() if v.grad is not None)
+    worst, bad = 0.0, []
+    for n, q in net.named_parameters():
+        if n.startswith("stn_head"):
+            continue
+        ref = p[n].grad
+        rel = (q.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-3 * gmax)
+        worst = max(worst, rel)
+        if rel > 2e-3:
+            bad.append((n, rel))
+    dgrid = ws["stn_dgrid"].cpu().reshape(N, H, W, 2)
+    e_dgrid = (dgrid - gl.grad).norm().item() / gl.grad.norm().item()
+    print(f"same grid: rectified err {e_xr:.2e}, SR err {e_sr:.2e}, loss {loss.item():.6f} vs {loss_ref.item():.6f}, worst non-STN "
+          f"parameter-gradient rel err {worst:.2e}, grid-gradient rel err {e_dgrid:.2e}")
+    assert e_xr < 2e-6 and e_sr < 5e-5
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+    assert not bad, bad[:10]
+    assert e_dgrid < 2e-3
+    # ---- stage A: the oracle's STN head + TPS map, driven by stage B's grid gradient
+    pa = O.as_params(sd)
+    _, ctrl = O.stn_head(pa, "stn_head", lr, True)
+    ctrl.retain_grad()
+    _, src = O.tps_transform(pa, "tps", lr, ctrl, (H, W))
+    grid_o = src.reshape(N, H, W, 2).clamp(0, 1) * 2.0 - 1.0
+    assert (grid_o.detach() - grid_b).abs().max() < 2e-4          # (the two grids agree to the conditioning of the TPS system)
+    grid_o.backward(gl.grad)
+    e_dctrl = (ws["stn_dctrl"].cpu().reshape(N, 20, 2) - ctrl.grad).norm().item() / ctrl.grad.norm().item()
+    gmax_a = max(v.grad.norm().item() for k, v in pa.items() if k.startswith("stn_head") and v.grad is not None)
+    worst_a = 0.0
+    for n, q in net.named_parameters():
+        if n.startswith("stn_head"):
+            ref = pa[n].grad
+            rel = (q.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-3 * gmax_a)
+            worst_a = max(worst_a, rel)
+            assert rel < 2e-2 * NOISE, (n, rel)
+    print(f"same grid, STN head: control-point gradient rel err {e_dctrl:.2e}, worst head parameter-gradient rel err {worst_a:.2e}")
+    assert e_dctrl < 5e-3
+
+
 def _build_tl(stn=True, seed=102):
     from tpgsr_amd.model import tsrn
     sd = O.recipe_state_dict(O.tsrn_spec(STN=stn, mask=True, text_prior=True), seed, tps_hw=(16, 64))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where does the halo weight-gradient kernel's time go?  The recogniser's conv5 (N48 4x26 512->512 3x3) and the up-sampling convolution
-(N48 16x64 64->256 3x3) timed with parts of the kernel switched off (tpgsr_wgh_debug: LAB ONLY, results are garbage with a bit set)."""
+(N48 16x64 64->256 3x3) timed with parts of the kernel switched off (tpgsr_wgh_debug: exists in TPGSR_LAB=1 builds only, results are garbage with a bit set)."""
 import math
 import os
 import sys
@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from tpgsr_amd import _lib, kernels as K  # noqa: E402
 
 lib = _lib.load()
+if not hasattr(lib, "tpgsr_wgh_debug"):
+    sys.exit("the debug switch of the halo weight-gradient kernel exists only in a lab build: TPGSR_LAB=1 python -m tpgsr_amd.build --force")
+lib.tpgsr_wgh_debug.argtypes, lib.tpgsr_wgh_debug.restype = [__import__("ctypes").c_int], __import__("ctypes").c_int
 DEV = "cuda"
 g = torch.Generator().manual_seed(0)
 for (N, H, W, Ci, Co) in ((48, 4, 26, 512, 512), (48, 16, 64, 64, 256), (48, 8, 25, 256, 256)):

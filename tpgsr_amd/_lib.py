@@ -112,9 +112,7 @@ _SIGS = {
     "tpgsr_conv_wgrad": (ci, [C.POINTER(WgradArgs), vp]),
     "tpgsr_wgrad_halo_plan": (ci, [C.POINTER(ConvArgs), C.POINTER(ci), C.POINTER(C.c_longlong)]),
     "tpgsr_wgrad_reduce": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, cf, vp]),
-    "tpgsr_wgrad_reduce_blocks": (ci, [ci, ci, ci]),
     "tpgsr_pack_blocks": (ci, [ci, ci, ci, ci, ci, ll]),
-    "tpgsr_wgh_debug": (ci, [ci]),
     "tpgsr_conv_wgrad_batch_prepare": (ci, [C.POINTER(WgradArgs), C.POINTER(WgradBatchItem)]),
     "tpgsr_conv_wgrad_batch": (ci, [vp, ci, ci, ci, ci, vp]),
     "tpgsr_wgrad_reduce_blocks2": (ci, [ci, ci, ci, ci, ci, ci, ci, ci]),

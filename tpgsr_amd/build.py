@@ -11,7 +11,8 @@ SOURCES = ["conv_mfma.hip", "conv_xbf.hip", "conv_panel.hip", "conv_halo3.hip", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("TPGSR_FAST_MATH"):   # A/B switch only: v_exp_f32 / v_rcp_f32 activations (costs gradient parity, see common.h)
     FLAGS.append("-DTPGSR_FAST_MATH")
-
+if os.environ.get("TPGSR_LAB"):         # lab build: compiles the kernels' debug switches in (tpgsr_wgh_debug, tools/lab/wgh_probe.py)
+    FLAGS.append("-DTPGSR_LAB")
 
 if os.environ.get("TPGSR_FRAG_PRELOAD") is not None:   # A/B switch: conv fragment preload (conv_mfma.hip)
     FLAGS.append("-DTPGSR_FRAG_PRELOAD=" + os.environ["TPGSR_FRAG_PRELOAD"])

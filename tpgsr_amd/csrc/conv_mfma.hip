@@ -903,11 +903,6 @@ extern "C" int tpgsr_wgrad_reduce_blocks2(int K, int Cin, int Cout, int KH, int 
   (void)cin_ld;
   return wr_weight_blocks(K, Cin, Cout, KH, KW, layout) + (has_bias ? cdiv(Cout, WR_BLK) : 0);
 }
-/* (legacy form: the workgroup count of a layer of which only K and Cout are known is no longer defined; kept for old callers of the
- * single-launch tpgsr_wgrad_reduce, which sizes its own grid) */
-extern "C" int tpgsr_wgrad_reduce_blocks(int K, int Cout, int has_bias) {
-  return cdiv((size_t)K * Cout, WR_BLK) + (has_bias ? cdiv(Cout, WR_BLK) : 0);
-}
 
 extern "C" int tpgsr_wgrad_reduce_program(const tpgsr_wgrad_reduce_desc* descs_dev, int ndesc, int total_blocks, void* stream) {
   TPGSR_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0, "tpgsr_wgrad_reduce_program: bad arguments");

@@ -1080,18 +1080,24 @@ struct HaloDivs {
   FastDiv ohw, ow, hpwp, wp;
 };
 
-// LAB ONLY (tools/lab/wgh_probe.py): bit 0 = consumers skip their fragment reads + MFMAs, bit 1 = producers issue no global loads after
-// the first tile, bit 2 = producers skip the prologue / split / LDS stores.  Results are garbage with any bit set.
+// LAB BUILDS ONLY (-DTPGSR_LAB, tools/lab/wgh_probe.py): bit 0 = consumers skip their fragment reads + MFMAs, bit 1 = producers issue no
+// global loads after the first tile, bit 2 = producers skip the prologue / split / LDS stores.  Results are garbage with any bit set, so
+// the switch, its export and its run-time branches do not exist in a release build.
+#ifdef TPGSR_LAB
 __device__ int g_wgh_dbg = 0;
 extern "C" int tpgsr_wgh_debug(int bits) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_wgh_dbg), &bits, sizeof(bits)) == hipSuccess ? 0 : TPGSR_ERR_LAUNCH;
 }
+#define WGH_DBG() __builtin_amdgcn_readfirstlane(g_wgh_dbg)
+#else
+#define WGH_DBG() 0
+#endif
 
 template <int LD, int T, int NE>
 __global__ __launch_bounds__(768, 3) void conv_wgrad_halo_kernel(tpgsr_wgrad_args w, int M, int Lcap, int Z, HaloDivs dv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];   // [2 buffers][T][Lcap entries][64 B], then [2][64] entry table
   const tpgsr_conv_args& a = w.c;
-  const int dbg = __builtin_amdgcn_readfirstlane(g_wgh_dbg);
+  const int dbg = WGH_DBG();
   const int PLANE = Lcap * 64, BUF = T * PLANE;
   int* etab = reinterpret_cast<int*>(hsm + 2 * BUF);
   const int tid = threadIdx.x;

@@ -156,7 +156,7 @@ extern "C" int tpgsr_grid_sample_fwd(const float* in, const float* grid, int N, 
 template <int C>
 __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __restrict__ in, const float* __restrict__ grid,
                                                               const float* __restrict__ dout, int N, int H, int W, int OHW,
-                                                              int align, float* din, float* __restrict__ dgrid) {
+                                                              int align, float* __restrict__ dgrid) {
   long long total = (long long)N * OHW;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -175,10 +175,8 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __res
       size_t o = ((size_t)(n * H + y) * W + x) * C;
       float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        dot = fmaf(in[o + c], g[c], dot);
-        if (din) atomicAdd(din + o + c, w * g[c]);
-      }
+      for (int c = 0; c < C; ++c) dot = fmaf(in[o + c], g[c], dot);
+      (void)w;
       gix = fmaf(dwx, dot, gix);
       giy = fmaf(dwy, dot, giy);
     }
@@ -195,22 +193,72 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __res
   }
 }
 
+// gradient with respect to the sampled IMAGE in GATHER form (round 5; it was the library's last floating-point atomicAdd): a thread
+// owns one input pixel and walks ALL output positions of its image in index order (staged through LDS in chunks: every lane of a wave
+// reads the same entry, a broadcast), adding weight * dout for those whose bilinear footprint {x0, x0+1} x {y0, y0+1} contains the
+// pixel -- the same weights the forward pass used, summed in a fixed order: deterministic, no memset.  O(HW * OHW) compares per image
+// (1 M for the 16 x 64 STN input: microseconds); no recorded train step asks for this gradient (the image is data), the functional
+// operator layer does.
+#define GS_CHUNK 512
+template <int C>
+__global__ __launch_bounds__(256) void grid_sample_bwd_din_kernel(const float* __restrict__ grid, const float* __restrict__ dout,
+                                                                  int H, int W, int OHW, int align, float* __restrict__ din) {
+  __shared__ int sx0[GS_CHUNK], sy0[GS_CHUNK];
+  __shared__ float swx[GS_CHUNK], swy[GS_CHUNK], sg[GS_CHUNK][C];
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int y = p / W, x = p - y * W;
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  for (int base = 0; base < OHW; base += GS_CHUNK) {
+    const int cnt = min(GS_CHUNK, OHW - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      const size_t i = (size_t)n * OHW + base + j;
+      const float ix = unnorm(grid[i * 2], W, align), iy = unnorm(grid[i * 2 + 1], H, align);
+      const float fx = floorf(ix), fy = floorf(iy);
+      sx0[j] = (int)fx;
+      sy0[j] = (int)fy;
+      swx[j] = ix - fx;
+      swy[j] = iy - fy;
+#pragma unroll
+      for (int c = 0; c < C; ++c) sg[j][c] = dout[i * C + c];
+    }
+    __syncthreads();
+    for (int j = 0; j < cnt; ++j) {
+      const unsigned dx = (unsigned)(x - sx0[j]), dy = (unsigned)(y - sy0[j]);
+      if (dx < 2u && dy < 2u) {
+        const float wx1 = swx[j], wy1 = swy[j];
+        const float w = (dy ? wy1 : 1.f - wy1) * (dx ? wx1 : 1.f - wx1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, sg[j][c], acc[c]);
+      }
+    }
+  }
+  if (p < H * W) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) din[((size_t)n * H * W + p) * C + c] = acc[c];
+  }
+}
+
 extern "C" int tpgsr_grid_sample_bwd(const float* in, const float* grid, const float* dout, int N, int H, int W, int C, int OH,
                                      int OW, int align_corners, float* din, float* dgrid, void* stream) {
   TPGSR_CHECK_ARG(in && grid && dout && (din || dgrid), "tpgsr_grid_sample_bwd: null pointer");
   TPGSR_CHECK_ARG(C == 3 || C == 4 || C == 1, "tpgsr_grid_sample_bwd: C must be 1, 3 or 4 (got %d)", C);
   hipStream_t s = (hipStream_t)stream;
   if (din) {
-    hipError_t e = hipMemsetAsync(din, 0, (size_t)N * H * W * C * sizeof(float), s);
-    if (e != hipSuccess) {
-      tpgsr_set_error("tpgsr_grid_sample_bwd: memset failed: %s", hipGetErrorString(e));
-      return TPGSR_ERR_LAUNCH;
-    }
+    dim3 gd(cdiv((long long)H * W, 256), N), bd(256);
+    if (C == 4) hipLaunchKernelGGL(grid_sample_bwd_din_kernel<4>, gd, bd, 0, s, grid, dout, H, W, OH * OW, align_corners, din);
+    else if (C == 3) hipLaunchKernelGGL(grid_sample_bwd_din_kernel<3>, gd, bd, 0, s, grid, dout, H, W, OH * OW, align_corners, din);
+    else hipLaunchKernelGGL(grid_sample_bwd_din_kernel<1>, gd, bd, 0, s, grid, dout, H, W, OH * OW, align_corners, din);
   }
-  long long total = (long long)N * OH * OW;
-  dim3 g(cdiv(total, 256)), b(256);
-  if (C == 4) hipLaunchKernelGGL(grid_sample_bwd_kernel<4>, g, b, 0, s, in, grid, dout, N, H, W, OH * OW, align_corners, din, dgrid);
-  else if (C == 3) hipLaunchKernelGGL(grid_sample_bwd_kernel<3>, g, b, 0, s, in, grid, dout, N, H, W, OH * OW, align_corners, din, dgrid);
-  else hipLaunchKernelGGL(grid_sample_bwd_kernel<1>, g, b, 0, s, in, grid, dout, N, H, W, OH * OW, align_corners, din, dgrid);
+  if (dgrid) {
+    long long total = (long long)N * OH * OW;
+    dim3 g(cdiv(total, 256)), b(256);
+    if (C == 4) hipLaunchKernelGGL(grid_sample_bwd_kernel<4>, g, b, 0, s, in, grid, dout, N, H, W, OH * OW, align_corners, dgrid);
+    else if (C == 3) hipLaunchKernelGGL(grid_sample_bwd_kernel<3>, g, b, 0, s, in, grid, dout, N, H, W, OH * OW, align_corners, dgrid);
+    else hipLaunchKernelGGL(grid_sample_bwd_kernel<1>, g, b, 0, s, in, grid, dout, N, H, W, OH * OW, align_corners, dgrid);
+  }
   TPGSR_LAUNCH_CHECK("tpgsr_grid_sample_bwd");
 }

@@ -628,7 +628,8 @@ class _EngineBase:
     # writes the arena through raw pointers or through the flat buffer (FusedAdam, a flat broadcast) bumps `_kernel_writes`.
     def _param_key(self):
         # (the parameters are `.data` views of the arena: each carries its OWN version counter, the arena's does not see their writes)
-        return (sum(p._version for p in self.P.values()), self._kernel_writes, self.arena.flat.data_ptr())
+        # (+ whether the bf16 twins exist: an engine bound under "f32" grows them when a split-operand policy records its first plan)
+        return (sum(p._version for p in self.P.values()), self._kernel_writes, self.arena.flat.data_ptr(), bool(getattr(self, "_split_tabs", None)))
 
     def pack_if_stale(self, pack_plan):
         capturing = (not K.DRYRUN) and torch.cuda.is_current_stream_capturing()   # a captured graph must contain its own pack
@@ -636,6 +637,15 @@ class _EngineBase:
         if capturing or key != self._packed_key or os.environ.get("TPGSR_PACK_ALWAYS") == "1":
             pack_plan.run()
             self._packed_key = None if capturing else key
+
+    def invalidate_packed(self):
+        """The parameters changed in a way no version counter sees -- a write through `p.data` (`p.data.copy_/mul_/clamp_`: EMA, weight
+        clipping), through a raw pointer or a flat view of the arena, a hipGraph replay containing the optimiser: the next eval-mode
+        forward re-packs its operands.  FusedAdam, the flat broadcasts and the train steps' `replay()` call this themselves
+        (`load_state_dict` / `p.copy_` bump torch's version counters, which the key sums); code that writes parameters behind torch's back must too (`module._engine().invalidate_packed()`).
+        TPGSR_PACK_ALWAYS=1 re-packs on every forward (debugging aid)."""
+        self._kernel_writes += 1
+        self._packed_key = None
 
     def note_packed(self):
         """a training-mode forward has just packed the current parameters"""
@@ -677,6 +687,8 @@ class _EngineBase:
     def _two_pass(self, key, record):
         """pass 1 sizes the stream-ordered scratch buffers, pass 2 records against their final addresses"""
         if key not in self._plans:
+            if K.POLICY != "f32" and self._operands and not self._split_tabs:
+                self._finish_split_table()      # bound under "f32" (no bf16 twins), now recording a split-operand policy
             ws = _Ws(self.device)
             record(ws, False)
             self._plans[key] = record(ws, True)
@@ -760,7 +772,7 @@ class TSRNEngine(_EngineBase):
         defer_join: the backward plan does NOT end by joining the weight-gradient stream -- the caller orders its stream after the
         side stream before anything reads the parameter gradients (TPGSRTrainStep at world size 1: the student's backward pass
         starts while this network's weight gradients are still running; ONE join before the optimiser)"""
-        return self._two_pass((N, H, W, bool(training), slot, bool(defer_join)),
+        return self._two_pass((N, H, W, bool(training), slot, bool(defer_join), K.POLICY),
                               lambda ws, final: self._record(N, H, W, training, ws, final, bool(defer_join)))
 
     def _record(self, N, H, W, training, ws, final, defer_join=False):

@@ -253,7 +253,7 @@ class CRNNEngine(_EngineBase):
         return dims
 
     def plans(self, N, training, slot=0):
-        return self._two_pass((N, bool(training), slot, getattr(self, "role", "tpg")), lambda ws, final: self._record(N, training, ws, final))
+        return self._two_pass((N, bool(training), slot, getattr(self, "role", "tpg"), K.POLICY), lambda ws, final: self._record(N, training, ws, final))
 
     def _record(self, N, training, ws, final):
         fwd, bwd, bwd_b, dgp, pack = Plan("crnn_fwd"), Plan("crnn_bwd"), Plan("crnn_bwd_b"), Plan("crnn_dgray"), Plan("crnn_pack")

@@ -44,6 +44,10 @@ class FunctionalEngine:
         self._pending_batches = 0
         self._kernel_writes = 0      # bumped by FusedAdam / broadcasts (engine protocol); every plan here re-packs its weights per replay
 
+    def invalidate_packed(self):
+        """engine protocol (engine._EngineBase.invalidate_packed): every plan here re-packs its weights per replay, so only the counter moves"""
+        self._kernel_writes += 1
+
     def bind(self, device):
         rebuilt = self.arena.ensure(device)
         if rebuilt or self.device != device:

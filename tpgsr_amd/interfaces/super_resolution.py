@@ -21,18 +21,29 @@ _NBLK = 128
 def _warn_hw_queues(collective: bool):
     """The step's three streams plus RCCL's are more than the four hardware queues HIP multiplexes streams onto by default: two of them
     share a queue and an event wait of one blocks the other (+0.9 ms per C3 step measured).  The variable is read
-    when the HIP runtime initialises, so a library cannot set it any more -- it can only say so."""
-    if collective and not K.DRYRUN and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+    when the HIP runtime initialises: `import tpgsr_amd` sets it to 8 unless the caller chose a value (tpgsr_amd/__init__.py), which
+    takes effect when the package is imported before the process's first HIP call; otherwise the step can only say so."""
+    from .. import HW_QUEUES_LATE
+    try:
+        nq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    except ValueError:          # an unparsable value is as good as unset: this is an advisory warning, never a start-up error
+        nq = 4
+    if HW_QUEUES_LATE:
+        nq = 4
+    if collective and not K.DRYRUN and nq < 8:
         import warnings
         warnings.warn("tpgsr_amd: a gradient exchange is on but GPU_MAX_HW_QUEUES is %s (< 8): the train step's streams and RCCL's will "
                       "share hardware queues (~0.9 ms per step on MI355X).  Export GPU_MAX_HW_QUEUES=8 before the process starts "
-                      "(INTEGRATION.md section 4)." % os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)"), RuntimeWarning, stacklevel=3)
+                      "(INTEGRATION.md section 4)." % ("unset when HIP initialised (default 4)" if HW_QUEUES_LATE else os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)")),
+                      RuntimeWarning, stacklevel=3)
 
 
 class TSRNTrainStep:
     def __init__(self, model, gradient=True, loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25,
-                 process_group=None, world_size: int = 1, force_collectives: bool = False):
+                 process_group=None, world_size: int = 1, force_collectives: bool = False, precision: Optional[str] = None):
         self.model = model
+        # arithmetic policy of the step's GEMMs (kernels.py): `precision`, else an explicit TPGSR_CONV_PREC / set_conv_prec, else "x2"
+        self.precision = K.train_step_policy(precision)
         self.collective = world_size > 1 or bool(force_collectives)   # force: drive RCCL at world size 1 too (tests)
         _warn_hw_queues(self.collective)
         self.gradient, self.w0, self.w1 = bool(gradient), float(loss_weight[0]), float(loss_weight[1])
@@ -91,10 +102,11 @@ class TSRNTrainStep:
         """Returns the (device) loss scalar = ImageLoss(sr, hr).mean() * 100 of this step (this rank's shard)."""
         if not self.model.training:
             raise RuntimeError("TSRNTrainStep.step needs model.train()")
-        self.pool.bind(lr_img.device)
-        loss = self._phase_a(lr_img, hr_img)
-        self._exchange()
-        self._phase_b()
+        with K.policy(self.precision):
+            self.pool.bind(lr_img.device)
+            loss = self._phase_a(lr_img, hr_img)
+            self._exchange()
+            self._phase_b()
         return loss
 
     def broadcast_parameters(self, src: int = 0):
@@ -119,7 +131,7 @@ class TSRNTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        with torch.cuda.graph(ga), K.policy(self.precision):
             self._graph_loss = self._phase_a(self._lr, self._hr)
             if self.world == 1:
                 self._phase_b()
@@ -141,6 +153,8 @@ class TSRNTrainStep:
         if self._graph_b is not None:
             self._exchange()
             self._graph_b.replay()
+        # the captured Adam rewrote the arena behind every version counter: an eval-mode forward after this must re-pack
+        self.model._engine().invalidate_packed()
         return self._graph_loss
 
 
@@ -180,7 +194,10 @@ class TPGSRTrainStep:
 
     def __init__(self, sr_models, students, teacher, stu_iter=1, sr_share=True, tpg_share=False, gradient=True,
                  loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1,
-                 force_collectives=False):
+                 force_collectives=False, precision: Optional[str] = None):
+        # arithmetic policy of the step's GEMMs (kernels.py): `precision`, else an explicit TPGSR_CONV_PREC / set_conv_prec, else "x2" --
+        # the benchmarked policy, gated at full size against the oracle on both north_star gates (tests/test_policy_x2*_gpu.py)
+        self.precision = K.train_step_policy(precision)
         self.collective = world_size > 1 or bool(force_collectives)   # force: drive RCCL at world size 1 too (tests)
         _warn_hw_queues(self.collective)
         self.sr = list(sr_models) if isinstance(sr_models, (list, tuple)) else [sr_models]
@@ -425,11 +442,12 @@ class TPGSRTrainStep:
         for m in self.sr + self.stu:
             if not m.training:
                 raise RuntimeError("TPGSRTrainStep.step needs the SR nets and students in train() mode")
-        self.pool.bind(lr_img.device)
-        self.teacher._engine().bind(lr_img.device)
-        loss = self._phase_a(lr_img, hr_img)
-        self._exchange()
-        self._phase_b()
+        with K.policy(self.precision):
+            self.pool.bind(lr_img.device)
+            self.teacher._engine().bind(lr_img.device)
+            loss = self._phase_a(lr_img, hr_img)
+            self._exchange()
+            self._phase_b()
         self._mark("optimiser")
         return loss
 
@@ -445,7 +463,7 @@ class TPGSRTrainStep:
         ga = torch.cuda.CUDAGraph()
         self._overlap_exchange = False       # the all-reduce stays between the two graphs ...
         try:
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga), K.policy(self.precision):
                 self._graph_loss = self._phase_a(self._lr, self._hr)
                 if self.world == 1:
                     self._phase_b()
@@ -468,6 +486,9 @@ class TPGSRTrainStep:
         if self._graph_b is not None:
             self._exchange()
             self._graph_b.replay()
+        # the captured Adam rewrote the pooled arena behind every version counter: eval-mode forwards after this must re-pack
+        for m in self.pool.modules:
+            m._engine().invalidate_packed()
         return self._graph_loss
 
 

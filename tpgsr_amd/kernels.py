@@ -49,10 +49,49 @@ CONV_TERMS = _TERMS[POLICY]
 # dies with the operand (a registry keyed by address would hand a stale twin to the next tensor allocated there)
 
 
+# Who chose the policy.  The fused TRAIN STEPS (interfaces.super_resolution.TSRNTrainStep / TPGSRTrainStep) default to "x2" -- the policy
+# that is benchmarked and gated at full size against the oracle on both north_star gates (|dPSNR| < 1e-3 dB, identical arg-max priors:
+# tests/test_policy_x2_gpu.py, test_policy_x2_gates_gpu.py) -- unless somebody chose one: the TPGSR_CONV_PREC variable, set_conv_prec(), or
+# the step's own `precision=` argument.  Everything else (module forwards, the functional layer, the evaluators) records "x3" by default.
+_POLICY_EXPLICIT = "TPGSR_CONV_PREC" in os.environ
+TRAIN_STEP_DEFAULT = "x2"
+
+
 def set_conv_prec(name: str):
-    """'f32' | 'x3' | 'x3b2' | 'x2' | 'bf16' for plans recorded from now on (engines bound earlier keep their recorded plans)"""
-    global CONV_TERMS, POLICY
-    POLICY, CONV_TERMS = name, _TERMS[name]
+    """'f32' | 'x3' | 'x3b2' | 'x2' | 'bf16' for plans recorded from now on (plans are cached per policy)"""
+    global CONV_TERMS, POLICY, _POLICY_EXPLICIT
+    if name not in _TERMS:
+        raise ValueError(f"set_conv_prec({name!r}): expected one of {sorted(_TERMS)}")
+    POLICY, CONV_TERMS, _POLICY_EXPLICIT = name, _TERMS[name], True
+
+
+def train_step_policy(precision=None) -> str:
+    """the arithmetic policy a fused train step records under: its `precision=` argument, else whatever was chosen explicitly
+    (TPGSR_CONV_PREC / set_conv_prec), else TRAIN_STEP_DEFAULT"""
+    if precision is not None:
+        if precision not in _TERMS:
+            raise ValueError(f"precision={precision!r}: expected one of {sorted(_TERMS)}")
+        return precision
+    return POLICY if _POLICY_EXPLICIT else TRAIN_STEP_DEFAULT
+
+
+class policy:
+    """``with policy(name):`` -- plans recorded / launches stamped inside run under `name`; restores the previous policy on exit and
+    does not count as an explicit choice"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global CONV_TERMS, POLICY
+        self.prev = (POLICY, CONV_TERMS)
+        POLICY, CONV_TERMS = self.name, _TERMS[self.name]
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_TERMS, POLICY
+        POLICY, CONV_TERMS = self.prev
+        return False
 
 
 def terms_for(net_kind: str, phase: str) -> int:
