@@ -21,21 +21,17 @@ _NBLK = 128
 def _warn_hw_queues(collective: bool):
     """The step's three streams plus RCCL's are more than the four hardware queues HIP multiplexes streams onto by default: two of them
     share a queue and an event wait of one blocks the other (+0.9 ms per C3 step measured).  The variable is read
-    when the HIP runtime initialises: `import tpgsr_amd` sets it to 8 unless the caller chose a value (tpgsr_amd/__init__.py), which
-    takes effect when the package is imported before the process's first HIP call; otherwise the step can only say so."""
-    from .. import HW_QUEUES_LATE
+    before the process creates its streams: `import tpgsr_amd` sets it to 8 unless the caller chose a value (tpgsr_amd/__init__.py;
+    measured effective even after torch.cuda.init(), profiles/r05a_hw_queues_probe.md).  A caller's own smaller value is warned about."""
     try:
         nq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
     except ValueError:          # an unparsable value is as good as unset: this is an advisory warning, never a start-up error
-        nq = 4
-    if HW_QUEUES_LATE:
         nq = 4
     if collective and not K.DRYRUN and nq < 8:
         import warnings
         warnings.warn("tpgsr_amd: a gradient exchange is on but GPU_MAX_HW_QUEUES is %s (< 8): the train step's streams and RCCL's will "
                       "share hardware queues (~0.9 ms per step on MI355X).  Export GPU_MAX_HW_QUEUES=8 before the process starts "
-                      "(INTEGRATION.md section 4)." % ("unset when HIP initialised (default 4)" if HW_QUEUES_LATE else os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)")),
-                      RuntimeWarning, stacklevel=3)
+                      "(INTEGRATION.md section 4)." % os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)"), RuntimeWarning, stacklevel=3)
 
 
 class TSRNTrainStep:
