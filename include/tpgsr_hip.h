@@ -32,7 +32,7 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
-/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc, 6 image_desc): a binding can verify its mirror */
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc, 6 image_desc, 7 gru_wgrad_args, 8 wgrad_batch_item, 9 bn_derive): a binding can verify its mirror */
 int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -124,7 +124,15 @@ typedef struct {
   float* fin_rv;
   float fin_momentum;
   float fin_eps;
+  /* --- granularity of bn_partial (round 5).  0 / 1: one row per 64-pixel block (every kernel).  3: one row per THREE consecutive blocks
+   *     = per 192-pixel super-tile of the whole-CU halo kernel, [ceil(ceil(M / 64) / 3)][2][Cout] -- a third of the rows for whoever
+   *     reduces them (csrc/bn_derive.h: every workgroup of the consuming launch).  Only the whole-CU kernel honours 3: ask
+   *     tpgsr_conv_bn_row_tiles() first, a launch that lands on any other kernel with 3 set is refused.  Not with fin_mode. --- */
+  int bn_row_tiles;
+  int reserved1;
 } tpgsr_conv_args;
+/* 3 when tpgsr_conv_fwd(a) will run on the whole-CU halo kernel (which can leave one bn_partial row per 192 pixels), else 1 */
+int tpgsr_conv_bn_row_tiles(const tpgsr_conv_args* a);
 
 int tpgsr_conv_fwd(const tpgsr_conv_args* a, void* stream);
 
@@ -344,6 +352,46 @@ int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long long count
 /* pass 2: dy = coef0*dz + coef1*y + coef2 (dz recomputed from da(+da2), y) */
 int tpgsr_bn_bwd_apply(const float* da, const float* da2, const float* y, long long M, int C, const float* scale,
                        const float* shift, int act, const float* coef, float* dy, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Consumer-side BatchNorm finalize (round 5; csrc/bn_derive.h).  The reduction of the producing convolution's partial rows that
+ * nn.BatchNorm2d's batch statistics (model/tsrn.py:376,380; model/stn_head.py:15; forward) and batch_norm_backward's coefficients
+ * (backward) need is done by the FIRST CONSUMER of the BatchNorm's output in its own prologue -- every workgroup sums the L2-resident
+ * rows in a fixed order, workgroup 0 publishes the result for the launches that follow -- instead of by a launch of its own
+ * (tpgsr_bn_finalize / tpgsr_bn_bwd_finalize stay for consumers without the prologue).  C: a power of two, 8 <= C <= 512.
+ *   forward  (tpgsr_affine_act_bnd, tpgsr_affine_act_pool_bnd): reads rows / count / bias / gamma / beta, writes scale / shift
+ *            (+ save_mean / save_rstd / running statistics when set) exactly as tpgsr_bn_finalize does
+ *   backward (tpgsr_bn_bwd_apply_bnd): reads rows ([.][0][c] = sum dz, [.][1][c] = sum dz * xhat) / count / gamma / save_mean /
+ *            save_rstd, writes coef (when set) and dgamma / dbeta (+= when accumulate) exactly as tpgsr_bn_bwd_finalize does
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tpgsr_bn_derive {
+  const float* rows;      /* [nrows][2][C] */
+  int nrows, C;
+  long long count;        /* elements per channel the rows were summed over */
+  const float* bias;      /* forward: the convolution's bias when it is not part of the stored map (shifts the mean only) or NULL */
+  const float* gamma;     /* [C] */
+  const float* beta;      /* forward */
+  float* running_mean;    /* forward, optional: updated with `momentum` (unbiased variance) */
+  float* running_var;
+  float momentum, eps;
+  float* scale;           /* forward out: folded scale / shift [C] */
+  float* shift;
+  float* save_mean;       /* forward: out (optional); backward: in */
+  float* save_rstd;
+  float* dgamma;          /* backward, optional */
+  float* dbeta;
+  float* coef;            /* backward, optional out [3][C] */
+  int accumulate;         /* backward: 1 = add to dgamma / dbeta */
+  int reserved;
+} tpgsr_bn_derive;
+/* tpgsr_affine_act with the BatchNorm finalized in the launch: out = act(scale[c] * x + shift[c]) */
+int tpgsr_affine_act_bnd(const tpgsr_bn_derive* d, const float* x, long long M, int act, float* out, void* stream);
+/* tpgsr_affine_act_pool likewise (STN head: conv -> BN -> ReLU -> max-pool, model/stn_head.py:34-45) */
+int tpgsr_affine_act_pool_bnd(const tpgsr_bn_derive* d, const float* x, int N, int H, int W, int act, int pool_h, int pool_w,
+                              float* out, void* stream);
+/* tpgsr_bn_bwd_finalize + tpgsr_bn_bwd_apply in one launch: dy = coef0 * dz + coef1 * y + coef2, dz = (da + da2) * act'(scale * y + shift) */
+int tpgsr_bn_bwd_apply_bnd(const tpgsr_bn_derive* d, const float* da, const float* da2, const float* y, long long M,
+                           const float* scale, const float* shift, int act, float* dy, void* stream);
+
 /* out = act(scale[c]*x + shift[c]) over an [M][C] tensor (scale/shift optional, C % 4 == 0): materialises an activation
  * once where re-applying it per filter tap in the consumer's loader would cost more (mish before a 3x3 / 9x1 conv). */
 int tpgsr_affine_act(const float* x, long long M, int C, const float* scale, const float* shift, int act, float* out,

@@ -1,0 +1,208 @@
+"""GPU: BatchNorm finalized by its FIRST CONSUMER (csrc/bn_derive.h, round 5) -- every workgroup of the consuming launch sums the producing
+convolution's partial rows itself, workgroup 0 publishes -- against the launches it replaces (tpgsr_bn_finalize + tpgsr_affine_act[_pool],
+tpgsr_bn_bwd_finalize + tpgsr_bn_bwd_apply) on the same rows, and the coarser statistics rows of the whole-CU halo kernel
+(tpgsr_conv_args.bn_row_tiles = 3) against the per-64-pixel rows.  Reference semantics: nn.BatchNorm2d in training mode and its backward
+(model/tsrn.py:376,380; model/stn_head.py:15)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bn(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    return dict(gamma=(torch.rand(C, generator=g) + 0.5).to(DEV), beta=torch.randn(C, generator=g).to(DEV),
+                bias=torch.randn(C, generator=g).to(DEV), rm=torch.randn(C, generator=g).to(DEV), rv=(torch.rand(C, generator=g) + 0.5).to(DEV))
+
+
+@pytest.mark.parametrize("M,C,nrows", [(49152, 64, 768), (49152, 64, 256), (12288, 32, 192), (96, 256, 2), (1248, 512, 20), (777, 8, 13)])
+def test_forward_derive_equals_finalize_plus_affine_act(M, C, nrows):
+    from tpgsr_amd import kernels as K
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(DEV)
+    rows = (torch.randn(nrows, 2, C, generator=g).abs() * 50 + 1).to(DEV)      # [.][1] > [.][0]^2 / count is not needed: var is clamped at 0
+    rows[:, 1] += rows[:, 0] ** 2
+    t = _bn(C, 1)
+    ref = {k: torch.empty(C, device=DEV) for k in ("scale", "shift", "mean", "rstd")}
+    rm0, rv0 = t["rm"].clone(), t["rv"].clone()
+    K.bn_finalize(rows, nrows, C, M, t["bias"], t["gamma"], t["beta"], rm0, rv0, ref["scale"], ref["shift"], ref["mean"], ref["rstd"])
+    out_ref = torch.empty(M, C, device=DEV)
+    K.affine_act(x, M, C, ref["scale"], ref["shift"], "mish", out_ref)
+    got = {k: torch.full((C,), float("nan"), device=DEV) for k in ("scale", "shift", "mean", "rstd")}
+    rm1, rv1 = t["rm"].clone(), t["rv"].clone()
+    d = K.make_bn_derive(rows, nrows, C, M, t["gamma"], bias=t["bias"], beta=t["beta"], running_mean=rm1, running_var=rv1,
+                         scale=got["scale"], shift=got["shift"], save_mean=got["mean"], save_rstd=got["rstd"])
+    out = torch.full((M, C), float("nan"), device=DEV)
+    K.affine_act_bnd(d, x, M, "mish", out)
+    torch.cuda.synchronize()
+    for k in ref:      # fp64 sums taken in a different order, rounded to fp32 once: equal to the last bit or two
+        assert torch.allclose(got[k], ref[k], rtol=3e-7, atol=0), (k, (got[k] - ref[k]).abs().max().item())
+    assert torch.allclose(rm1, rm0, rtol=3e-7, atol=1e-7) and torch.allclose(rv1, rv0, rtol=3e-7, atol=1e-7)
+    assert torch.allclose(out, out_ref, rtol=2e-6, atol=2e-6)
+    # every workgroup derives for itself, in an order fixed by (nrows, C): bitwise repeatable
+    out2 = torch.empty_like(out)
+    rm1.copy_(t["rm"]); rv1.copy_(t["rv"])
+    K.affine_act_bnd(d, x, M, "mish", out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_forward_derive_pool_variant():
+    from tpgsr_amd import kernels as K
+    N, H, W, C = 6, 16, 64, 32
+    M, nrows = N * H * W, (N * H * W + 63) // 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, C, generator=g).to(DEV)
+    rows = torch.zeros(nrows, 2, C, device=DEV)
+    xs = x.view(nrows, -1, C)
+    rows[:, 0], rows[:, 1] = xs.sum(1), (xs * xs).sum(1)
+    t = _bn(C, 2)
+    sc, sh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    K.bn_finalize(rows, nrows, C, M, None, t["gamma"], t["beta"], None, None, sc, sh)
+    ref = torch.empty(N * (H // 2) * (W // 2), C, device=DEV)
+    K.affine_act_pool(x, N, H, W, C, sc, sh, "relu", 2, 2, ref)
+    sc2, sh2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    d = K.make_bn_derive(rows, nrows, C, M, t["gamma"], beta=t["beta"], scale=sc2, shift=sh2)
+    out = torch.empty_like(ref)
+    K.affine_act_pool_bnd(d, x, N, H, W, "relu", 2, 2, out)
+    torch.cuda.synchronize()
+    assert torch.allclose(sc2, sc, rtol=3e-7, atol=0) and torch.allclose(sh2, sh, rtol=3e-7, atol=1e-7)
+    assert torch.allclose(out, ref, rtol=2e-6, atol=2e-6)
+    # and against nn.BatchNorm2d itself (training mode) + ReLU + max-pool
+    bn = torch.nn.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(t["gamma"]); bn.bias.copy_(t["beta"])
+        y = torch.nn.functional.max_pool2d(torch.relu(bn(x.view(N, H, W, C).permute(0, 3, 1, 2))), 2)
+    assert torch.allclose(out.view(N, H // 2, W // 2, C).permute(0, 3, 1, 2), y, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,C,nrows,act,two", [(49152, 64, 768, "mish", False), (49152, 64, 256, "none", True), (3072, 128, 48, "relu", False),
+                                               (1248, 512, 20, "relu", False)])
+def test_backward_derive_equals_finalize_plus_apply(M, C, nrows, act, two):
+    from tpgsr_amd import kernels as K
+    g = torch.Generator().manual_seed(M + 7 * C)
+    da, y = torch.randn(M, C, generator=g).to(DEV), torch.randn(M, C, generator=g).to(DEV)
+    da2 = torch.randn(M, C, generator=g).to(DEV) if two else None
+    rows = torch.randn(nrows, 2, C, generator=g).to(DEV) * 10
+    t = _bn(C, 5)
+    mean, rstd = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    scale, shift = t["gamma"] * rstd, t["beta"] - mean * t["gamma"] * rstd
+    dg0, db0 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    coef0, dy0 = torch.empty(3, C, device=DEV), torch.empty(M, C, device=DEV)
+    K.bn_bwd_finalize(rows, nrows, C, M, t["gamma"], mean, rstd, dg0, db0, coef0, accumulate=True)
+    K.bn_bwd_apply(da, da2, y, M, C, scale, shift, act, coef0, dy0)
+    dg1, db1 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    coef1, dy1 = torch.full((3, C), float("nan"), device=DEV), torch.full((M, C), float("nan"), device=DEV)
+    d = K.make_bn_derive(rows, nrows, C, M, t["gamma"], save_mean=mean, save_rstd=rstd, dgamma=dg1, dbeta=db1, coef=coef1, accumulate=True)
+    K.bn_bwd_apply_bnd(d, da, da2, y, M, scale, shift, act, dy1)
+    torch.cuda.synchronize()
+    assert torch.allclose(coef1, coef0, rtol=1e-6, atol=1e-9), (coef1 - coef0).abs().max().item()
+    assert torch.allclose(dg1, dg0, rtol=1e-6, atol=1e-6) and torch.allclose(db1, db0, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(dy1, dy0, rtol=1e-5, atol=1e-6), (dy1 - dy0).abs().max().item()
+    dy2 = torch.empty_like(dy1)
+    dg1.fill_(1.0); db1.fill_(1.0)
+    K.bn_bwd_apply_bnd(d, da, da2, y, M, scale, shift, act, dy2)
+    torch.cuda.synchronize()
+    assert torch.equal(dy1, dy2)
+
+
+def test_unsupported_channel_counts_are_refused_loudly(monkeypatch):
+    from tpgsr_amd import kernels as K
+    from tpgsr_amd._lib import TpgsrKernelError
+    monkeypatch.setattr(K, "BN_DERIVE", True)
+    assert not K.bn_derive_ok(96) and not K.bn_derive_ok(1024) and not K.bn_derive_ok(4) and K.bn_derive_ok(64)
+    C, M = 96, 640
+    rows, x = torch.zeros(10, 2, C, device=DEV), torch.zeros(M, C, device=DEV)
+    one = torch.ones(C, device=DEV)
+    d = K.make_bn_derive(rows, 10, C, M, one, beta=one, scale=one.clone(), shift=one.clone())
+    with pytest.raises(TpgsrKernelError, match="channel count"):
+        K.affine_act_bnd(d, x, M, "relu", torch.empty_like(x))
+
+
+@pytest.mark.parametrize("shape", [(48, 16, 64, 64, 64), (37, 16, 64, 64, 64), (48, 8, 25, 128, 256)])      # (37: 592 tiles = 197 super-tiles + 1 tile)
+def test_coarse_statistics_rows_of_the_whole_cu_kernel(shape):
+    """bn_row_tiles = 3: one row per 192-pixel super-tile == the three per-64-pixel rows added in tile order, bit for bit; forward
+    statistics and the BatchNorm-backward sums alike; a kernel that cannot honour it refuses the launch"""
+    from tpgsr_amd import _lib, kernels as K
+    from tpgsr_amd._lib import TpgsrKernelError
+    lib = _lib.load()
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N * H * W, Ci, generator=g).to(DEV)
+    w = (torch.randn(9 * Ci, Co, generator=g) / math.sqrt(9 * Ci)).to(DEV)
+    geom = K.ConvGeom(N, H, W, Ci, Co, 3, 3, 1, 1)
+    M, nblk = geom.M, (geom.M + 63) // 64
+    with K.conv_terms(2):
+        K.make_bf_twin(w, Ci)
+        fine, out0 = torch.full((nblk, 2, Co), float("nan"), device=DEV), torch.empty(M, Co, device=DEV)
+        K.conv_fwd(K.make_conv_args(geom, x, w, out0, bn_partial=fine))
+        a = K.make_conv_args(geom, x, w, torch.empty(M, Co, device=DEV), bn_partial=torch.full((nblk, 2, Co), float("nan"), device=DEV), bn_coarse=True)
+        assert a.bn_row_tiles == 3, "this shape is the whole-CU kernel's"
+        nr = K.bn_rows(M, 3)
+        coarse = torch.full((nr, 2, Co), float("nan"), device=DEV)
+        out1 = torch.empty(M, Co, device=DEV)
+        a = K.make_conv_args(geom, x, w, out1, bn_partial=coarse, bn_coarse=True)
+        K.conv_fwd(a)
+        torch.cuda.synchronize()
+        assert torch.equal(out0, out1)
+        pad = torch.zeros(nr * 3, 2, Co, device=DEV)
+        pad[:nblk] = fine
+        p3 = pad.view(nr, 3, 2, Co)
+        assert torch.equal(coarse, (p3[:, 0] + p3[:, 1]) + p3[:, 2])
+        # backward sums through the same flush
+        y, mean, rstd = torch.randn(M, Co, generator=g).to(DEV), torch.randn(Co, generator=g).to(DEV), (torch.rand(Co, generator=g) + 0.5).to(DEV)
+        sc, sh = torch.rand(Co, generator=g).to(DEV) + 0.5, torch.randn(Co, generator=g).to(DEV)
+        res = []
+        for coarse_on in (False, True):
+            part = torch.full((nr if coarse_on else nblk, 2, Co), float("nan"), device=DEV)
+            bnb = dict(y=y, mean=mean, rstd=rstd, scale=sc, shift=sh, act="mish", partial=part, coarse=coarse_on)
+            K.conv_fwd(K.make_conv_args(geom, x, w, torch.empty(M, Co, device=DEV), bnb=bnb))
+            assert bnb["row_tiles"] == (3 if coarse_on else 1)
+            res.append(part)
+        torch.cuda.synchronize()
+        pad[:] = 0
+        pad[:nblk] = res[0]
+        p3 = pad.view(nr, 3, 2, Co)
+        assert torch.equal(res[1], (p3[:, 0] + p3[:, 1]) + p3[:, 2])
+        # the two-workgroup kernel cannot: loud refusal, not silently finer rows
+        lib.tpgsr_halo3_set_enabled(0)
+        try:
+            assert lib.tpgsr_conv_bn_row_tiles(__import__("ctypes").byref(a)) == 1
+            with pytest.raises(TpgsrKernelError, match="bn_row_tiles"):
+                K.conv_fwd(a)
+        finally:
+            lib.tpgsr_halo3_set_enabled(1)
+
+
+def test_train_step_with_consumer_side_finalize_matches_the_separate_launches(monkeypatch):
+    """the switchable whole-step path (TPGSR_BN_DERIVE=1; off by default, profiles/r05e_bn_derive_ab.md): C2 at bs 8 with the STN on, three
+    steps -- losses, gradient norms and BatchNorm buffers against the default plans (fp64 sums in another order: last-bit differences
+    in scale / shift), and no finalize launch left where a consumer took it over"""
+    from oracle import tpgsr_oracle as O
+    from tpgsr_amd import kernels as K
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    from tpgsr_amd.model import tsrn
+    lr, hr = O.synthetic_batch(8, 21)
+    lr, hr = lr.to(DEV), hr.to(DEV)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(K, "BN_DERIVE", on)
+        net = tsrn.TSRN(STN=True, mask=True)
+        net.load_state_dict(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True), 31, tps_hw=(16, 64)))
+        net = net.to(DEV).train()
+        ts = TSRNTrainStep(net)
+        losses = [ts.step(lr, hr).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        names = [op[0] for pl in net._engine()._plans.values() for k in ("pre", "fwd", "bwd") for op in pl[k].ops]
+        bufs = torch.cat([b.detach().float().reshape(-1) for n, b in net.named_buffers() if "running" in n])
+        res.append((losses, ts.opt.grad_norm(net).item(), bufs, names))
+    (l0, g0, b0, n0), (l1, g1, b1, n1) = res
+    assert n1.count("tpgsr_bn_bwd_finalize") == 0 and n1.count("tpgsr_bn_bwd_apply_bnd") == n0.count("tpgsr_bn_bwd_apply") > 10
+    assert n1.count("tpgsr_affine_act_bnd") == 5 and n1.count("tpgsr_bn_finalize") == n0.count("tpgsr_bn_finalize") - 10
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 2e-5 * abs(a), (l0, l1)
+    assert abs(g0 - g1) < 1e-3 * g0
+    assert torch.allclose(b0, b1, rtol=1e-5, atol=1e-6)

@@ -34,7 +34,7 @@ class ConvArgs(C.Structure):
                 ("bnb_y", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_act", ci), ("bnb_store_dz", ci),
                 ("fin_mode", ci), ("fin_accumulate", ci), ("fin_count", ll), ("fin_counter", vp), ("fin_gamma", vp), ("fin_beta", vp),
                 ("fin_bias", vp), ("fin_scale", vp), ("fin_shift", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_rm", vp), ("fin_rv", vp),
-                ("fin_momentum", cf), ("fin_eps", cf)]
+                ("fin_momentum", cf), ("fin_eps", cf), ("bn_row_tiles", ci), ("reserved1", ci)]
 
 
 class WgradArgs(C.Structure):
@@ -76,6 +76,13 @@ class ImageDesc(C.Structure):
     _fields_ = [("offset", ll), ("H", ci), ("W", ci), ("xb_off", ci), ("xk_off", ci), ("kx", ci), ("yb_off", ci), ("yk_off", ci), ("ky", ci)]
 
 
+class BnDerive(C.Structure):
+    """tpgsr_bn_derive: a BatchNorm finalized inside its first consumer's launch (csrc/bn_derive.h)"""
+    _fields_ = [("rows", vp), ("nrows", ci), ("C", ci), ("count", ll), ("bias", vp), ("gamma", vp), ("beta", vp),
+                ("running_mean", vp), ("running_var", vp), ("momentum", cf), ("eps", cf), ("scale", vp), ("shift", vp),
+                ("save_mean", vp), ("save_rstd", vp), ("dgamma", vp), ("dbeta", vp), ("coef", vp), ("accumulate", ci), ("reserved", ci)]
+
+
 class PlanArg(C.Union):
     """tpgsr_plan_arg: one launch argument of a native plan (pointer / integer / float)"""
     _fields_ = [("p", vp), ("i", ll), ("f", C.c_double)]
@@ -108,6 +115,9 @@ _SIGS = {
     "tpgsr_version": (ci, []),
     "tpgsr_sizeof": (ci, [ci]),
     "tpgsr_conv_fwd": (ci, [C.POINTER(ConvArgs), vp]),
+    "tpgsr_affine_act_bnd": (ci, [C.POINTER(BnDerive), vp, ll, ci, vp, vp]),
+    "tpgsr_affine_act_pool_bnd": (ci, [C.POINTER(BnDerive), vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_bn_bwd_apply_bnd": (ci, [C.POINTER(BnDerive), vp, vp, vp, ll, vp, vp, ci, vp, vp]),
     "tpgsr_wgrad_splits": (ci, [ci, ci, ci]),
     "tpgsr_conv_wgrad": (ci, [C.POINTER(WgradArgs), vp]),
     "tpgsr_wgrad_halo_plan": (ci, [C.POINTER(ConvArgs), C.POINTER(ci), C.POINTER(C.c_longlong)]),
@@ -211,6 +221,7 @@ _SIGS = {
     "tpgsr_softmax_max": (ci, [vp, ci, ci, vp, vp, ci, ci, vp, vp]),
     "tpgsr_halo_trace": (ci, [vp]),
     "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
+    "tpgsr_conv_bn_row_tiles": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_halo_set_colmajor_min_bytes": (None, [C.c_longlong]),
     "tpgsr_halo_set_min_taps": (None, [ci]),
     "tpgsr_halo_set_ne9": (None, [ci]),
@@ -247,7 +258,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs, WgradBatchItem)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs, WgradBatchItem, BnDerive)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

@@ -312,10 +312,28 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
   int j = 0, pend_mblk = -1, pend_n0 = 0, ndone = 0;
   auto flush_pending = [&]() __attribute__((always_inline)) {   // the previous super-tile's BN statistics: behind a barrier now
     if (pend_mblk >= 0) {
+      if (a.bn_row_tiles == H3_TM) {
+        // ONE row per super-tile (tpgsr_conv_args.bn_row_tiles): the tiles' sums -- each exactly what the per-tile row would hold --
+        // added in tile order
+        if (tid < 64 && pend_n0 + tid < a.Cout) {
+          float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-      for (int m = 0; m < H3_TM; ++m)
-        if ((pend_mblk + m) * 64 < M)
-          xbf_bn_flush<1, 1>(a, M, pend_n0, pend_mblk + m, tid, red_base + (((ndone - 1) & 1) * H3_TM + m) * 256, a.fin_mode != 0);
+          for (int m = 0; m < H3_TM; ++m)
+            if ((pend_mblk + m) * 64 < M) {
+              const float* red = red_base + (((ndone - 1) & 1) * H3_TM + m) * 256;
+              v0 += red[tid] + red[128 + tid];
+              v1 += red[64 + tid] + red[192 + tid];
+            }
+          float* dst = a.bn_partial + (size_t)(pend_mblk / H3_TM) * 2 * a.Cout;
+          dst[pend_n0 + tid] = v0;
+          dst[a.Cout + pend_n0 + tid] = v1;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < H3_TM; ++m)
+          if ((pend_mblk + m) * 64 < M)
+            xbf_bn_flush<1, 1>(a, M, pend_n0, pend_mblk + m, tid, red_base + (((ndone - 1) & 1) * H3_TM + m) * 256, a.fin_mode != 0);
+      }
       pend_mblk = -1;
     }
   };
@@ -559,8 +577,8 @@ extern "C" void tpgsr_halo3_set_enabled(int on) { g_h3_on = on ? 1 : 0; }
 
 #define H3_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
 
-// returns 1 when launched, 0 when the shape is not this kernel's, < 0 on error
-extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+// > 0 (the halo capacity) when the shape is this kernel's, else 0
+static int halo3_takes(const tpgsr_conv_args* a, long long M, int ld) {
   const int T = a->terms;
   if (!g_h3_on || T < 1 || T > 2 || a->KH * a->KW < 3 || !((a->KH * a->KW) & 1) || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_b ||
       a->in_ps || (ld & ~7) || ld == 6 || a->OW + a->KW - 1 < 8)
@@ -576,6 +594,31 @@ extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M
   const long long nst = (long long)cdiv(cdiv(M, 64), H3_TM) * cdiv(a->Cout, 64);
   static const long long min_st = [] { const char* e = getenv("TPGSR_XBF_HALO3_MIN"); return e ? atoll(e) : 192ll; }();
   if (nst < min_st) return 0;
+  switch (ld) {
+#define H3_OK(B) case B:
+    H3_LD_CASES(H3_OK)
+#undef H3_OK
+    return Lcap;
+    default: return 0;
+  }
+}
+
+/* tpgsr_conv_args.bn_row_tiles: 3 when tpgsr_conv_fwd(a) lands here (the dispatch of conv_mfma.hip / conv_xbf.hip up to this kernel) */
+extern "C" int tpgsr_conv_bn_row_tiles(const tpgsr_conv_args* a) {
+  if (!a || !(a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) || a->fin_mode) return 1;
+  const int ld = (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0);
+  return halo3_takes(a, (long long)a->N * a->OH * a->OW, ld) > 0 ? H3_TM : 1;
+}
+
+// returns 1 when launched, 0 when the shape is not this kernel's, < 0 on error
+extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+  const int T = a->terms;
+  const int Lcap = halo3_takes(a, M, ld);
+  if (Lcap <= 0) return 0;
+  TPGSR_CHECK_ARG(a->bn_row_tiles == 0 || a->bn_row_tiles == 1 || (a->bn_row_tiles == H3_TM && !a->fin_mode),
+                  "tpgsr_conv_fwd(halo3): bn_row_tiles %d (0, 1 or %d without fin_mode)", a->bn_row_tiles, H3_TM);
+  const size_t lds = (size_t)2 * T * H3_PLANE + 2 * H3_TM * 1024 + 8 * 4096;
+  const long long nst = (long long)cdiv(cdiv(M, 64), H3_TM) * cdiv(a->Cout, 64);
   const void* fn = nullptr;
   const bool t9 = a->KH * a->KW == 9;
 #define H3_CASE(B)                                                                                                                 \

@@ -412,6 +412,7 @@ static int conv_fwd_impl(const tpgsr_conv_args* a, void* stream) {
     TPGSR_CHECK_ARG(a->kp >= K && (a->kp & 31) == 0 && ((uintptr_t)a->wt_bf & 15) == 0, "tpgsr_conv_fwd: bad split operand (kp %d, K %d)", a->kp, K);
     return tpgsr_conv_fwd_xbf_launch(a, M, K, ld, st);
   }
+  TPGSR_CHECK_ARG(a->bn_row_tiles <= 1, "tpgsr_conv_fwd: bn_row_tiles %d needs the whole-CU halo kernel (split-bf16 path)", a->bn_row_tiles);
   TPGSR_CHECK_ARG(!a->bnb_y, "tpgsr_conv_fwd: the BatchNorm-backward epilogue (bnb_y) exists in the split-bf16 kernels only (terms > 0, wt_bf, Cin %% 4 == 0)");
   // the 64-channel 3x3 trunk convs on 64-wide maps: weights-stationary kernel (TPGSR_CONV_WSTAT=0 falls back to the tile loop)
   static const bool wstat_on = [] { const char* e = getenv("TPGSR_CONV_WSTAT"); return !(e && e[0] == '0'); }();

@@ -27,6 +27,7 @@ extern "C" int tpgsr_sizeof(int which) {
     case 6: return (int)sizeof(tpgsr_image_desc);
     case 7: return (int)sizeof(tpgsr_gru_wgrad_args);
     case 8: return (int)sizeof(tpgsr_wgrad_batch_item);
+    case 9: return (int)sizeof(tpgsr_bn_derive);
     default: return -1;
   }
 }

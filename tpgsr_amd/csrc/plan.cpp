@@ -62,6 +62,7 @@ const std::unordered_map<std::string, Entry>& registry() {
       TPGSR_REG(tpgsr_pack_program), TPGSR_REG(tpgsr_mfma_probe), TPGSR_REG(tpgsr_copy), TPGSR_REG(tpgsr_zero),
       TPGSR_REG(tpgsr_bn_finalize), TPGSR_REG(tpgsr_bn_stats), TPGSR_REG(tpgsr_bn_bwd_reduce),
       TPGSR_REG(tpgsr_bn_bwd_finalize), TPGSR_REG(tpgsr_bn_bwd_apply), TPGSR_REG(tpgsr_affine_act),
+      TPGSR_REG_S(tpgsr_affine_act_bnd, tpgsr_bn_derive), TPGSR_REG_S(tpgsr_affine_act_pool_bnd, tpgsr_bn_derive), TPGSR_REG_S(tpgsr_bn_bwd_apply_bnd, tpgsr_bn_derive),
       TPGSR_REG(tpgsr_affine_act_pool), TPGSR_REG(tpgsr_affine_act_pool_bwd), TPGSR_REG(tpgsr_prelu_fwd),
       TPGSR_REG(tpgsr_prelu_bwd), TPGSR_REG(tpgsr_add), TPGSR_REG(tpgsr_act_bwd), TPGSR_REG(tpgsr_nchw_to_nhwc),
       TPGSR_REG(tpgsr_nhwc_to_nchw), TPGSR_REG(tpgsr_reduce_partials), TPGSR_REG(tpgsr_bigru_fwd),

@@ -198,7 +198,9 @@ class ConvLayer:
 
     def fwd(self, N, H, W, x, out, *, use_bias=True, **kw) -> ConvGeom:
         g = self.geom(N, H, W)
-        K.conv_fwd(K.make_conv_args(g, x, self.wt_f, out, bias=self.b if (use_bias and not self.tail) else None, **kw))
+        a = K.make_conv_args(g, x, self.wt_f, out, bias=self.b if (use_bias and not self.tail) else None, **kw)
+        K.conv_fwd(a)
+        g.bn_row_tiles = max(1, a.bn_row_tiles)       # granularity of the statistics rows this launch leaves (kernels.make_conv_args)
         return g
 
     def dgrad(self, N, H, W, dy, dx, **kw):
@@ -248,14 +250,26 @@ class BNLayer:
         nblk = (M + 63) // 64
         return self.eng.scratch("bn_partial", nblk * 2 * self.C), nblk
 
-    def finalize(self, M, conv_bias, training):
+    def finalize(self, M, conv_bias, training, row_tiles=1):
         if training:
-            part, nblk = self.partial(M)
+            part, _ = self.partial(M)
+            nblk = K.bn_rows(M, row_tiles)
             K.bn_finalize(part, nblk, self.C, M, conv_bias, self.gamma, self.beta, self.rm, self.rv, self.scale, self.shift,
                           self.save_mean, self.save_rstd)
         else:
             K.bn_finalize(None, 0, self.C, 0, None, self.gamma, self.beta, self.rm, self.rv, self.scale, self.shift,
                           eval_mode=True)
+
+    def derive_fwd(self, M, conv_bias, row_tiles=1):
+        """descriptor (kernels.make_bn_derive) for the FIRST consumer of this training-mode BatchNorm's output: that launch reduces the
+        producing convolution's partial rows itself (csrc/bn_derive.h) and finalize() is NOT recorded; None when the channel count is
+        outside the prologue's range or the switch is off (then: finalize() + the plain consumer)"""
+        if not K.bn_derive_ok(self.C):
+            return None
+        part, _ = self.partial(M)
+        return K.make_bn_derive(part, K.bn_rows(M, row_tiles), self.C, M, self.gamma, bias=conv_bias, beta=self.beta, running_mean=self.rm,
+                                running_var=self.rv, scale=self.scale, shift=self.shift, save_mean=self.save_mean,
+                                save_rstd=self.save_rstd)
 
     def fin(self, M, conv_bias):
         """kwargs (`bn_fin=`) for the training-mode convolution that leaves this BatchNorm's statistics in partial(M): the launch
@@ -277,7 +291,8 @@ class BNLayer:
             return None
         nblk = (M + 63) // 64
         part = self.eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
-        d = dict(y=y, mean=self.save_mean, rstd=self.save_rstd, scale=self.scale, shift=self.shift, act=act, partial=part)
+        d = dict(y=y, mean=self.save_mean, rstd=self.save_rstd, scale=self.scale, shift=self.shift, act=act, partial=part,
+                 coarse=not K.bn_fin_fused())      # (make_conv_args writes the granularity it settled on back as d["row_tiles"])
         if K.bn_fin_fused():       # the producing launch also reduces the sums (backward(..., fused=) then records the apply only)
             d["fin"] = dict(mode=2, count=M, counter=self.tickets[1:2], gamma=self.gamma, coef=self.coef,
                             dgamma=self.eng.G[self.prefix + ".weight"], dbeta=self.eng.G[self.prefix + ".bias"], accumulate=True)
@@ -289,7 +304,7 @@ class BNLayer:
         eng = self.eng
         if fused is not None:
             assert da2 is None and fused["y"] is y and fused["act"] == act
-            nblk, part = (M + 63) // 64, fused["partial"]
+            nblk, part = K.bn_rows(M, fused.get("row_tiles", 1)), fused["partial"]
             if fused.get("fin") is not None and K.BN_FIN_FUSE:      # finalized by the producing launch
                 K.bn_bwd_apply(da, da2, y, M, self.C, self.scale, self.shift, act, self.coef, dy)
                 return
@@ -297,6 +312,11 @@ class BNLayer:
             nblk = min(1024, max(1, M // 64))
             part = eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
             K.bn_bwd_reduce(da, da2, y, M, self.C, self.scale, self.shift, self.save_mean, self.save_rstd, act, part, nblk)
+        if K.bn_derive_ok(self.C):      # coefficients + dgamma / dbeta derived by the apply launch itself: one launch instead of two
+            d = K.make_bn_derive(part, nblk, self.C, M, self.gamma, save_mean=self.save_mean, save_rstd=self.save_rstd,
+                                 dgamma=eng.G[self.prefix + ".weight"], dbeta=eng.G[self.prefix + ".bias"], coef=self.coef, accumulate=True)
+            K.bn_bwd_apply_bnd(d, da, da2, y, M, self.scale, self.shift, act, dy)
+            return
         K.bn_bwd_finalize(part, nblk, self.C, M, self.gamma, self.save_mean, self.save_rstd, eng.G[self.prefix + ".weight"],
                           eng.G[self.prefix + ".bias"], self.coef, accumulate=True)
         K.bn_bwd_apply(da, da2, y, M, self.C, self.scale, self.shift, act, self.coef, dy)
@@ -840,15 +860,19 @@ class TSRNEngine(_EngineBase):
             gt2 = ws(t + "gt2", P1, 256) if training else None
             part, _ = L["bn1"].partial(P1)
             fin = L["bn1"].fin(P1, L["conv1"].b) if training else None      # finalized by the convolution's own launch
-            L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None, bn_fin=fin)
-            if fin is None:
-                L["bn1"].finalize(P1, L["conv1"].b, training)
+            g1 = L["conv1"].fwd(N, H, W, cur, y1, bn_partial=part if training else None, bn_fin=fin, bn_coarse=training)
             a1 = ws(t + "a1", P1, Cc)                   # mish(bn1(y1)) once: a 3x3 consumer would re-apply it 9x per element
-            K.affine_act(y1, P1, Cc, L["bn1"].scale, L["bn1"].shift, "mish", a1)
+            dd = L["bn1"].derive_fwd(P1, L["conv1"].b, g1.bn_row_tiles) if (training and fin is None) else None
+            if dd is not None:                          # the materialising launch finalizes bn1 itself
+                K.affine_act_bnd(dd, y1, P1, "mish", a1)
+            else:
+                if fin is None:
+                    L["bn1"].finalize(P1, L["conv1"].b, training, g1.bn_row_tiles)
+                K.affine_act(y1, P1, Cc, L["bn1"].scale, L["bn1"].shift, "mish", a1)
             fin = L["bn2"].fin(P1, L["conv2"].b) if training else None
-            L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None, bn_fin=fin)
+            g2 = L["conv2"].fwd(N, H, W, a1, y2, bn_partial=part if training else None, bn_fin=fin, bn_coarse=training)
             if fin is None:
-                L["bn2"].finalize(P1, L["conv2"].b, training)
+                L["bn2"].finalize(P1, L["conv2"].b, training, g2.bn_row_tiles)
             if self.tl:   # torch.cat([bn2(y2), text strip], 1) inside the 1x1 conv's loader (model/tsrn.py:419-423)
                 L["gru1"].fwd(N, H, W, y2, gi1, h1, gt1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
             else:
@@ -858,9 +882,9 @@ class TSRNEngine(_EngineBase):
         y7 = ws("y7", P1, Cc)
         part, _ = self.bn7.partial(P1)
         fin = self.bn7.fin(P1, self.conv7.b) if training else None
-        self.conv7.fwd(N, H, W, cur, y7, bn_partial=part if training else None, bn_fin=fin)
+        g7 = self.conv7.fwd(N, H, W, cur, y7, bn_partial=part if training else None, bn_fin=fin, bn_coarse=training)
         if fin is None:
-            self.bn7.finalize(P1, self.conv7.b, training)
+            self.bn7.finalize(P1, self.conv7.b, training, g7.bn_row_tiles)
         ups = ws("ups", 4 * P1, Cc)                      # pre-mish, pixel-shuffled [N][2H][2W][C]
         self.up.fwd(N, H, W, y7, ups, in2=b1, out_ps=True, **self.bn7.loader)
         mu = ws("mups", 4 * P1, Cc)                      # mish(ups) once (the 9-tap tail conv and its wgrad both read it)
@@ -934,10 +958,15 @@ class TSRNEngine(_EngineBase):
             s = ws(f"stn_s{i}", M, conv.Cout)
             part, _ = bn.partial(M)
             conv.fwd(N, h, w, cur, s, bn_partial=part)
-            bn.finalize(M, conv.b, True)
+            dd = bn.derive_fwd(M, conv.b) if i < 5 else None
+            if dd is None:
+                bn.finalize(M, conv.b, True)
             if i < 5:
                 a = ws(f"stn_a{i}", N * (h // ph) * (w // pw), conv.Cout)
-                K.affine_act_pool(s, N, h, w, conv.Cout, bn.scale, bn.shift, "relu", ph, pw, a)
+                if dd is not None:                      # the pooling launch finalizes this stage's BatchNorm itself
+                    K.affine_act_pool_bnd(dd, s, N, h, w, "relu", ph, pw, a)
+                else:
+                    K.affine_act_pool(s, N, h, w, conv.Cout, bn.scale, bn.shift, "relu", ph, pw, a)
                 cur = a
             else:
                 cur = s  # relu(bn(.)) of the last stage rides on fc1's loader

@@ -607,7 +607,8 @@ class ConvGeom:
 
 def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, in_scale=None, in_shift=None, in_act=None,
                    in_ps=False, in_ld=None, in_coff=0, in2_ld=None, out_act=None, out_ps=False, out_ld=None, out_coff=0,
-                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1, bnb=None, bn_fin=None) -> ConvArgs:
+                   bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1, bnb=None, bn_fin=None,
+                   bn_coarse=False) -> ConvArgs:
     """`bnb` (a dict from engine.BNLayer.fuse_stats): this convolution produces the gradient that enters a BatchNorm's backward pass --
     its epilogue also writes that BatchNorm's two reduction sums per 64-pixel row block (tpgsr_conv_args.bnb_y).
     `bn_fin` (a dict from engine.BNLayer.fin / fuse_stats(...)["fin"]): the launch also FINALIZES the BatchNorm whose statistics it
@@ -663,7 +664,24 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
         else:
             a.fin_scale, a.fin_shift, a.fin_mean = _p(f["coef"]), _p(f.get("dgamma")), _p(f.get("dbeta"))
             a.fin_accumulate = int(bool(f.get("accumulate", True)))
+    # bn_coarse (or bnb["coarse"]): whoever reduces the partial rows copes with ONE ROW PER 192 PIXELS when the launch lands on the
+    # whole-CU halo kernel (tpgsr_conv_args.bn_row_tiles; a third of the rows for every workgroup of a consumer that finalizes the
+    # BatchNorm itself, csrc/bn_derive.h); the caller reads the granularity back from `a.bn_row_tiles` / bnb["row_tiles"]
+    if (bn_coarse or (bnb is not None and bnb.get("coarse"))) and a.bn_partial and not a.fin_mode and BN_COARSE_ROWS and CONV_TERMS:
+        if _lib.load().tpgsr_conv_bn_row_tiles(C.byref(a)) == 3:
+            a.bn_row_tiles = 3
+    if bnb is not None:
+        bnb["row_tiles"] = max(1, a.bn_row_tiles)
     return a
+
+
+BN_COARSE_ROWS = os.environ.get("TPGSR_BN_COARSE_ROWS", "1") != "0"
+
+
+def bn_rows(M: int, row_tiles: int = 1) -> int:
+    """rows of a bn_partial buffer over M pixels at `row_tiles` 64-pixel blocks per row"""
+    nblk = (M + 63) // 64
+    return (nblk + max(1, row_tiles) - 1) // max(1, row_tiles)
 
 
 # BatchNorm finalize (forward statistics -> scale / shift; backward sums -> dgamma / dbeta / coefficients) as part of the convolution
@@ -897,6 +915,44 @@ def bn_bwd_finalize(partial, nblk, C_, count, gamma, save_mean, save_rstd, dgamm
 
 def bn_bwd_apply(da, da2, y, M, C_, scale, shift, act, coef, dy):
     _launch("tpgsr_bn_bwd_apply", _p(da), _p(da2), _p(y), M, C_, _p(scale), _p(shift), act_code(act), _p(coef), _p(dy))
+
+
+# BatchNorm finalized inside its first consumer's launch (csrc/bn_derive.h, round 5) instead of by tpgsr_bn_finalize / tpgsr_bn_bwd_finalize
+# launches of their own: every workgroup of the consumer (ONE 1024-thread workgroup per CU) sums the partial rows in its prologue.
+# OFF by default -- measured (profiles/r05e_bn_derive_ab.md): alone on the chip the fused launches WIN clearly (finalize + mish 19.0 us ->
+# 14.3 at 768 rows / 10.6 at 256; finalize + apply 19.5 -> 14.6 / 12.2), inside the three-stream train step they LOSE (C3 6.09 vs 5.93 ms):
+# a 1024-thread workgroup with 44 KB of LDS needs sixteen free wave slots on ONE CU and waits for the weight-gradient stream's
+# workgroups to drain (25 us per launch in the step's trace against 14.5 for the pair), where the 256-thread launches it replaces slot in
+# anywhere; with 256-thread workgroups the redundant row sums cost more than the launch they save (6.34 vs 6.06 ms).  What stays on:
+# the COARSER ROWS the whole-CU kernel leaves for whoever reduces them (bn_row_tiles, below).  TPGSR_BN_DERIVE=1 switches it on.
+BN_DERIVE = os.environ.get("TPGSR_BN_DERIVE", "0") == "1"
+
+
+def bn_derive_ok(C_: int) -> bool:
+    return BN_DERIVE and 8 <= C_ <= 512 and (C_ & (C_ - 1)) == 0
+
+
+def make_bn_derive(rows, nrows, C_, count, gamma, *, bias=None, beta=None, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
+                   scale=None, shift=None, save_mean=None, save_rstd=None, dgamma=None, dbeta=None, coef=None, accumulate=False):
+    d = _lib.BnDerive()
+    d.rows, d.nrows, d.C, d.count = _p(rows), int(nrows), int(C_), int(count)
+    d.bias, d.gamma, d.beta = _p(bias), _p(gamma), _p(beta)
+    d.running_mean, d.running_var, d.momentum, d.eps = _p(running_mean), _p(running_var), momentum, eps
+    d.scale, d.shift, d.save_mean, d.save_rstd = _p(scale), _p(shift), _p(save_mean), _p(save_rstd)
+    d.dgamma, d.dbeta, d.coef, d.accumulate = _p(dgamma), _p(dbeta), _p(coef), int(bool(accumulate))
+    return d
+
+
+def affine_act_bnd(d, x, M, act, out):
+    _launch("tpgsr_affine_act_bnd", C.byref(d), _p(x), M, act_code(act), _p(out))
+
+
+def affine_act_pool_bnd(d, x, N, H, W, act, ph, pw, out):
+    _launch("tpgsr_affine_act_pool_bnd", C.byref(d), _p(x), N, H, W, act_code(act), ph, pw, _p(out))
+
+
+def bn_bwd_apply_bnd(d, da, da2, y, M, scale, shift, act, dy):
+    _launch("tpgsr_bn_bwd_apply_bnd", C.byref(d), _p(da), _p(da2), _p(y), M, _p(scale), _p(shift), act_code(act), _p(dy))
 
 
 def affine_act(x, M, C_, scale, shift, act, out):
