@@ -32,7 +32,7 @@ extern "C" {
 
 const char* tpgsr_last_error(void);
 int tpgsr_version(void);
-/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc, 6 image_desc, 7 gru_wgrad_args, 8 wgrad_batch_item, 9 bn_derive): a binding can verify its mirror */
+/* sizeof of the argument structs (0 conv_args, 1 wgrad_args, 2 pack_desc, 3 wgrad_reduce_desc, 4 compose_bwd_desc, 5 split_desc, 6 image_desc, 7 gru_wgrad_args, 8 wgrad_batch_item, 9 bn_derive, 10 bigru_proj_args): a binding can verify its mirror */
 int tpgsr_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -427,6 +427,26 @@ int tpgsr_reduce_partials(const float* part, int Z, int n, float* out, int accum
  * ---------------------------------------------------------------------------------------------- */
 int tpgsr_bigru_fwd(const float* gi, const float* w_hh /* [2][96][32] */, const float* b_hh /* [2][96] */,
                     int N, int H, int W, int axis, float* h_out, float* gates /* [P][256] or NULL */, void* stream);
+/* GruBlock FORWARD in one launch (round 5, csrc/gru_proj.hip; model/tsrn.py:491-508 with the 1x1 convolution and nn.GRU's input
+ * projection composed, :419-426 for the text-prior variant): gi = loader(x) Wc^T + bc is computed by the wave that owns the sequence, on
+ * the matrix cores, into LDS, and the scan of tpgsr_bigru_fwd runs from there -- the [P][192] projection never touches HBM.
+ *   c       the projection as tpgsr_conv_args: in / in_ld, the loader (in_scale + in_shift, in2, in_b + cin_a), Cin 64 | 96, Cout 192,
+ *           bias = bc [192], terms 1..3 with wt_bf / kp = the operand Wc [Cin][192] split by tpgsr_split_bf_program; wt / out are not read
+ *   w_hh [2][96][32], b_hh [2][96], h_out [P][64], gates [P][256] or NULL (inference), axis as tpgsr_bigru_fwd
+ * tpgsr_bigru_proj_supported() says whether a GruBlock is this kernel's (scan length 16 or 64, the loaders above); results equal
+ * tpgsr_conv_fwd + tpgsr_bigru_fwd up to the accumulation order of the projection. */
+typedef struct tpgsr_bigru_proj_args {
+  tpgsr_conv_args c;
+  const float* w_hh;
+  const float* b_hh;
+  float* h_out;
+  float* gates;
+  int axis;
+  int reserved;
+} tpgsr_bigru_proj_args;
+int tpgsr_bigru_proj_supported(const tpgsr_bigru_proj_args* p);
+int tpgsr_bigru_proj_fwd(const tpgsr_bigru_proj_args* p, void* stream);
+void tpgsr_bigru_proj_set_enabled(int on);
 /* Backward through time from the gate values the forward pass stored: gates [P][256], column = dir*128 + q*32 + j,
  * q = (r, z, n, W_hn h + b_hn) -- pass gates = NULL to tpgsr_bigru_fwd at inference.  dh = dh_out (+ dh_out2 if
  * non-NULL).  Writes dgi [P][192] = (dr, dz, dn) pre-activation gradients of the input side and

@@ -1,0 +1,116 @@
+"""GPU: the GruBlock forward as ONE launch (csrc/gru_proj.hip: the composed input projection on the matrix cores into LDS + the
+bidirectional scan) against the two launches it replaces (tpgsr_conv_fwd into a [P][192] map + tpgsr_bigru_fwd) and against nn.GRU's gate
+equations in fp64 -- every loader the SR network uses (plain, BatchNorm affine, residual add, affine + concatenated text strip), both scan
+axes of the 16 x 64 map, two- and three-term arithmetic, training (gates stored) and inference.  Reference: GruBlock, model/tsrn.py:491-508;
+RecurrentResidualBlockTL, model/tsrn.py:411-426."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _case(N, H, W, Cin, loader, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = N * H * W
+    t = dict(x=torch.randn(P, 64, generator=g), wc=torch.randn(Cin, 192, generator=g) / Cin ** 0.5, bc=torch.randn(192, generator=g) * 0.1,
+             whh=torch.randn(2, 96, 32, generator=g) / 32 ** 0.5, bhh=torch.randn(2, 96, generator=g) * 0.1)
+    kw = {}
+    if loader in ("affine", "affine+strip"):
+        t["scale"], t["shift"] = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+        if loader == "affine+strip":
+            t["scale"][64:], t["shift"][64:] = 1.0, 0.0                 # (engine.BNLayer pads its scale / shift with the identity)
+            t["strip"] = torch.randn(N * W, 32, generator=g)
+    if loader == "residual":
+        t["x2"] = torch.randn(P, 64, generator=g)
+    t = {k: v.to(DEV).contiguous() for k, v in t.items()}
+    if "scale" in t:
+        kw.update(in_scale=t["scale"], in_shift=t["shift"])
+    if "strip" in t:
+        kw.update(in_b=t["strip"], cin_a=64)
+    if "x2" in t:
+        kw.update(in2=t["x2"])
+    return t, kw
+
+
+def _reference_fp64(t, N, H, W, Cin, axis):
+    """nn.GRU's equations (gate order r, z, n) on the fp64 projection of the loader's output"""
+    x = t["x"].double().cpu().view(N, H, W, 64)
+    if "scale" in t:
+        x = x * t["scale"][:64].double().cpu() + t["shift"][:64].double().cpu()
+    if "x2" in t:
+        x = x + t["x2"].double().cpu().view(N, H, W, 64)
+    if "strip" in t:
+        x = torch.cat([x, t["strip"].double().cpu().view(N, 1, W, 32).expand(N, H, W, 32)], -1)
+    gi = x @ t["wc"].double().cpu() + t["bc"].double().cpu()             # [N][H][W][192]
+    if axis == 1:
+        gi = gi.transpose(1, 2)                                          # sequences along H: [N][W][H][192]
+    S, T = gi.shape[0] * gi.shape[1], gi.shape[2]
+    gi = gi.reshape(S, T, 192)
+    whh, bhh = t["whh"].double().cpu(), t["bhh"].double().cpu()
+    out = torch.zeros(S, T, 64, dtype=torch.float64)
+    for d in range(2):
+        h = torch.zeros(S, 32, dtype=torch.float64)
+        for step in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            gh = h @ whh[d].T + bhh[d]
+            g_ = gi[:, step, 96 * d:96 * d + 96]
+            r = torch.sigmoid(g_[:, :32] + gh[:, :32])
+            z = torch.sigmoid(g_[:, 32:64] + gh[:, 32:64])
+            n = torch.tanh(g_[:, 64:] + r * gh[:, 64:])
+            h = (1 - z) * n + z * h
+            out[:, step, 32 * d:32 * d + 32] = h
+    out = out.view(-1, (W if axis == 1 else H), T, 64)
+    if axis == 1:
+        out = out.transpose(1, 2)
+    return out.reshape(N * H * W, 64)
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("axis,loader", [(0, "residual"), (0, "plain"), (1, "affine+strip"), (1, "affine"), (1, "plain"), (0, "affine")])
+def test_one_launch_gru_block_forward(axis, loader, terms):
+    from tpgsr_amd import kernels as K
+    N, H, W = 3, 16, 64
+    Cin = 96 if loader == "affine+strip" else 64
+    t, kw = _case(N, H, W, Cin, loader, seed=17 * axis + terms)
+    P = N * H * W
+    geom = K.ConvGeom(N, H, W, Cin, 192)
+    with K.conv_terms(terms):
+        K.make_bf_twin(t["wc"], 0)
+        # two launches
+        gi, h0, gt0 = torch.empty(P, 192, device=DEV), torch.empty(P, 64, device=DEV), torch.empty(P, 256, device=DEV)
+        K.conv_fwd(K.make_conv_args(geom, t["x"], t["wc"], gi, bias=t["bc"], **kw))
+        K.bigru_fwd(gi, t["whh"], t["bhh"], N, H, W, axis, h0, gt0)
+        # one launch, training and inference
+        h1, gt1, h2 = torch.full((P, 64), float("nan"), device=DEV), torch.full((P, 256), float("nan"), device=DEV), torch.full((P, 64), float("nan"), device=DEV)
+        pa = K.make_bigru_proj_args(K.make_conv_args(geom, t["x"], t["wc"], None, bias=t["bc"], **kw), t["whh"], t["bhh"], axis, h1, gt1)
+        assert K.bigru_proj_supported(pa)
+        K.bigru_proj_fwd(pa)
+        K.bigru_proj_fwd(K.make_bigru_proj_args(K.make_conv_args(geom, t["x"], t["wc"], None, bias=t["bc"], **kw), t["whh"], t["bhh"], axis, h2, None))
+        h3 = torch.empty_like(h1)
+        K.bigru_proj_fwd(K.make_bigru_proj_args(K.make_conv_args(geom, t["x"], t["wc"], None, bias=t["bc"], **kw), t["whh"], t["bhh"], axis, h3, None))
+    torch.cuda.synchronize()
+    ref = _reference_fp64(t, N, H, W, Cin, axis)
+    e_two, e_one = (h0.double().cpu() - ref).abs().max().item(), (h1.double().cpu() - ref).abs().max().item()
+    print(f"axis {axis} {loader} x{terms}: max |h - fp64| two launches {e_two:.2e}, one launch {e_one:.2e}; one vs two {float((h1 - h0).abs().max()):.2e}")
+    tol = 8e-5 if terms == 2 else 3e-6            # (two-term split: ~16 significand bits per operand, the scan feeds it back 64 times)
+    assert e_one < tol and e_one < 2 * e_two + 1e-6
+    assert (h1 - h0).abs().max() < tol and (gt1 - gt0).abs().max() < 2 * tol
+    assert torch.equal(h1, h2) and torch.equal(h2, h3)          # inference variant == training variant, bitwise repeatable
+
+
+def test_shapes_the_fused_kernel_does_not_take_fall_back_loudly():
+    from tpgsr_amd import kernels as K
+    from tpgsr_amd._lib import TpgsrKernelError
+    N, H, W = 2, 8, 32                                           # scan lengths 8 / 32: not this kernel's
+    t, kw = _case(N, H, W, 64, "plain", 1)
+    geom = K.ConvGeom(N, H, W, 64, 192)
+    with K.conv_terms(2):
+        K.make_bf_twin(t["wc"], 0)
+        h = torch.empty(N * H * W, 64, device=DEV)
+        pa = K.make_bigru_proj_args(K.make_conv_args(geom, t["x"], t["wc"], None, bias=t["bc"]), t["whh"], t["bhh"], 0, h, None)
+        assert not K.bigru_proj_supported(pa)
+        with pytest.raises(TpgsrKernelError, match="not the fused kernel"):
+            K.bigru_proj_fwd(pa)
+    with K.conv_terms(0):                                        # fp32 matrix cores: no split planes
+        pa = K.make_bigru_proj_args(K.make_conv_args(K.ConvGeom(3, 16, 64, 64, 192), t["x"], t["wc"], None, bias=t["bc"]), t["whh"], t["bhh"], 0, h, None)
+        assert not K.bigru_proj_supported(pa)

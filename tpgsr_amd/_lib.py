@@ -47,6 +47,10 @@ class GruWgradArgs(C.Structure):
                 ("axis", ci), ("zsplits", ci)]
 
 
+class BigruProjArgs(C.Structure):
+    _fields_ = [("c", ConvArgs), ("w_hh", vp), ("b_hh", vp), ("h_out", vp), ("gates", vp), ("axis", ci), ("reserved", ci)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst_f", vp), ("dst_d", vp), ("Cout", ci), ("Cin", ci), ("KH", ci), ("KW", ci),
                 ("kind", ci), ("f_ld", ci), ("f_coff", ci), ("wscale", cf), ("numel", ci), ("blk0", ci),
@@ -115,6 +119,9 @@ _SIGS = {
     "tpgsr_version": (ci, []),
     "tpgsr_sizeof": (ci, [ci]),
     "tpgsr_conv_fwd": (ci, [C.POINTER(ConvArgs), vp]),
+    "tpgsr_bigru_proj_supported": (ci, [C.POINTER(BigruProjArgs)]),
+    "tpgsr_bigru_proj_fwd": (ci, [C.POINTER(BigruProjArgs), vp]),
+    "tpgsr_bigru_proj_set_enabled": (None, [ci]),
     "tpgsr_affine_act_bnd": (ci, [C.POINTER(BnDerive), vp, ll, ci, vp, vp]),
     "tpgsr_affine_act_pool_bnd": (ci, [C.POINTER(BnDerive), vp, ci, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_bn_bwd_apply_bnd": (ci, [C.POINTER(BnDerive), vp, vp, vp, ll, vp, vp, ci, vp, vp]),
@@ -258,7 +265,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs, WgradBatchItem, BnDerive)):
+    for which, st in enumerate((ConvArgs, WgradArgs, PackDesc, WgradReduceDesc, ComposeBwdDesc, SplitDesc, ImageDesc, GruWgradArgs, WgradBatchItem, BnDerive, BigruProjArgs)):
         if lib.tpgsr_sizeof(which) != C.sizeof(st):
             raise TpgsrKernelError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes in the binding, "
                                    f"{lib.tpgsr_sizeof(which)} in {LIB_PATH}: rebuild (python -m tpgsr_amd.build)")

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtpgsr_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_xbf.hip", "conv_panel.hip", "conv_halo3.hip", "elementwise.hip", "gru.hip", "gru_wgrad.hip", "stn.hip", "loss_optim.hip", "crnn.hip", "lstm_seq.hip", "glue.hip", "metrics.hip", "preprocess.hip", "aster.hip", "error.cpp", "plan.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_xbf.hip", "conv_panel.hip", "conv_halo3.hip", "elementwise.hip", "gru.hip", "gru_proj.hip", "gru_wgrad.hip", "stn.hip", "loss_optim.hip", "crnn.hip", "lstm_seq.hip", "glue.hip", "metrics.hip", "preprocess.hip", "aster.hip", "error.cpp", "plan.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("TPGSR_FAST_MATH"):   # A/B switch only: v_exp_f32 / v_rcp_f32 activations (costs gradient parity, see common.h)
     FLAGS.append("-DTPGSR_FAST_MATH")

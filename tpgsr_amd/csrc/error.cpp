@@ -28,6 +28,7 @@ extern "C" int tpgsr_sizeof(int which) {
     case 7: return (int)sizeof(tpgsr_gru_wgrad_args);
     case 8: return (int)sizeof(tpgsr_wgrad_batch_item);
     case 9: return (int)sizeof(tpgsr_bn_derive);
+    case 10: return (int)sizeof(tpgsr_bigru_proj_args);
     default: return -1;
   }
 }

@@ -1,0 +1,75 @@
+// Device code shared by the BiGRU kernels (gru.hip: the scans over precomputed input projections and back-propagation through time;
+// gru_proj.hip: the forward scan with the GruBlock's input projection computed in the same launch): sequence geometry, the gate
+// functions of the recurrence, packed-FMA helpers.  GruBlock: model/tsrn.py:491-508.
+#pragma once
+#include "common.h"
+
+#define GRU_H 32
+// one wavefront per workgroup: the per-step barrier degenerates to wave-local ordering
+
+struct SeqGeom {
+  int base;    // pixel index of t = 0 (32-bit: the launchers bound N H W 256 by 2^31 -- 64-bit multiplies were ~20 instructions of a step)
+  int stride;  // pixel stride between time steps
+  int T;
+  bool active;
+};
+
+__device__ __forceinline__ SeqGeom seq_geom(int s, int N, int H, int W, int axis) {
+  SeqGeom g;
+  int nseq = axis == 0 ? N * H : N * W;
+  g.active = s < nseq;
+  if (!g.active) s = 0;
+  if (axis == 0) {
+    g.base = s * W;
+    g.stride = 1;
+    g.T = W;
+  } else {
+    int n = s / W, col = s - n * W;
+    g.base = n * H * W + col;
+    g.stride = W;
+    g.T = H;
+  }
+  return g;
+}
+
+// Gate functions of the recurrence.  A time step is ONE dependent instruction stream per wave (a step of the W-axis scan runs with at most
+// one wave per SIMD), so its length in instructions is its latency: libm's expf + expm1f + three IEEE divisions were ~110 of the ~190
+// instructions of a step.  These keep libm-level accuracy in a third of that:
+//   e^x   = v_exp_f32(t) * (1 + ln2 * lo),  t = fl(x log2e), lo = the exact rounding error of t + x * (log2e - fl(log2e))   (6 instructions;
+//           the bare v_exp_f32(x * log2e) loses |x| * 6e-8 relative -- common.h's note on what that did to the text-prior gradient)
+//   1 / d = v_rcp_f32 + one Newton step (3 instructions, <= 1 ulp)
+//   tanh  = x * P(x^2) for |x| < 0.35 (odd Taylor polynomial to x^11: 5e-9 relative), (1 - q) / (1 + q) with q = e^(-2|x|) elsewhere
+// Checked against fp64 over the gates' range by tests/test_gru_gate_math_gpu.py: worst case 3.5 ulp (sigmoid) / 4.5 ulp (tanh, where
+// 1 - q cancels one bit), against 2 ulp of the libm path; mean error 0.4 ulp either way.
+__device__ __forceinline__ float gru_exp(float x) {
+  const float t = x * 1.44269504088896341f;
+  float lo = __builtin_fmaf(x, 1.44269504088896341f, -t);
+  lo = __builtin_fmaf(x, 1.925963033500011e-08f, lo);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float gru_rcp(float d) {      // d finite, |d| in [2^-126, 2^126]
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+}
+__device__ __forceinline__ float gru_sigmoid(float x) { return gru_rcp(1.f + gru_exp(fminf(-x, 80.f))); }
+__device__ __forceinline__ float gru_tanh(float x) {
+  const float q = gru_exp(-2.f * fabsf(x));
+  const float big = (1.f - q) * gru_rcp(1.f + q);
+  const float x2 = x * x;
+  float p = __builtin_fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
+  p = __builtin_fmaf(x2, p, -17.f / 315.f);
+  p = __builtin_fmaf(x2, p, 2.f / 15.f);
+  p = __builtin_fmaf(x2, p, -1.f / 3.f);
+  p = __builtin_fmaf(x2, p, 1.f);
+  return fabsf(x) < 0.35f ? x * p : copysignf(big, x);
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 mk2(float x, float y) {
+  f2 v;
+  v.x = x;
+  v.y = y;
+  return v;
+}

@@ -1,0 +1,278 @@
+// GruBlock forward in ONE launch (round 5): the composed input projection gi = loader(x) Wc^T + bc
+// (model/tsrn.py:495-496: the 1x1 convolution and nn.GRU's W_ih back to back, tpgsr_amd.engine.GruLayer) is computed by the wave that owns
+// the sequence, on the matrix cores, straight into LDS -- and the bidirectional scan of gru.hip runs from there.  Until round 4 the
+// projection was a launch of its own (the row-panel kernel, conv_panel.hip) that wrote gi [P][192] to HBM (37.7 MB at bs 48) for the
+// scan to read back through a prefetch ring: 10 launches and 0.75 GB per forward pass that need not exist.
+//
+// One wavefront = one workgroup = one sequence of T = 16 NRT steps (the 16 x 64 map: T = 16 along H, 64 along W), as in gru.hip.
+//   phase 1  the [T x Cin] input panel as MFMA fragments STRAIGHT FROM GLOBAL MEMORY: a 16x16x32 fragment is 8 consecutive channels of one
+//            pixel per lane (32 contiguous bytes), so no LDS transposition is needed; the fused prologue of the convolution loaders
+//            (BatchNorm affine, residual add, concatenated text strip: conv_loader.h's LD bits 1 / 4 / 16) is applied and the values are
+//            split into bf16 terms in registers (conv_xbf_common.h: exact three-term or two-term split-operand arithmetic);
+//   phase 2  gi^T tiles = Wc^T-tile x panel^T: the weight fragment is the A operand, the panel the B operand, so a lane ends up with FOUR
+//            CONSECUTIVE gate columns of one time step -> one ds_write_b128 per 16 x 16 tile into gi [T][196] (row pitch 196 floats: the
+//            sixteen time steps of a tile land in distinct bank quads).  Weight fragments come from the planes tpgsr_split_bf_program
+//            wrote for the 32x32x16 kernels ([term][n/32][k/16][lane][8]); a 16x16x32 fragment is a different 16-byte gather of the same
+//            bytes.  288 MFMAs per 64-step sequence in two-term arithmetic (~2 us), the weights stay L2-resident.
+//   phase 3  the scan of bigru_fwd_kernel, value for value (same gate functions, same packed-FMA order), with the step's three input
+//            projections read from LDS one step ahead instead of from HBM eight steps ahead.
+// LDS: 4 T x 196 B + 512 B = 49.5 KB per 64-step sequence (three per CU = the 768 sequences of the W-axis scan in one round), 12.8 KB per
+// 16-step sequence.  Forward only: back-propagation through time keeps its own kernels (the weight-gradient stream's workgroups leave
+// no room for 50 KB workgroups next to them, profiles/r05e_bn_derive_ab.md tells that story for BatchNorm).
+#include "conv_xbf_common.h"
+#include "gru_common.h"
+#include <mutex>
+#include <vector>
+
+#define GP_RS 196     // floats per gi row in LDS
+
+__device__ __forceinline__ floatx4 gp_mfma(const bf16x8 a, const bf16x8 b, const floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// acc += sum over the term pairs kept by the policy, smallest magnitudes first (as mfma_terms of conv_xbf_common.h)
+template <int TT>
+__device__ __forceinline__ floatx4 gp_mfma_terms(const bf16x8 (&w)[TT], const bf16x8 (&x)[TT], floatx4 acc) {
+  if (TT == 3) {
+    acc = gp_mfma(w[0], x[2], acc);
+    acc = gp_mfma(w[2], x[0], acc);
+    acc = gp_mfma(w[1], x[1], acc);
+    acc = gp_mfma(w[0], x[1], acc);
+    acc = gp_mfma(w[1], x[0], acc);
+  }
+  if (TT == 2) {
+    acc = gp_mfma(w[0], x[1], acc);
+    acc = gp_mfma(w[1], x[0], acc);
+  }
+  return gp_mfma(w[0], x[0], acc);
+}
+
+// LD: 1 = per-channel affine (BatchNorm) on the image channels, 4 = residual add (in2), 16 = channels >= cin_a from the [N][W][.] strip
+template <int LD, int TT, int NRT, int NKS, bool TRAIN>
+__global__ __launch_bounds__(64) void bigru_proj_fwd_kernel(const tpgsr_bigru_proj_args p) {
+  constexpr int T = 16 * NRT;
+  extern __shared__ __attribute__((aligned(16))) float gsm[];      // gi [T][GP_RS], then hs [2][64]
+  float* const gi = gsm;
+  float* const hs = gsm + T * GP_RS;
+  const tpgsr_conv_args& a = p.c;
+  const int lane = threadIdx.x & 63;
+  const SeqGeom g = seq_geom(blockIdx.x, a.N, a.H, a.W, p.axis);
+  if (!g.active) return;        // (one wave per workgroup: nobody waits for it)
+  const int l16 = lane & 15, kq = lane >> 4;
+
+  // ---- phase 1: the panel as split MFMA fragments: xf[rt][ks][term] = 8 channels 32 ks + 8 kq .. of time step 16 rt + l16 ----
+  bf16x8 xf[NRT][NKS][TT];
+  {
+    const int hw = a.H * a.W;
+    float4 lo[NRT][NKS], hi[NRT][NKS], lo2[NRT][NKS], hi2[NRT][NKS];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const int pix = g.base + (16 * rt + l16) * g.stride;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int c = 32 * ks + 8 * kq;
+        const float* src;
+        if ((LD & 16) && c >= a.cin_a) {        // the text strip: one row per (image, column), shared by all H rows
+          const int n = pix / hw, w = pix % a.W;
+          src = a.in_b + (size_t)(n * a.W + w) * a.in_b_ld + (c - a.cin_a);
+        } else {
+          src = a.in + (size_t)pix * a.in_ld + a.in_coff + c;
+        }
+        lo[rt][ks] = *reinterpret_cast<const float4*>(src);
+        hi[rt][ks] = *reinterpret_cast<const float4*>(src + 4);
+        if (LD & 4) {
+          const float* s2 = a.in2 + (size_t)pix * a.in2_ld + c;
+          lo2[rt][ks] = *reinterpret_cast<const float4*>(s2);
+          hi2[rt][ks] = *reinterpret_cast<const float4*>(s2 + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int c = 32 * ks + 8 * kq;
+      const bool img = !(LD & 16) || c < a.cin_a;
+      float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+      if ((LD & 1) && img) {
+        s0 = *reinterpret_cast<const float4*>(a.in_scale + c);
+        s1 = *reinterpret_cast<const float4*>(a.in_scale + c + 4);
+        t0 = *reinterpret_cast<const float4*>(a.in_shift + c);
+        t1 = *reinterpret_cast<const float4*>(a.in_shift + c + 4);
+      }
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        float4 u = lo[rt][ks], v = hi[rt][ks];
+        if (LD & 1) {      // (identity on the strip's channels: 1 * x + 0 is exact)
+          u.x = u.x * s0.x + t0.x; u.y = u.y * s0.y + t0.y; u.z = u.z * s0.z + t0.z; u.w = u.w * s0.w + t0.w;
+          v.x = v.x * s1.x + t1.x; v.y = v.y * s1.y + t1.y; v.z = v.z * s1.z + t1.z; v.w = v.w * s1.w + t1.w;
+        }
+        if (LD & 4) {
+          u.x += lo2[rt][ks].x; u.y += lo2[rt][ks].y; u.z += lo2[rt][ks].z; u.w += lo2[rt][ks].w;
+          v.x += hi2[rt][ks].x; v.y += hi2[rt][ks].y; v.z += hi2[rt][ks].z; v.w += hi2[rt][ks].w;
+        }
+        uint2 hu[TT], hv[TT];
+        split4<TT>(u, hu);
+        split4<TT>(v, hv);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          u32x4 q;
+          q.x = hu[t].x; q.y = hu[t].y; q.z = hv[t].x; q.w = hv[t].y;
+          xf[rt][ks][t] = __builtin_bit_cast(bf16x8, q);
+        }
+      }
+    }
+  }
+
+  // ---- phase 2: gi [t][col] = bc[col] + sum_k panel[t][k] Wc[k][col], twelve 16-column tiles ----
+  {
+    constexpr int KB16 = 2 * NKS;                       // k-blocks of 16 in the split planes (kp = 32 NKS)
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const float*>(a.wt_bf), (size_t)TT * 6 * 32 * (32 * NKS) / 2);
+    constexpr unsigned plane_w = 6u * KB16 * 1024u;
+    // this lane's 16-byte piece of a (16-column tile ct, k-step ks) weight fragment inside the 32x32x16 fragment planes: column
+    // ct 16 + l16 -> block (ct >> 1), lane slot (ct & 1) 16 + l16 (+ 32 for the upper 8 of a 16-k block); k = 32 ks + 8 kq -> k-block
+    // 2 ks + (kq >> 1), upper half when kq is odd
+    const unsigned wlane = ((unsigned)l16 + 32u * (kq & 1)) * 16u + (unsigned)(kq >> 1) * 1024u;
+#pragma unroll 2
+    for (int ct = 0; ct < 12; ++ct) {
+      bf16x8 wf[NKS][TT];
+      const unsigned wbase = ((unsigned)(ct >> 1) * KB16) * 1024u + (unsigned)(ct & 1) * 256u + wlane;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+          wf[ks][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase + t * plane_w + (unsigned)ks * 2048u), 0, 0));
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 16 + 4 * kq);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) acc = gp_mfma_terms<TT>(wf[ks], xf[rt][ks], acc);
+        // lane: time step 16 rt + l16, gate columns ct 16 + 4 kq .. + 3
+        float4 o;
+        o.x = acc[0] + b4.x; o.y = acc[1] + b4.y; o.z = acc[2] + b4.z; o.w = acc[3] + b4.w;
+        *reinterpret_cast<float4*>(gi + (16 * rt + l16) * GP_RS + ct * 16 + 4 * kq) = o;
+      }
+    }
+  }
+
+  __syncthreads();      // (one wave: its LDS operations execute in order anyway; this makes the hand-over explicit for the compiler)
+
+  // ---- phase 3: the scan (bigru_fwd_kernel of gru.hip, the inputs out of LDS) ----
+  const int d = lane >> 5, j = lane & 31;
+  f2 wrz[GRU_H], wn2[GRU_H / 2];
+  {
+    const float* pr = p.w_hh + ((size_t)(d * 96 + 0 * 32 + j)) * GRU_H;
+    const float* pz = p.w_hh + ((size_t)(d * 96 + 1 * 32 + j)) * GRU_H;
+    const float* pn = p.w_hh + ((size_t)(d * 96 + 2 * 32 + j)) * GRU_H;
+#pragma unroll
+    for (int k = 0; k < GRU_H; ++k) wrz[k] = mk2(pr[k], pz[k]);
+#pragma unroll
+    for (int k = 0; k < GRU_H / 2; ++k) wn2[k] = mk2(pn[2 * k], pn[2 * k + 1]);
+  }
+  const float br = p.b_hh[d * 96 + j], bz = p.b_hh[d * 96 + 32 + j], bn = p.b_hh[d * 96 + 64 + j];
+  float h = 0.f;
+  hs[lane] = 0.f;
+  __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order; this only pins the compiler's order
+  const int dpix = d == 0 ? g.stride : -g.stride;
+  int pix = g.base + (d == 0 ? 0 : (T - 1) * g.stride);
+  const int drow = d == 0 ? GP_RS : -GP_RS;
+  const float* gp = gi + (d == 0 ? 0 : (T - 1) * GP_RS) + d * 96 + j;      // this lane's r-gate input of the current step
+  float cr = gp[0], cz = gp[32], cn = gp[64];
+#pragma unroll 2
+  for (int step = 0; step < T; ++step) {
+    const float ir = cr, iz = cz, in_ = cn;
+    if (step + 1 < T) {                   // next step's inputs: issued now, needed one step later
+      gp += drow;
+      cr = gp[0]; cz = gp[32]; cn = gp[64];
+    }
+    f2 a0 = mk2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, n0 = a0, n1 = a0;
+    const float4* hp = reinterpret_cast<const float4*>(&hs[(step & 1) * 64 + d * 32]);
+#pragma unroll
+    for (int k = 0; k < GRU_H / 4; ++k) {
+      const float4 hv = hp[k];
+      a0 = pk_fma(wrz[4 * k], mk2(hv.x, hv.x), a0);
+      a1 = pk_fma(wrz[4 * k + 1], mk2(hv.y, hv.y), a1);
+      a2 = pk_fma(wrz[4 * k + 2], mk2(hv.z, hv.z), a2);
+      a3 = pk_fma(wrz[4 * k + 3], mk2(hv.w, hv.w), a3);
+      n0 = pk_fma(wn2[2 * k], mk2(hv.x, hv.y), n0);
+      n1 = pk_fma(wn2[2 * k + 1], mk2(hv.z, hv.w), n1);
+    }
+    const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
+    const float an = bn + (nn.x + nn.y);
+    const float r = gru_sigmoid(ir + (br + rz.x));
+    const float z = gru_sigmoid(iz + (bz + rz.y));
+    const float n = gru_tanh(in_ + r * an);
+    h = (1.f - z) * n + z * h;
+    hs[((step + 1) & 1) * 64 + lane] = h;
+    p.h_out[pix * 64 + d * 32 + j] = h;
+    if (TRAIN) {
+      float* q = p.gates + pix * 256 + d * 128 + j;
+      q[0] = r; q[32] = z; q[64] = n; q[96] = an;
+    }
+    pix += dpix;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static int g_gp_on = [] { const char* e = getenv("TPGSR_GRU_PROJ_FUSE"); return (e && e[0] == '0') ? 0 : 1; }();
+/* experiment / test switch: 0 makes tpgsr_bigru_proj_supported() say no (the engines then record projection + scan as two launches) */
+extern "C" void tpgsr_bigru_proj_set_enabled(int on) { g_gp_on = on ? 1 : 0; }
+
+static int gp_loader_bits(const tpgsr_conv_args* a) {
+  return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0);
+}
+
+/* 1 when tpgsr_bigru_proj_fwd takes this GruBlock: split-operand arithmetic (terms 1..3 with the pre-split weight planes), Cin 64 or 96,
+ * 192 gate columns, scan length 16 or 64, a loader it has (plain, BatchNorm affine, residual add, affine + text strip) */
+extern "C" int tpgsr_bigru_proj_supported(const tpgsr_bigru_proj_args* p) {
+  if (!p || !g_gp_on) return 0;
+  const tpgsr_conv_args* a = &p->c;
+  const int T = p->axis == 0 ? a->W : a->H, ld = gp_loader_bits(a);
+  if (a->terms < 1 || a->terms > 3 || !a->wt_bf || a->wt_bf_cin != 0 || a->Cout != 192 || (a->Cin != 64 && a->Cin != 96) || a->kp != a->Cin) return 0;
+  if (a->KH * a->KW != 1 || a->wt_ld || a->wt_coff || a->in_coff || a->stride_w > 1 || a->in_dil_w > 1) return 0;
+  if (T != 16 && T != 64) return 0;
+  if (!(ld == 0 || ld == 1 || ld == 4 || ld == 17)) return 0;
+  if ((ld & 16) && (a->cin_a != 64 || a->Cin != 96)) return 0;
+  return 1;
+}
+
+extern "C" int tpgsr_bigru_proj_fwd(const tpgsr_bigru_proj_args* p, void* stream) {
+  TPGSR_CHECK_ARG(p && p->c.in && p->c.bias && p->w_hh && p->b_hh && p->h_out, "tpgsr_bigru_proj_fwd: null pointer");
+  TPGSR_CHECK_ARG(p->axis == 0 || p->axis == 1, "tpgsr_bigru_proj_fwd: bad axis");
+  TPGSR_CHECK_ARG(tpgsr_bigru_proj_supported(p), "tpgsr_bigru_proj_fwd: this GruBlock is not the fused kernel's (ask tpgsr_bigru_proj_supported first: "
+                  "Cin %d, terms %d, scan length %d, loader %d)", p->c.Cin, p->c.terms, p->axis == 0 ? p->c.W : p->c.H, gp_loader_bits(&p->c));
+  const tpgsr_conv_args* a = &p->c;
+  TPGSR_CHECK_ARG((long long)a->N * a->H * a->W * 256 < (1ll << 31), "tpgsr_bigru_proj_fwd: map too large for the kernel's 32-bit indices");
+  TPGSR_CHECK_ARG((a->in_ld & 3) == 0 && (((uintptr_t)a->in | (uintptr_t)a->bias) & 15) == 0 && (!a->in2 || ((a->in2_ld & 3) == 0 && ((uintptr_t)a->in2 & 15) == 0)) &&
+                  (!a->in_b || ((a->in_b_ld & 3) == 0 && ((uintptr_t)a->in_b & 15) == 0)) && (!a->in_scale || (((uintptr_t)a->in_scale | (uintptr_t)a->in_shift) & 15) == 0),
+                  "tpgsr_bigru_proj_fwd: operands must be 16-byte aligned with row pitches that are multiples of 4 floats");
+  const int T = p->axis == 0 ? a->W : a->H, nseq = p->axis == 0 ? a->N * a->H : a->N * a->W;
+  const int ld = gp_loader_bits(a), nks = a->Cin / 32, tt = a->terms;
+  const bool train = p->gates != nullptr;
+  const void* fn = nullptr;
+#define GP_PICK3(LDV, TTV, NRTV, NKSV) fn = train ? (const void*)bigru_proj_fwd_kernel<LDV, TTV, NRTV, NKSV, true> : (const void*)bigru_proj_fwd_kernel<LDV, TTV, NRTV, NKSV, false>;
+#define GP_PICK2(LDV, TTV)                                       \
+  if (T == 64 && nks == 2) { GP_PICK3(LDV, TTV, 4, 2) }           \
+  else if (T == 16 && nks == 2) { GP_PICK3(LDV, TTV, 1, 2) }      \
+  else if (T == 64 && nks == 3) { GP_PICK3(LDV, TTV, 4, 3) }      \
+  else { GP_PICK3(LDV, TTV, 1, 3) }
+#define GP_PICK1(LDV)                      \
+  if (tt == 1) { GP_PICK2(LDV, 1) }        \
+  else if (tt == 2) { GP_PICK2(LDV, 2) }   \
+  else { GP_PICK2(LDV, 3) }
+  switch (ld) {
+    case 0: GP_PICK1(0) break;
+    case 1: GP_PICK1(1) break;
+    case 4: GP_PICK1(4) break;
+    default: GP_PICK1(17) break;
+  }
+#undef GP_PICK1
+#undef GP_PICK2
+#undef GP_PICK3
+  const size_t lds = ((size_t)T * GP_RS + 128) * sizeof(float);
+  tpgsr_bigru_proj_args args = *p;
+  void* params[] = {&args};
+  if (hipLaunchKernel(fn, dim3((unsigned)nseq), dim3(64), params, lds, (hipStream_t)stream) != hipSuccess) {
+    tpgsr_set_error("tpgsr_bigru_proj_fwd: launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return TPGSR_ERR_LAUNCH;
+  }
+  TPGSR_LAUNCH_CHECK("tpgsr_bigru_proj_fwd");
+}

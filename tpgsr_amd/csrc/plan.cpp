@@ -66,7 +66,7 @@ const std::unordered_map<std::string, Entry>& registry() {
       TPGSR_REG(tpgsr_affine_act_pool), TPGSR_REG(tpgsr_affine_act_pool_bwd), TPGSR_REG(tpgsr_prelu_fwd),
       TPGSR_REG(tpgsr_prelu_bwd), TPGSR_REG(tpgsr_add), TPGSR_REG(tpgsr_act_bwd), TPGSR_REG(tpgsr_nchw_to_nhwc),
       TPGSR_REG(tpgsr_nhwc_to_nchw), TPGSR_REG(tpgsr_reduce_partials), TPGSR_REG(tpgsr_bigru_fwd),
-      TPGSR_REG(tpgsr_bigru_bwd), TPGSR_REG(tpgsr_bigru_bwd2), TPGSR_REG_S(tpgsr_gru_wgrad, tpgsr_gru_wgrad_args), TPGSR_REG(tpgsr_tps_grid_fwd), TPGSR_REG(tpgsr_tps_grid_bwd),
+      TPGSR_REG(tpgsr_bigru_bwd), TPGSR_REG(tpgsr_bigru_bwd2), TPGSR_REG_S(tpgsr_bigru_proj_fwd, tpgsr_bigru_proj_args), TPGSR_REG_S(tpgsr_gru_wgrad, tpgsr_gru_wgrad_args), TPGSR_REG(tpgsr_tps_grid_fwd), TPGSR_REG(tpgsr_tps_grid_bwd),
       TPGSR_REG(tpgsr_grid_sample_fwd), TPGSR_REG(tpgsr_grid_sample_bwd), TPGSR_REG(tpgsr_strip_resample_fwd),
       TPGSR_REG(tpgsr_strip_resample_bwd), TPGSR_REG(tpgsr_hsum), TPGSR_REG(tpgsr_bicubic_gray_fwd),
       TPGSR_REG(tpgsr_bicubic_gray_bwd), TPGSR_REG(tpgsr_pool2d_fwd), TPGSR_REG(tpgsr_pool2d_bwd),

@@ -360,8 +360,15 @@ class GruLayer:
         eng.register_operand(self.wc_f, self.wc_d)
 
     def fwd(self, N, H, W, x, gi, h, gates=None, **loader):
-        """gi = loader(x) Wc^T + bc; h = BiGRU(gi) (gates: saved for bwd in training plans)"""
+        """gi = loader(x) Wc^T + bc; h = BiGRU(gi) (gates: saved for bwd in training plans).  ONE launch (csrc/gru_proj.hip: the
+        projection goes from the matrix cores into LDS, `gi` is not touched) when the block is that kernel's, else projection + scan;
+        gi: the [P][192] workspace or a callable returning it (only called when it is needed)"""
         g = ConvGeom(N, H, W, self.Cin, 192)
+        pa = K.make_bigru_proj_args(K.make_conv_args(g, x, self.wc_f, None, bias=self.bc, **loader), self.whh, self.bhh, self.axis, h, gates)
+        if K.bigru_proj_supported(pa):
+            K.bigru_proj_fwd(pa)
+            return
+        gi = gi() if callable(gi) else gi
         K.conv_fwd(K.make_conv_args(g, x, self.wc_f, gi, bias=self.bc, **loader))
         K.bigru_fwd(gi, self.whh, self.bhh, N, H, W, self.axis, h, gates)
 
@@ -854,8 +861,8 @@ class TSRNEngine(_EngineBase):
         for i, L in enumerate(self.rrb):
             t = f"r{i}_"
             y1, y2 = ws(t + "y1", P1, Cc), ws(t + "y2", P1, Cc)
-            gi1, h1 = ws(t + "gi1", P1, 192), ws(t + "h1", P1, Cc)
-            gi2, out = ws(t + "gi2", P1, 192), ws(t + "out", P1, Cc)
+            h1, out = ws(t + "h1", P1, Cc), ws(t + "out", P1, Cc)
+            gi1, gi2 = (lambda t=t: ws(t + "gi1", P1, 192)), (lambda t=t: ws(t + "gi2", P1, 192))      # only without the one-launch GruBlock
             gt1 = ws(t + "gt1", P1, 256) if training else None      # GRU gate values, kept for back-propagation
             gt2 = ws(t + "gt2", P1, 256) if training else None
             part, _ = L["bn1"].partial(P1)

@@ -1002,6 +1002,23 @@ def bigru_fwd(gi, w_hh, b_hh, N, H, W, axis, h_out, gates=None):
     _launch("tpgsr_bigru_fwd", _p(gi), _p(w_hh), _p(b_hh), N, H, W, axis, _p(h_out), _p(gates))
 
 
+def make_bigru_proj_args(cargs: ConvArgs, w_hh, b_hh, axis, h_out, gates=None) -> "_lib.BigruProjArgs":
+    """cargs: make_conv_args(ConvGeom(N, H, W, Cin, 192), x, Wc, None, bias=bc, **loader) -- the GruBlock's composed input projection"""
+    a = _lib.BigruProjArgs()
+    a.c = cargs
+    a.w_hh, a.b_hh, a.h_out, a.gates, a.axis = _p(w_hh), _p(b_hh), _p(h_out), _p(gates), int(axis)
+    return a
+
+
+def bigru_proj_supported(pargs) -> bool:
+    """does the one-launch GruBlock forward (csrc/gru_proj.hip) take this block under the current arithmetic policy?"""
+    return bool(_lib.load().tpgsr_bigru_proj_supported(C.byref(pargs)))
+
+
+def bigru_proj_fwd(pargs):
+    _launch("tpgsr_bigru_proj_fwd", C.byref(pargs))
+
+
 def bigru_bwd(gates, h_out, dh_out, dh_out2, w_hh, N, H, W, axis, dgi, dgh):
     _launch("tpgsr_bigru_bwd", _p(gates), _p(h_out), _p(dh_out), _p(dh_out2), _p(w_hh), N, H, W, axis, _p(dgi), _p(dgh))
 
