@@ -353,15 +353,17 @@ int tpgsr_bn_bwd_finalize(const float* partial, int nblk, int C, long long count
 int tpgsr_bn_bwd_apply(const float* da, const float* da2, const float* y, long long M, int C, const float* scale,
                        const float* shift, int act, const float* coef, float* dy, void* stream);
 /* ------------------------------------------------------------------------------------------------
- * Consumer-side BatchNorm finalize (round 5; csrc/bn_derive.h).  The reduction of the producing convolution's partial rows that
- * nn.BatchNorm2d's batch statistics (model/tsrn.py:376,380; model/stn_head.py:15; forward) and batch_norm_backward's coefficients
- * (backward) need is done by the FIRST CONSUMER of the BatchNorm's output in its own prologue -- every workgroup sums the L2-resident
- * rows in a fixed order, workgroup 0 publishes the result for the launches that follow -- instead of by a launch of its own
- * (tpgsr_bn_finalize / tpgsr_bn_bwd_finalize stay for consumers without the prologue).  C: a power of two, 8 <= C <= 512.
+ * BatchNorm finalize inside the launch that consumes it (round 5; csrc/bn_derive.h).  The reduction of the producing convolution's
+ * partial rows that nn.BatchNorm2d's batch statistics (model/tsrn.py:376,380; model/stn_head.py:15; forward) and batch_norm_backward's
+ * coefficients (backward) need is done by the FIRST CONSUMER's launch instead of a launch of its own: the first ceil(C / 16) workgroups
+ * of its grid each sum the rows of 16 channels (fp64, fixed order), publish by write-through stores and arrive on `flag`; every workgroup
+ * waits for the flag (its first loads already in flight) and reads the published values with L1-bypassing loads.  A wait that never ends
+ * poisons the outputs with NaN.  tpgsr_bn_finalize / tpgsr_bn_bwd_finalize stay for consumers without the prologue.
+ * C: 8, or a multiple of 16 up to 512; the grid must have at least ceil(C / 16) workgroups (M C >= 1024 ceil(C / 16)).
  *   forward  (tpgsr_affine_act_bnd, tpgsr_affine_act_pool_bnd): reads rows / count / bias / gamma / beta, writes scale / shift
  *            (+ save_mean / save_rstd / running statistics when set) exactly as tpgsr_bn_finalize does
  *   backward (tpgsr_bn_bwd_apply_bnd): reads rows ([.][0][c] = sum dz, [.][1][c] = sum dz * xhat) / count / gamma / save_mean /
- *            save_rstd, writes coef (when set) and dgamma / dbeta (+= when accumulate) exactly as tpgsr_bn_bwd_finalize does
+ *            save_rstd, writes coef and dgamma / dbeta (+= when accumulate) exactly as tpgsr_bn_bwd_finalize does
  * ---------------------------------------------------------------------------------------------- */
 typedef struct tpgsr_bn_derive {
   const float* rows;      /* [nrows][2][C] */
@@ -382,6 +384,8 @@ typedef struct tpgsr_bn_derive {
   float* coef;            /* backward, optional out [3][C] */
   int accumulate;         /* backward: 1 = add to dgamma / dbeta */
   int reserved;
+  unsigned* flag;         /* one word of device memory, ZERO when the launch starts (tpgsr_zero earlier on the stream): the arrival counter
+                             of the launch's deriver workgroups; the launch leaves ceil(C / 16) in it */
 } tpgsr_bn_derive;
 /* tpgsr_affine_act with the BatchNorm finalized in the launch: out = act(scale[c] * x + shift[c]) */
 int tpgsr_affine_act_bnd(const tpgsr_bn_derive* d, const float* x, long long M, int act, float* out, void* stream);

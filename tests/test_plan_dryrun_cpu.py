@@ -127,10 +127,12 @@ def test_record_all_plans_without_gpu():
     # ... + the tail's mish backward (an epilogue without sums) + InfoGen bn0..bn2 + bn6 (BiLSTM projection's data gradient)
     assert res["c3"][2].get("conv_fwd+bnb", 0) == 11 + 1 + 3 + 3, res["c3"][2]
     assert res["c2"][2].get("conv_fwd+bnb", 0) == 11 + 1
-    n_apply = res["c3"][2].get("tpgsr_bn_bwd_apply_bnd", 0) + res["c3"][2].get("tpgsr_bn_bwd_apply", 0)
-    assert res["c3"][2].get("tpgsr_bn_bwd_reduce", 0) == n_apply - 17
-    # (round 5's consumer-side finalize, csrc/bn_derive.h, is off by default: every backward BatchNorm still has its finalize launch)
-    assert res["c3"][2].get("tpgsr_bn_bwd_finalize", 0) == n_apply and res["c3"][2].get("tpgsr_affine_act_bnd", 0) == 0
+    nm = res["c3"][2]
+    n_apply = nm.get("tpgsr_bn_bwd_apply_bnd", 0) + nm.get("tpgsr_bn_bwd_apply", 0)
+    assert nm.get("tpgsr_bn_bwd_reduce", 0) == n_apply - 17
+    # (round 5's in-launch finalize, csrc/bn_derive.h, is off by default -- measured slower inside the step: every BatchNorm keeps its
+    #  finalize launch; tests/test_bn_derive_gpu.py runs the switched-on plans)
+    assert nm.get("tpgsr_bn_bwd_finalize", 0) == n_apply and nm.get("tpgsr_affine_act_bnd", 0) == 0
     assert res["c3"][2].get("tpgsr_act_bwd", 0) == 0
     # the text-prior generator's backward pass is two plans: the first forks and never joins, the second ends with THE join; everything
     # from conv3 on (offset 370176 of 8331304 floats) is final in between

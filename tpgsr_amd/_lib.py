@@ -84,7 +84,7 @@ class BnDerive(C.Structure):
     """tpgsr_bn_derive: a BatchNorm finalized inside its first consumer's launch (csrc/bn_derive.h)"""
     _fields_ = [("rows", vp), ("nrows", ci), ("C", ci), ("count", ll), ("bias", vp), ("gamma", vp), ("beta", vp),
                 ("running_mean", vp), ("running_var", vp), ("momentum", cf), ("eps", cf), ("scale", vp), ("shift", vp),
-                ("save_mean", vp), ("save_rstd", vp), ("dgamma", vp), ("dbeta", vp), ("coef", vp), ("accumulate", ci), ("reserved", ci)]
+                ("save_mean", vp), ("save_rstd", vp), ("dgamma", vp), ("dbeta", vp), ("coef", vp), ("accumulate", ci), ("reserved", ci), ("flag", vp)]
 
 
 class PlanArg(C.Union):

@@ -298,123 +298,112 @@ extern "C" int tpgsr_affine_act(const float* x, long long M, int C, const float*
   TPGSR_LAUNCH_CHECK("tpgsr_affine_act");
 }
 
-// ---- the same with the BatchNorm finalized by the launch itself (bn_derive.h): ONE 1024-thread workgroup per CU (the derive is paid
-// once per CU, by 16 waves), grid-stride loops with two independent iterations in flight, scale / shift out of LDS ----
-#define BND_NT 1024
+// ---- the same with the BatchNorm finalized by the launch itself (bn_derive.h): the grid's first ceil(C / 16) workgroups derive and
+// publish, everybody waits on the flag with its first loads already in flight, scale / shift out of LDS ----
 #define BND_LDS_DECL                                              \
-  __shared__ double bnd_scr[4 * BND_NT];                          \
-  __shared__ double bnd_sums[2 * 512];                            \
+  __shared__ double bnd_scr[32 * 32];                             \
+  __shared__ double bnd_sums[32];                                 \
   __shared__ __attribute__((aligned(16))) float bnd_a[512], bnd_b[512]
 
-static int bnd_check(const tpgsr_bn_derive* d, const char* who, bool fwd) {
-  TPGSR_CHECK_ARG(d && d->rows && d->nrows > 0 && d->count > 0 && d->gamma, "%s: incomplete BatchNorm descriptor", who);
-  TPGSR_CHECK_ARG(bnd_shape_ok(d->C, BND_NT) && d->C <= 512, "%s: channel count %d not supported by the in-launch finalize (a power of two, 8..512)", who, d->C);
+static int bnd_check(const tpgsr_bn_derive* d, const char* who, bool fwd, long long grid) {
+  TPGSR_CHECK_ARG(d && d->rows && d->nrows > 0 && d->count > 0 && d->gamma && d->flag, "%s: incomplete BatchNorm descriptor (rows, count, gamma, flag)", who);
+  TPGSR_CHECK_ARG(bnd_shape_ok(d->C), "%s: channel count %d not supported by the in-launch finalize (a multiple of 16 up to 512, or 8)", who, d->C);
   TPGSR_CHECK_ARG((((uintptr_t)d->rows) & 15) == 0, "%s: partial rows must be 16-byte aligned", who);
+  TPGSR_CHECK_ARG(grid >= bnd_derivers(d->C), "%s: the launch has %lld workgroups, the finalize needs %d derivers", who, grid, bnd_derivers(d->C));
   if (fwd) TPGSR_CHECK_ARG(d->beta && d->scale && d->shift && (!d->running_mean == !d->running_var), "%s: forward descriptor needs beta / scale / shift", who);
-  else TPGSR_CHECK_ARG(d->save_mean && d->save_rstd, "%s: backward descriptor needs the saved statistics", who);
+  else TPGSR_CHECK_ARG(d->save_mean && d->save_rstd && d->coef, "%s: backward descriptor needs the saved statistics and coef", who);
   return 0;
 }
 
-// workgroups of a launch that pays a per-workgroup prologue: one per CU, never more than there is work
-static int bnd_grid(long long items) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-    cus = n;
-  }
-  return (int)max(1ll, min((long long)cus, (items + BND_NT - 1) / BND_NT));
-}
-
-__global__ __launch_bounds__(BND_NT) void affine_act_bnd_kernel(const tpgsr_bn_derive d, const float* __restrict__ x, long long total4,
-                                                                int act, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void affine_act_bnd_kernel(const tpgsr_bn_derive d, const float* __restrict__ x, long long total4,
+                                                             int act, float* __restrict__ out) {
   BND_LDS_DECL;
-  bnd_forward(d, threadIdx.x, BND_NT, blockIdx.x == 0, bnd_scr, bnd_sums, bnd_a, bnd_b);
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float4 v = i < total4 ? ld4(x + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);      // in flight while the BatchNorm is being finalized
+  bnd_forward(d, threadIdx.x, bnd_scr, bnd_sums, bnd_a, bnd_b);
   const int C4 = d.C >> 2;
-  const long long stride = (long long)gridDim.x * BND_NT;
-  for (long long i = (long long)blockIdx.x * BND_NT + threadIdx.x; i < total4; i += 2 * stride) {
-    const long long i1 = i + stride;
-    const bool ok1 = i1 < total4;
-    float4 v0 = ld4(x + i * 4), v1 = ld4(x + (ok1 ? i1 : i) * 4);
-    const int c0 = (int)(i % C4) * 4, c1 = (int)((ok1 ? i1 : i) % C4) * 4;
-    const float4 s0 = *reinterpret_cast<const float4*>(bnd_a + c0), t0 = *reinterpret_cast<const float4*>(bnd_b + c0);
-    const float4 s1 = *reinterpret_cast<const float4*>(bnd_a + c1), t1 = *reinterpret_cast<const float4*>(bnd_b + c1);
-    v0.x = apply_act(v0.x * s0.x + t0.x, act); v0.y = apply_act(v0.y * s0.y + t0.y, act);
-    v0.z = apply_act(v0.z * s0.z + t0.z, act); v0.w = apply_act(v0.w * s0.w + t0.w, act);
-    v1.x = apply_act(v1.x * s1.x + t1.x, act); v1.y = apply_act(v1.y * s1.y + t1.y, act);
-    v1.z = apply_act(v1.z * s1.z + t1.z, act); v1.w = apply_act(v1.w * s1.w + t1.w, act);
-    *reinterpret_cast<float4*>(out + i * 4) = v0;
-    if (ok1) *reinterpret_cast<float4*>(out + i1 * 4) = v1;
+  while (i < total4) {
+    const long long nx = i + stride;
+    const float4 vn = nx < total4 ? ld4(x + nx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = (int)(i % C4) * 4;
+    const float4 s = *reinterpret_cast<const float4*>(bnd_a + c), t = *reinterpret_cast<const float4*>(bnd_b + c);
+    v.x = apply_act(v.x * s.x + t.x, act); v.y = apply_act(v.y * s.y + t.y, act);
+    v.z = apply_act(v.z * s.z + t.z, act); v.w = apply_act(v.w * s.w + t.w, act);
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+    v = vn;
+    i = nx;
   }
 }
 
 extern "C" int tpgsr_affine_act_bnd(const tpgsr_bn_derive* d, const float* x, long long M, int act, float* out, void* stream) {
-  if (int rc = bnd_check(d, "tpgsr_affine_act_bnd", true)) return rc;
-  TPGSR_CHECK_ARG(x && out && M > 0, "tpgsr_affine_act_bnd: bad arguments");
+  TPGSR_CHECK_ARG(d && x && out && M > 0, "tpgsr_affine_act_bnd: bad arguments");
   const long long total4 = M * d->C / 4;
-  hipLaunchKernelGGL(affine_act_bnd_kernel, dim3(bnd_grid(total4)), dim3(BND_NT), 0, (hipStream_t)stream, *d, x, total4, act, out);
+  const int grid = (int)min((long long)8192, (total4 + 255) / 256);
+  if (int rc = bnd_check(d, "tpgsr_affine_act_bnd", true, grid)) return rc;
+  hipLaunchKernelGGL(affine_act_bnd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, x, total4, act, out);
   TPGSR_LAUNCH_CHECK("tpgsr_affine_act_bnd");
 }
 
-__device__ __forceinline__ float4 bnd_bwd_elem(float4 g, const float4 g2, const bool has2, const float4 yv, const float* __restrict__ scale,
-                                               const float* __restrict__ shift, const int act, const float* __restrict__ coef, const int C,
-                                               const int c) {
-  if (has2) {
-    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
-  }
-  if (act) {
-    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
-    g.x *= act_grad(yv.x * sc.x + sh.x, act);
-    g.y *= act_grad(yv.y * sc.y + sh.y, act);
-    g.z *= act_grad(yv.z * sc.z + sh.z, act);
-    g.w *= act_grad(yv.w * sc.w + sh.w, act);
-  }
-  const float4 c0 = *reinterpret_cast<const float4*>(coef + c), c1 = *reinterpret_cast<const float4*>(coef + C + c),
-               c2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
-  float4 o;
-  o.x = c0.x * g.x + c1.x * yv.x + c2.x;
-  o.y = c0.y * g.y + c1.y * yv.y + c2.y;
-  o.z = c0.z * g.z + c1.z * yv.z + c2.z;
-  o.w = c0.w * g.w + c1.w * yv.w + c2.w;
-  return o;
-}
-
-__global__ __launch_bounds__(BND_NT) void bn_bwd_apply_bnd_kernel(const tpgsr_bn_derive d, const float* __restrict__ da,
-                                                                  const float* __restrict__ da2, const float* __restrict__ y,
-                                                                  long long total4, const float* __restrict__ scale,
-                                                                  const float* __restrict__ shift, int act, float* __restrict__ dy) {
-  __shared__ double bnd_scr[4 * BND_NT];
-  __shared__ double bnd_sums[2 * 512];
+__global__ __launch_bounds__(256) void bn_bwd_apply_bnd_kernel(const tpgsr_bn_derive d, const float* __restrict__ da,
+                                                               const float* __restrict__ da2, const float* __restrict__ y,
+                                                               long long total4, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int act, float* __restrict__ dy) {
+  __shared__ double bnd_scr[32 * 32];
+  __shared__ double bnd_sums[32];
   __shared__ __attribute__((aligned(16))) float coef[3 * 512];
-  bnd_backward(d, threadIdx.x, BND_NT, blockIdx.x == 0, bnd_scr, bnd_sums, coef);
   const int C = d.C, C4 = C >> 2;
-  const long long stride = (long long)gridDim.x * BND_NT;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool has2 = da2 != nullptr;
-  for (long long i = (long long)blockIdx.x * BND_NT + threadIdx.x; i < total4; i += 2 * stride) {
-    const long long i1 = i + stride;
-    const bool ok1 = i1 < total4;
-    const long long j1 = ok1 ? i1 : i;
-    const float4 g0 = ld4(da + i * 4), g1 = ld4(da + j1 * 4);
-    const float4 y0 = ld4(y + i * 4), y1 = ld4(y + j1 * 4);
-    float4 h0 = g0, h1 = g1;
-    if (has2) {
-      h0 = ld4(da2 + i * 4);
-      h1 = ld4(da2 + j1 * 4);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 g = zero, g2 = zero, yv = zero;
+  if (i < total4) {      // in flight while the coefficients are being derived
+    g = ld4(da + i * 4);
+    yv = ld4(y + i * 4);
+    if (has2) g2 = ld4(da2 + i * 4);
+  }
+  bnd_backward(d, threadIdx.x, bnd_scr, bnd_sums, coef);
+  while (i < total4) {
+    const long long nx = i + stride;
+    float4 gn = zero, g2n = zero, yn = zero;
+    if (nx < total4) {
+      gn = ld4(da + nx * 4);
+      yn = ld4(y + nx * 4);
+      if (has2) g2n = ld4(da2 + nx * 4);
     }
-    const float4 o0 = bnd_bwd_elem(g0, h0, has2, y0, scale, shift, act, coef, C, (int)(i % C4) * 4);
-    const float4 o1 = bnd_bwd_elem(g1, h1, has2, y1, scale, shift, act, coef, C, (int)(j1 % C4) * 4);
-    *reinterpret_cast<float4*>(dy + i * 4) = o0;
-    if (ok1) *reinterpret_cast<float4*>(dy + i1 * 4) = o1;
+    const int c = (int)(i % C4) * 4;
+    if (has2) {
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+    }
+    if (act) {
+      const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+      g.x *= act_grad(yv.x * sc.x + sh.x, act);
+      g.y *= act_grad(yv.y * sc.y + sh.y, act);
+      g.z *= act_grad(yv.z * sc.z + sh.z, act);
+      g.w *= act_grad(yv.w * sc.w + sh.w, act);
+    }
+    const float4 c0 = *reinterpret_cast<const float4*>(coef + c), c1 = *reinterpret_cast<const float4*>(coef + C + c),
+                 c2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    float4 o;
+    o.x = c0.x * g.x + c1.x * yv.x + c2.x;
+    o.y = c0.y * g.y + c1.y * yv.y + c2.y;
+    o.z = c0.z * g.z + c1.z * yv.z + c2.z;
+    o.w = c0.w * g.w + c1.w * yv.w + c2.w;
+    *reinterpret_cast<float4*>(dy + i * 4) = o;
+    g = gn; g2 = g2n; yv = yn;
+    i = nx;
   }
 }
 
 extern "C" int tpgsr_bn_bwd_apply_bnd(const tpgsr_bn_derive* d, const float* da, const float* da2, const float* y, long long M,
                                       const float* scale, const float* shift, int act, float* dy, void* stream) {
-  if (int rc = bnd_check(d, "tpgsr_bn_bwd_apply_bnd", false)) return rc;
-  TPGSR_CHECK_ARG(da && y && dy && M > 0, "tpgsr_bn_bwd_apply_bnd: bad arguments");
+  TPGSR_CHECK_ARG(d && da && y && dy && M > 0, "tpgsr_bn_bwd_apply_bnd: bad arguments");
   TPGSR_CHECK_ARG(!act || (scale && shift), "tpgsr_bn_bwd_apply_bnd: activation needs scale/shift");
   const long long total4 = M * d->C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_bnd_kernel, dim3(bnd_grid(total4)), dim3(BND_NT), 0, (hipStream_t)stream, *d, da, da2, y, total4, scale,
+  const int grid = (int)min((long long)4096, (total4 + 255) / 256);
+  if (int rc = bnd_check(d, "tpgsr_bn_bwd_apply_bnd", false, grid)) return rc;
+  hipLaunchKernelGGL(bn_bwd_apply_bnd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, da, da2, y, total4, scale,
                      shift, act, dy);
   TPGSR_LAUNCH_CHECK("tpgsr_bn_bwd_apply_bnd");
 }
@@ -457,13 +446,13 @@ extern "C" int tpgsr_affine_act_pool(const float* x, int N, int H, int W, int C,
   TPGSR_LAUNCH_CHECK("tpgsr_affine_act_pool");
 }
 
-__global__ __launch_bounds__(BND_NT) void affine_act_pool_bnd_kernel(const tpgsr_bn_derive d, const float* __restrict__ x, int N, int H, int W,
+__global__ __launch_bounds__(256) void affine_act_pool_bnd_kernel(const tpgsr_bn_derive d, const float* __restrict__ x, int N, int H, int W,
                                                                   int act, int ph, int pw, float* __restrict__ out) {
   BND_LDS_DECL;
-  bnd_forward(d, threadIdx.x, BND_NT, blockIdx.x == 0, bnd_scr, bnd_sums, bnd_a, bnd_b);
+  bnd_forward(d, threadIdx.x, bnd_scr, bnd_sums, bnd_a, bnd_b);
   const int C = d.C, OH = H / ph, OW = W / pw;
   const long long total = (long long)N * OH * OW * C;
-  for (long long i = (long long)blockIdx.x * BND_NT + threadIdx.x; i < total; i += (long long)gridDim.x * BND_NT) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C);
     long long p = i / C;
     const int ow = (int)(p % OW);
@@ -484,10 +473,11 @@ __global__ __launch_bounds__(BND_NT) void affine_act_pool_bnd_kernel(const tpgsr
 
 extern "C" int tpgsr_affine_act_pool_bnd(const tpgsr_bn_derive* d, const float* x, int N, int H, int W, int act, int pool_h, int pool_w,
                                          float* out, void* stream) {
-  if (int rc = bnd_check(d, "tpgsr_affine_act_pool_bnd", true)) return rc;
-  TPGSR_CHECK_ARG(x && out && pool_h >= 1 && pool_w >= 1 && H >= pool_h && W >= pool_w, "tpgsr_affine_act_pool_bnd: bad arguments");
+  TPGSR_CHECK_ARG(d && x && out && pool_h >= 1 && pool_w >= 1 && H >= pool_h && W >= pool_w, "tpgsr_affine_act_pool_bnd: bad arguments");
   const long long total = (long long)N * (H / pool_h) * (W / pool_w) * d->C;
-  hipLaunchKernelGGL(affine_act_pool_bnd_kernel, dim3(bnd_grid(total)), dim3(BND_NT), 0, (hipStream_t)stream, *d, x, N, H, W, act, pool_h,
+  const int grid = (int)min((long long)4096, (total + 255) / 256);
+  if (int rc = bnd_check(d, "tpgsr_affine_act_pool_bnd", true, grid)) return rc;
+  hipLaunchKernelGGL(affine_act_pool_bnd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, x, N, H, W, act, pool_h,
                      pool_w, out);
   TPGSR_LAUNCH_CHECK("tpgsr_affine_act_pool_bnd");
 }

@@ -264,7 +264,7 @@ class BNLayer:
         """descriptor (kernels.make_bn_derive) for the FIRST consumer of this training-mode BatchNorm's output: that launch reduces the
         producing convolution's partial rows itself (csrc/bn_derive.h) and finalize() is NOT recorded; None when the channel count is
         outside the prologue's range or the switch is off (then: finalize() + the plain consumer)"""
-        if not K.bn_derive_ok(self.C):
+        if not K.bn_derive_ok(self.C, M):
             return None
         part, _ = self.partial(M)
         return K.make_bn_derive(part, K.bn_rows(M, row_tiles), self.C, M, self.gamma, bias=conv_bias, beta=self.beta, running_mean=self.rm,
@@ -312,7 +312,7 @@ class BNLayer:
             nblk = min(1024, max(1, M // 64))
             part = eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
             K.bn_bwd_reduce(da, da2, y, M, self.C, self.scale, self.shift, self.save_mean, self.save_rstd, act, part, nblk)
-        if K.bn_derive_ok(self.C):      # coefficients + dgamma / dbeta derived by the apply launch itself: one launch instead of two
+        if K.bn_derive_ok(self.C, M):      # coefficients + dgamma / dbeta derived by the apply launch itself: one launch instead of two
             d = K.make_bn_derive(part, nblk, self.C, M, self.gamma, save_mean=self.save_mean, save_rstd=self.save_rstd,
                                  dgamma=eng.G[self.prefix + ".weight"], dbeta=eng.G[self.prefix + ".bias"], coef=self.coef, accumulate=True)
             K.bn_bwd_apply_bnd(d, da, da2, y, M, self.scale, self.shift, act, dy)

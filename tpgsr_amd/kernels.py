@@ -918,28 +918,53 @@ def bn_bwd_apply(da, da2, y, M, C_, scale, shift, act, coef, dy):
 
 
 # BatchNorm finalized inside its first consumer's launch (csrc/bn_derive.h, round 5) instead of by tpgsr_bn_finalize / tpgsr_bn_bwd_finalize
-# launches of their own: every workgroup of the consumer (ONE 1024-thread workgroup per CU) sums the partial rows in its prologue.
-# OFF by default -- measured (profiles/r05e_bn_derive_ab.md): alone on the chip the fused launches WIN clearly (finalize + mish 19.0 us ->
-# 14.3 at 768 rows / 10.6 at 256; finalize + apply 19.5 -> 14.6 / 12.2), inside the three-stream train step they LOSE (C3 6.09 vs 5.93 ms):
-# a 1024-thread workgroup with 44 KB of LDS needs sixteen free wave slots on ONE CU and waits for the weight-gradient stream's
-# workgroups to drain (25 us per launch in the step's trace against 14.5 for the pair), where the 256-thread launches it replaces slot in
-# anywhere; with 256-thread workgroups the redundant row sums cost more than the launch they save (6.34 vs 6.06 ms).  What stays on:
-# the COARSER ROWS the whole-CU kernel leaves for whoever reduces them (bn_row_tiles, below).  TPGSR_BN_DERIVE=1 switches it on.
+# launches of their own: the first ceil(C / 16) workgroups of the consumer's grid sum the partial rows and publish, everybody waits on a
+# flag.  OFF by default: three forms of "no finalize launch" were built and measured against the separate launches inside the C3 step
+# (profiles/r05e_bn_derive_ab.md) -- every workgroup summing the rows itself (256-thread workgroups: 6.34 vs 6.06 ms; one 1024-thread
+# workgroup per CU: 6.09 vs 5.93), and this deriver + flag hand-off (6.10 vs 5.99) -- and round 4's last-workgroup finalize before them
+# (6.19 vs 6.08): the separate 64-workgroup launch (3 us + a ~2 us boundary) is the cheapest way this chip has of putting a grid-wide
+# reduction between two launches.  TPGSR_BN_DERIVE=1 records the in-launch form (results agree to the last bit or two of scale / shift).
 BN_DERIVE = os.environ.get("TPGSR_BN_DERIVE", "0") == "1"
 
 
-def bn_derive_ok(C_: int) -> bool:
-    return BN_DERIVE and 8 <= C_ <= 512 and (C_ & (C_ - 1)) == 0
+def bn_derive_ok(C_: int, M: int = 1 << 30) -> bool:
+    """can a launch over an [M][C] map finalize its BatchNorm itself?  (channel counts the derivers split evenly; enough workgroups)"""
+    D = (C_ + 15) // 16
+    return BN_DERIVE and (C_ == 8 or (C_ % 16 == 0 and 16 <= C_ <= 512)) and M * C_ >= 1024 * D
 
 
-def make_bn_derive(rows, nrows, C_, count, gamma, *, bias=None, beta=None, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
-                   scale=None, shift=None, save_mean=None, save_rstd=None, dgamma=None, dbeta=None, coef=None, accumulate=False):
+def plan_flag(device):
+    """one int32 word, zero when the launch that uses it starts: a fresh tensor for a direct call; inside a recorded plan a slot of the
+    plan's flag block, which the plan zeroes with ONE launch at its very start (inserted here when the first flag is asked for)"""
+    rec = _REC
+    if rec is None:
+        return torch.zeros(1, dtype=torch.int32, device=device)
+    if getattr(rec, "flags", None) is None:
+        rec.flags, rec.nflags = torch.zeros(128, dtype=torch.int32, device=device), 0
+        rec.keep.append(rec.flags)
+        rec.ops.insert(0, ["tpgsr_zero", getattr(_lib.load(), "tpgsr_zero"), [rec.flags.data_ptr(), 128], 0])
+        rec.dyn = {k: [(oi + 1, ai) for oi, ai in v] for k, v in rec.dyn.items()}      # every recorded op moved down by one
+        rec.meta = {oi + 1: v for oi, v in rec.meta.items()}
+    if rec.nflags >= rec.flags.numel():
+        raise RuntimeError("a recorded plan finalizes more than 128 BatchNorms inside their consumers")
+    rec.nflags += 1
+    return rec.flags[rec.nflags - 1:rec.nflags]
+
+
+def make_bn_derive(rows, nrows, C_, count, gamma, *, flag=None, bias=None, beta=None, running_mean=None, running_var=None, momentum=0.1,
+                   eps=1e-5, scale=None, shift=None, save_mean=None, save_rstd=None, dgamma=None, dbeta=None, coef=None, accumulate=False):
+    """flag: one zeroed int32 word (default: plan_flag -- a slot of the recorded plan's block, or a fresh tensor for a direct call, which
+    then serves ONE launch)"""
     d = _lib.BnDerive()
+    if flag is None:
+        flag = plan_flag(rows.device if isinstance(rows, torch.Tensor) else None)
+    d._flag_keep = flag
     d.rows, d.nrows, d.C, d.count = _p(rows), int(nrows), int(C_), int(count)
     d.bias, d.gamma, d.beta = _p(bias), _p(gamma), _p(beta)
     d.running_mean, d.running_var, d.momentum, d.eps = _p(running_mean), _p(running_var), momentum, eps
     d.scale, d.shift, d.save_mean, d.save_rstd = _p(scale), _p(shift), _p(save_mean), _p(save_rstd)
     d.dgamma, d.dbeta, d.coef, d.accumulate = _p(dgamma), _p(dbeta), _p(coef), int(bool(accumulate))
+    d.flag = _p(flag)
     return d
 
 
