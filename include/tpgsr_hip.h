@@ -227,6 +227,8 @@ int tpgsr_pack_tail_weight(const float* w, int Co, int C, int KS, float* wt_f, f
  *           Wc[g][ci] = sum_u src[g][u] * src2[u][ci]  (src = weight_ih [Cout=96][KH=64 hidden-of-conv], src2 = conv1
  *           weight [64][Cin]) -> dst_f[ci*f_ld + f_coff + g] and dst_d[(f_coff + g)*Cin + ci]; numel = Cout*Cin
  *   kind 6: its bias: dst_f[f_coff + g] = sum_u src[g][u] * src2[u] + src3[g]  (src2 = conv1 bias, src3 = bias_ih)
+ *   kind 7: DATA-GRADIENT operand of a KS x KS convolution [Cout][Cin][KS][KS] with few input channels, folded like the tail:
+ *           dst_f[(kh' Cout + c)][kw' Cin + ci] = src[c][ci][KS-1-kh'][KS-1-kw'] (a KS x 1 convolution over dy + tpgsr_shiftsum_nhwc)
  * blk0 = prefix sum of tpgsr_pack_blocks(...) over the preceding descriptors (ceil(numel / 256), except kind 0 with <= 9 taps and Cout * Cin >= 65536,
  * which is packed in 32 x 32-channel tiles through LDS: ceil(Cout / 32) * ceil(Cin / 32) workgroups); total_blocks = the full sum. */
 typedef struct {
@@ -566,6 +568,11 @@ int tpgsr_lstm_stepx_fwd(float* G, const void* wfr, const float* bhh, float* Cst
 int tpgsr_lstm_seq_fwd(float* G, const float* whhT, const float* bhh, float* Cst, float* out, void* hx, unsigned* sync, int N, int T,
                        int Hh, void* stream);
 long long tpgsr_lstm_seq_hx_bytes(void);
+/* Can the persistent BiLSTM launches (tpgsr_lstm_seq_*) run here?  They need their 2 x 32 workgroups resident TOGETHER; this launches
+ * 64 workgroups with the larger kernel's footprint that wait for each other for at most ~50 ms.  1: yes; 0: no (record the per-step
+ * launches tpgsr_lstm_rec_gemm + tpgsr_lstm_step_* instead: a timed-out hand-off would poison the step with NaN); < 0: error.
+ * Synchronises `stream`.  words: 2 u32 of device memory. */
+int tpgsr_lstm_seq_probe(unsigned* words, void* stream);
 /* The same forward recurrence with a DATA-TAGGED hand-off (8-byte {three bf16 terms of h, tag} granules, no counter, no wait for the
  * stores; csrc/lstm_seq.hip).  hg: tpgsr_lstm_seq_hg_bytes() bytes and sync: 8 x u32, both ZEROED ONCE by the caller and then owned by
  * these launches (the launch epoch lives in sync[4..5]); T <= 31.  sync[2] != 0: a hand-off timed out. */
@@ -622,6 +629,9 @@ int tpgsr_hbroadcast(const float* dout, int N, int H, int W, int C, float scale,
  * ---------------------------------------------------------------------------------------------- */
 int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,
                              float* out_nchw, void* stream);
+/* out [N][H][W][Co] = sum_kw P[n][h][w+kw-KS/2][kw*Co+co]: the same column-group sum without bias / tanh into an NHWC map -- the
+ * second half of block1's data gradient (model/tsrn.py:28, 64 -> 4 over 9 x 9 taps) run as a 9 x 1 convolution with 36 columns */
+int tpgsr_shiftsum_nhwc(const float* P, int N, int H, int W, int Co, int KS, float* out, void* stream);
 /* dP[h][x][kw][co] = dpre[h][x-kw+4][co], dpre = dout*(1-out^2); also bias-grad partials */
 int tpgsr_tail_bwd(const float* out_nchw, const float* dout_nchw, int N, int H, int W, int Co, int KS,
                    float* dP, float* dbias_partial /* optional [nblk][Co] */, int nblk, void* stream);

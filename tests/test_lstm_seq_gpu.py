@@ -209,3 +209,35 @@ def test_lstm_seq_granule_handoff_equals_counter_handoff():
         assert int(bsync[2].item()) == 0 and int(bgsync[2].item()) == 0, "a backward hand-off timed out"
         assert int(bgsync[4].item()) == rep + 1 and int(bgsync[5].item()) == rep + 1
         assert torch.equal(Ga, Gb), (rep, N, T)
+
+
+def test_coresidency_probe_and_the_automatic_fall_back(monkeypatch):
+    """the persistent kernels need their 64 workgroups resident together.  On this (idle, whole) MI355X the probe says
+    yes; when it says no -- forced here -- the text-prior generator records the per-step recurrence (no persistent launch in its plans)
+    and a training forward + backward gives the same logits and gradients instead of a NaN step."""
+    import warnings
+    from oracle import tpgsr_oracle as O
+    from tpgsr_amd import kernels as K
+    from tpgsr_amd.model.crnn import crnn
+    K._LSTM_CORESIDENT.clear()
+    assert K.lstm_seq_coresident(torch.device("cuda", 0)) is True
+    gray = torch.rand(6, 1, 32, 100, generator=torch.Generator().manual_seed(3)).to(DEV)
+    dl = torch.randn(26, 6, 37, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for ok in (True, False):
+        monkeypatch.setitem(K._LSTM_CORESIDENT, str(torch.device("cuda", 0)), ok)
+        monkeypatch.setitem(K._LSTM_CORESIDENT, "cuda:0", ok)
+        m = crnn.CRNN(32, 1, 37, 256)
+        m.load_state_dict(O.recipe_state_dict(O.crnn_spec(), 5))
+        m = m.to(DEV).train()
+        y = m(gray)
+        (y * dl).sum().backward()
+        torch.cuda.synchronize()
+        names = [op[0] for pl in m._engine()._plans.values() for k in pl if hasattr(pl[k], "ops") for op in pl[k].ops]
+        n_seq = sum(n.startswith("tpgsr_lstm_seq") for n in names)
+        assert (n_seq > 0) == ok and (("tpgsr_lstm_step_fwd" in names) != ok)
+        res.append((y.detach().clone(), m._engine().arena.grad.clone()))
+    (y0, g0), (y1, g1) = res
+    assert torch.isfinite(y1).all() and torch.isfinite(g1).all()
+    assert (y0 - y1).abs().max() <= 1e-5 * y0.abs().max()
+    assert (g0 - g1).norm() <= 1e-4 * g0.norm()

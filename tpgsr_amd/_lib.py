@@ -174,6 +174,7 @@ _SIGS = {
     "tpgsr_lstm_step_fwd": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_hx_bytes": (C.c_longlong, []),
+    "tpgsr_lstm_seq_probe": (ci, [vp, vp]),
     "tpgsr_lstm_seq_fwdg": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "tpgsr_lstm_seq_hg_bytes": (C.c_longlong, []),
     "tpgsr_lstm_seq_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
@@ -188,6 +189,7 @@ _SIGS = {
     "tpgsr_semantic_loss_finalize": (ci, [vp, ci, ll, cf, vp, vp]),
     "tpgsr_softmax_prior_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, ci, vp]),
     "tpgsr_tail_shiftsum_tanh": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "tpgsr_shiftsum_nhwc": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_tail_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]),
     "tpgsr_tail_bwd_blocks": (ci, [ci, ci, ci, ci, ci]),
     "tpgsr_image_loss_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),

@@ -1094,6 +1094,16 @@ __global__ __launch_bounds__(256) void pack_program_kernel(const tpgsr_pack_desc
     if (d.dst_d) d.dst_d[((size_t)(d.KH - 1 - kh) * NP + np) * d.Cin + ci] = v;
     return;
   }
+  if (d.kind == 7) {  // folded DATA-GRADIENT operand of a KS x KS convolution with few input channels: src [Cout][Cin][KS][KS]
+    // (block1, model/tsrn.py:28: 4 -> 64, 9 x 9).  dx = conv(dy, flipped taps) run as a KS x 1 convolution over dy's Cout channels with the
+    // KS kw-taps folded into the columns, k = kh' Cout + c, column = kw' Cin + ci, value = w[c][ci][KS-1-kh'][KS-1-kw'];
+    // tpgsr_shiftsum_nhwc adds the KS column groups back up
+    int ci = r % d.Cin;
+    int c = (int)(r / d.Cin);
+    int NP = d.KW * d.Cin;
+    d.dst_f[((size_t)(d.KH - 1 - kh) * d.Cout + c) * NP + (d.KW - 1 - kw) * d.Cin + ci] = v;
+    return;
+  }
   if (d.kind == 4) {  // ConvTranspose2d weight [Cin][Cout][3][3] on an H=1 strip: only the kh=1 row ever meets data
     int co = r % d.Cout;
     int ci = (int)(r / d.Cout);

@@ -36,6 +36,34 @@ extern "C" int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N
   TPGSR_LAUNCH_CHECK("tpgsr_tail_shiftsum_tanh");
 }
 
+// the same sum without bias / tanh into an NHWC map: out[n][h][w][co] = sum_kw P[n][h][w+kw-KS/2][kw*Co+co] -- the second half of a
+// KS x KS convolution with few output channels run as a KS x 1 convolution with the kw taps folded into its columns (block1's data
+// gradient, model/tsrn.py:28: 64 -> 4 over 81 taps: on the matrix cores' 32-column blocks it ran at 2 % of its peak, 115 us)
+__global__ __launch_bounds__(256) void shiftsum_nhwc_kernel(const float* __restrict__ P, int N, int H, int W, int Co, int KS,
+                                                            float* __restrict__ out) {
+  const long long total = (long long)N * H * W * Co;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % Co);
+  const long long pix = i / Co;
+  const int w = (int)(pix % W);
+  const int NP = KS * Co, half = KS / 2;
+  const float* row = P + (size_t)(pix - w) * NP;
+  float s = 0.f;
+  for (int kw = 0; kw < KS; ++kw) {
+    const int x = w + kw - half;
+    if ((unsigned)x < (unsigned)W) s += row[(size_t)x * NP + kw * Co + co];
+  }
+  out[i] = s;
+}
+
+extern "C" int tpgsr_shiftsum_nhwc(const float* P, int N, int H, int W, int Co, int KS, float* out, void* stream) {
+  TPGSR_CHECK_ARG(P && out && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "tpgsr_shiftsum_nhwc: bad arguments");
+  const long long total = (long long)N * H * W * Co;
+  hipLaunchKernelGGL(shiftsum_nhwc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, P, N, H, W, Co, KS, out);
+  TPGSR_LAUNCH_CHECK("tpgsr_shiftsum_nhwc");
+}
+
 // dP[n][h][x][kw*Co+co] = dpre[n][co][h][x-kw+KS/2], dpre = dout*(1-out^2); dbias partial per block
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, int N,
                                                        int H, int W, int Co, int KS, float* __restrict__ dP,

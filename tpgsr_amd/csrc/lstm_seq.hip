@@ -842,3 +842,43 @@ extern "C" int tpgsr_lstm_seq_bwd(float* G, const float* Cst, const float* dout,
                      T);
   TPGSR_LAUNCH_CHECK("tpgsr_lstm_seq_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Co-residency probe (round 5).  Both persistent kernels hand data between their 2 x 32 workgroups every time
+// step: they only make progress when all 64 are RESIDENT TOGETHER.  On an idle MI355X they are (64 workgroups on 256 CUs); on a GPU that
+// is shared with another process, partitioned, or smaller, they may never be -- and a hand-off that times out poisons the step with NaN.
+// The engines therefore ask ONCE per device, when they record their plans: 64 workgroups of 256 threads with the backward kernel's LDS
+// footprint (the larger of the two: one workgroup per CU) arrive on a counter and wait until everybody has, or ~50 ms have passed.
+// Returns 1 (co-resident: record the persistent launches), 0 (not: the engines record the per-step launches instead -- slower, never
+// wrong) or < 0 on error.  Synchronises `stream`; never part of a recorded plan.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_seq_probe_kernel(unsigned* __restrict__ words, long long budget_ticks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char probe_lds[];
+  if (threadIdx.x == 0) {
+    probe_lds[0] = 1;      // (touch the allocation)
+    __hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    bool all = false;
+    while (!(all = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) && wall_clock64() - t0 < budget_ticks)
+      __builtin_amdgcn_s_sleep(8);
+    if (!all) __hip_atomic_store(words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" int tpgsr_lstm_seq_probe(unsigned* words /* 2 u32 of device memory */, void* stream) {
+  TPGSR_CHECK_ARG(words, "tpgsr_lstm_seq_probe: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipFuncSetAttribute((const void*)lstm_seq_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSB_LDS) != hipSuccess ||
+      hipMemsetAsync(words, 0, 2 * sizeof(unsigned), st) != hipSuccess) {
+    tpgsr_set_error("tpgsr_lstm_seq_probe: set-up failed: %s", hipGetErrorString(hipGetLastError()));
+    return TPGSR_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(lstm_seq_probe_kernel, dim3(2 * LS_NW), dim3(256), LSB_LDS, st, words, 5000000ll /* 50 ms of the 100 MHz clock */);
+  unsigned host[2] = {0, 1};
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(host, words, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    tpgsr_set_error("tpgsr_lstm_seq_probe: launch / read-back failed: %s", hipGetErrorString(hipGetLastError()));
+    return TPGSR_ERR_LAUNCH;
+  }
+  return (host[0] == 2u * LS_NW && host[1] == 0u) ? 1 : 0;
+}

@@ -71,7 +71,7 @@ const std::unordered_map<std::string, Entry>& registry() {
       TPGSR_REG(tpgsr_strip_resample_bwd), TPGSR_REG(tpgsr_hsum), TPGSR_REG(tpgsr_bicubic_gray_fwd),
       TPGSR_REG(tpgsr_bicubic_gray_bwd), TPGSR_REG(tpgsr_pool2d_fwd), TPGSR_REG(tpgsr_pool2d_bwd),
       TPGSR_REG(tpgsr_lstm_rec_gemm), TPGSR_REG(tpgsr_lstm_step_fwd), TPGSR_REG(tpgsr_lstm_seq_fwd), TPGSR_REG(tpgsr_lstm_seq_fwdg), TPGSR_REG(tpgsr_lstm_seq_bwd), TPGSR_REG(tpgsr_lstm_seq_bwdg), TPGSR_REG(tpgsr_lstm_wfrag), TPGSR_REG(tpgsr_lstm_stepx_fwd), TPGSR_REG(tpgsr_lstm_step_bwd), TPGSR_REG(tpgsr_softmax_prior_fwd),
-      TPGSR_REG(tpgsr_semantic_loss_finalize), TPGSR_REG(tpgsr_softmax_prior_bwd), TPGSR_REG(tpgsr_tail_shiftsum_tanh),
+      TPGSR_REG(tpgsr_semantic_loss_finalize), TPGSR_REG(tpgsr_softmax_prior_bwd), TPGSR_REG(tpgsr_tail_shiftsum_tanh), TPGSR_REG(tpgsr_shiftsum_nhwc),
       TPGSR_REG(tpgsr_tail_bwd), TPGSR_REG(tpgsr_image_loss_fwd), TPGSR_REG(tpgsr_image_loss_finalize),
       TPGSR_REG(tpgsr_image_loss_bwd), TPGSR_REG(tpgsr_sumsq_partial), TPGSR_REG(tpgsr_clip_coef),
       TPGSR_REG(tpgsr_adam_step), TPGSR_REG(tpgsr_step_inc), TPGSR_REG(tpgsr_scale_),

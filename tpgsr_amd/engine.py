@@ -221,6 +221,28 @@ class ConvLayer:
                            layout=2 if self.tail else 0, accumulate=True, gscale=self.wscale)
 
 
+class FoldedDgrad:
+    """Data gradient of a KS x KS convolution with FEW input channels (block1, model/tsrn.py:28: 4 -> 64 over 9 x 9 taps; the STN head's
+    gradient enters through it, model/tsrn.py:183-186).  As an implicit GEMM it has 4 output columns in a 32-column MFMA block (115 us at
+    2 % of its peak); folded like the tail convolution -- a KS x 1 convolution over dy's channels with the KS kw-taps in the columns
+    (36 of them), then tpgsr_shiftsum_nhwc adds the column groups back up -- it runs on the whole-CU halo kernel like a trunk layer."""
+
+    def __init__(self, eng, wname: str):
+        w = eng.P[wname]
+        self.Cout, self.Ci, self.KS = w.shape[0], w.shape[1], w.shape[2]
+        assert w.shape[2] == w.shape[3] and self.KS % 2 == 1 and (self.KS * self.Ci) % 4 == 0
+        self.NP = self.KS * self.Ci
+        self.wt = torch.empty(self.KS * self.Cout, self.NP, dtype=F32, device=eng.device)
+        eng.add_pack(w, self.wt, None, Cout=self.Cout, Cin=self.Ci, KH=self.KS, KW=self.KS, kind=7)
+        eng.register_operand(self.wt, cins=(self.Cout,))
+
+    def run(self, N, H, W, dy, P, dx):
+        """dx [N][H][W][Ci] from dy [N][H][W][Cout]; P: [N H W][KS Ci] scratch"""
+        g = ConvGeom(N, H, W, self.Cout, self.NP, self.KS, 1, self.KS // 2, 0)
+        K.conv_fwd(K.make_conv_args(g, dy, self.wt, P))
+        K.shiftsum_nhwc(P, N, H, W, self.Ci, self.KS, dx)
+
+
 class BNLayer:
     def __init__(self, eng, prefix: str, pad_to: int = 0):
         self.eng, self.prefix = eng, prefix
@@ -750,7 +772,8 @@ class TSRNEngine(_EngineBase):
         self.srb = m.srb_nums
         self.stn = bool(m.stn)
         self.C = self.P["block1.0.weight"].shape[0]
-        self.block1 = ConvLayer(self, "block1.0.weight", "block1.0.bias", 9, 9, 4, 4, need_dgrad=self.stn)
+        self.block1 = ConvLayer(self, "block1.0.weight", "block1.0.bias", 9, 9, 4, 4, need_dgrad=False)
+        self.block1_dx = FoldedDgrad(self, "block1.0.weight") if self.stn else None      # its data gradient: only the STN head asks for it
         self.tl = hasattr(m, "infoGen")
         self.rrb = []
         for i in range(self.srb):
@@ -1107,7 +1130,7 @@ class TSRNEngine(_EngineBase):
         t = ws.t
         Ci = self.in_planes
         dxr = ws("dxr", N * H * W, Ci)
-        self.block1.dgrad(N, H, W, dc1, dxr)
+        self.block1_dx.run(N, H, W, dc1, ws("stn_Pd", N * H * W, self.block1_dx.NP), dxr)
         dgrid = ws("stn_dgrid", N, H * W, 2)
         K.grid_sample_bwd(t["x_nhwc"], t["stn_grid"], dxr, N, H, W, Ci, H, W, self.grid_align_corners, None, dgrid)
         dctrl = ws("stn_dctrl", N, 2 * self.NC)

@@ -113,7 +113,7 @@ class LstmLayer:
         """x [N][T][Cin] -> G (gates) -> out [N][T][2Hh] -> e = Linear(out) [N][T][nOut]"""
         Hh, G4, P = self.Hh, 4 * self.Hh, self.eng.P
         K.conv_fwd(K.make_conv_args(ConvGeom(N, 1, T, self.Cin, 2 * G4), x, self.wih_f, G, bias=self.bih, **loader))
-        if K.LSTM_SEQ and Hh == 256 and N <= 64:             # the whole recurrence as one persistent launch
+        if K.LSTM_SEQ and Hh == 256 and N <= 64 and K.lstm_seq_coresident(self.eng.device):      # the whole recurrence as one persistent launch
             if not hasattr(self, "_seq"):
                 self._seq = {}
             gran = K.LSTM_GRANULE and T <= 31
@@ -158,7 +158,7 @@ class LstmLayer:
             self.emb.wgrad(N, 1, T, out, de)
         self.emb.dgrad(N, 1, T, de, dout)
         S = G4 // (32 * K.LSTM_BWD_KCHUNKS)                 # K-split of the recurrent gradient GEMM (K = 4 Hh)
-        seq = K.LSTM_SEQ_BWD and Hh == 256 and N <= 64
+        seq = K.LSTM_SEQ_BWD and Hh == 256 and N <= 64 and K.lstm_seq_coresident(self.eng.device)
         if seq:                                              # the whole BPTT recurrence as one persistent launch
             if not hasattr(self, "_seqb"):
                 self._seqb = {}

@@ -1139,6 +1139,30 @@ def lstm_rec_gemm(a0, a1, a_stride, b0, b1, Nrows, Kd, Nc, S, out):
 # TPGSR_LSTM_SEQ=0 records the per-step launches (tpgsr_lstm_rec_gemm + tpgsr_lstm_step_{fwd,bwd}) instead.
 LSTM_SEQ = os.environ.get("TPGSR_LSTM_SEQ", "1") == "1"
 LSTM_SEQ_BWD = os.environ.get("TPGSR_LSTM_SEQ_BWD", "1" if LSTM_SEQ else "0") == "1"
+_LSTM_CORESIDENT = {}
+
+
+def lstm_seq_coresident(device) -> bool:
+    """Can the persistent BiLSTM launches run on `device`?  Asked once per device when an engine records its plans
+    (tpgsr_lstm_seq_probe: 64 workgroups with the backward kernel's footprint must become resident together within ~50 ms).  False --
+    a shared / partitioned / smaller GPU -- makes the engines record the per-step launches instead of a step that ends in NaN.
+    TPGSR_LSTM_SEQ_PROBE=0 skips the question (the persistent form is recorded unconditionally, as before round 5)."""
+    if DRYRUN or os.environ.get("TPGSR_LSTM_SEQ_PROBE", "1") == "0":
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return True                       # (plans are recorded by the eager warm-up steps before a capture; a capture cannot synchronise)
+    key = str(device)
+    if key not in _LSTM_CORESIDENT:
+        words = torch.zeros(2, dtype=torch.int32, device=device)
+        rc = _lib.load().tpgsr_lstm_seq_probe(words.data_ptr(), _stream())
+        if rc < 0:
+            check(rc, "tpgsr_lstm_seq_probe")
+        _LSTM_CORESIDENT[key] = bool(rc)
+        if not rc:
+            import warnings
+            warnings.warn("tpgsr_amd: the persistent BiLSTM kernels' 64 workgroups do not become co-resident on %s (a shared or partitioned GPU?): "
+                          "recording the per-step recurrence instead (slower, never wrong)" % key, RuntimeWarning, stacklevel=2)
+    return _LSTM_CORESIDENT[key]
 # the five weight-gradient GEMMs of a BidirectionalLSTM layer as one launch (tpgsr_conv_wgrad_batch); 0: five launches
 LSTM_WGRAD_BATCH = os.environ.get("TPGSR_LSTM_WGRAD_BATCH", "1") == "1"
 
@@ -1232,6 +1256,10 @@ def softmax_prior_bwd(p, q, dprior, dp_in, N, T, C_, drop_n, wsem, dlogits, nblk
 # ---- tail / loss / optimiser ----------------------------------------------------------------------------------
 def tail_shiftsum_tanh(P, bias, N, H, W, Co, KS, out_nchw):
     _launch("tpgsr_tail_shiftsum_tanh", _p(P), _p(bias), N, H, W, Co, KS, _p(out_nchw))
+
+
+def shiftsum_nhwc(P, N, H, W, Co, KS, out):
+    _launch("tpgsr_shiftsum_nhwc", _p(P), N, H, W, Co, KS, _p(out))
 
 
 def tail_bwd_blocks(N, H, W, Co, KS) -> int:
