@@ -590,7 +590,16 @@ __global__ __launch_bounds__(256) void strip_resample_bwd_kernel(const float* __
   int iw = (int)(r % Win);
   int n = (int)(r / Win);
   float g = 0.f;
-  for (int ow = 0; ow < Wout; ++ow) {
+  // only outputs whose two source columns include iw contribute: sx(ow) = ow (Win-1)/(Wout-1) in [iw - 1, iw + 1).  The loop visits that
+  // window (+ one output either side against rounding) in ascending ow with the forward pass's own strip_src -- the same addends in the
+  // same order as the full 0 .. Wout-1 sweep it replaces (27 us for a 1 MB tensor: Wout dependent loads and divisions per element)
+  int lo = 0, hi = Wout - 1;
+  if (Win > 1 && Wout > 1) {
+    const float inv = (float)(Wout - 1) / (float)(Win - 1);
+    lo = max(0, (int)floorf((float)(iw - 1) * inv) - 1);
+    hi = min(Wout - 1, (int)ceilf((float)(iw + 1) * inv) + 1);
+  }
+  for (int ow = lo; ow <= hi; ++ow) {
     int x0, x1;
     float l;
     strip_src(ow, Win, Wout, x0, x1, l);
@@ -611,22 +620,41 @@ extern "C" int tpgsr_strip_resample_bwd(const float* in, const float* scale, con
   TPGSR_LAUNCH_CHECK("tpgsr_strip_resample_bwd");
 }
 
-__global__ __launch_bounds__(256) void hsum_kernel(const float* __restrict__ d, int N, int H, int W, int C, float* dstrip,
-                                                   int accumulate) {
-  long long total = (long long)N * W * C;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  long long wc = i % ((long long)W * C);
-  int n = (int)(i / ((long long)W * C));
-  float s = 0.f;
-  for (int h = 0; h < H; ++h) s += d[((size_t)n * H + h) * W * C + wc];
-  dstrip[i] = accumulate ? dstrip[i] + s : s;
+// dstrip[n][w][c] (+)= sum_h d[n][h][w][c]: one thread per float4 of a strip row, the H loads issued together (the sum runs h = 0 .. H-1)
+__global__ __launch_bounds__(256) void hsum_kernel(const float* __restrict__ d, int N, int H, int WC4, float* dstrip, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * WC4) return;
+  const int n = i / WC4, wc = i - n * WC4;
+  const float4* src = reinterpret_cast<const float4*>(d) + (size_t)n * H * WC4 + wc;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int h = 0;
+  for (; h + 8 <= H; h += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(h + u) * WC4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+    }
+  }
+  for (; h < H; ++h) {
+    const float4 v = src[(size_t)h * WC4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4* dst = reinterpret_cast<float4*>(dstrip) + i;
+  if (accumulate) {
+    const float4 o = *dst;
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  *dst = s;
 }
 
 extern "C" int tpgsr_hsum(const float* d, int N, int H, int W, int C, float* dstrip, int accumulate, void* stream) {
   TPGSR_CHECK_ARG(d && dstrip && N > 0 && H > 0 && W > 0 && C > 0, "tpgsr_hsum: bad arguments");
-  long long total = (long long)N * W * C;
-  hipLaunchKernelGGL(hsum_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, d, N, H, W, C, dstrip, accumulate);
+  TPGSR_CHECK_ARG(((W * C) & 3) == 0 && ((((uintptr_t)d) | ((uintptr_t)dstrip)) & 15) == 0 && (long long)N * W * C < (1ll << 31),
+                  "tpgsr_hsum: needs W C %% 4 == 0, 16-byte aligned operands and fewer than 2^31 strip elements");
+  const int WC4 = (W * C) >> 2;
+  hipLaunchKernelGGL(hsum_kernel, dim3(cdiv((long long)N * WC4, 256)), dim3(256), 0, (hipStream_t)stream, d, N, H, WC4, dstrip, accumulate);
   TPGSR_LAUNCH_CHECK("tpgsr_hsum");
 }
 

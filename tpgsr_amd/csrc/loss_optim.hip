@@ -4,124 +4,115 @@
 
 // ------------------------------------------------------------------------------------------------------
 // tail: out[n][co][h][w] = tanh(bias[co] + sum_kw P[n][h][w+kw-KS/2][kw*Co+co])   (NCHW output)
+//
+// Round 5: ONE WORKGROUP PER IMAGE ROW (n, h).  The first form gave every output element a thread that decoded its position with three
+// 64-bit divisions and read its KS addends 144 bytes apart (33 us for 28 MB in, 3 MB out); here the row's [W][KS Co] block of P is staged
+// into LDS by coalesced 16-byte loads (row pitch KS Co + 1 floats: the strided reads that follow are conflict-free) and summed from there.
+// The same code without bias / tanh into an NHWC map is tpgsr_shiftsum_nhwc (block1's folded data gradient).  Sums run kw = 0 .. KS-1
+// as before: same bits.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tail_shiftsum_tanh_kernel(const float* __restrict__ P, const float* __restrict__ bias,
-                                                                 int N, int H, int W, int Co, int KS,
-                                                                 float* __restrict__ out) {
-  long long total = (long long)N * Co * H * W;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  int w = (int)(i % W);
-  long long r = i / W;
-  int h = (int)(r % H);
-  r /= H;
-  int co = (int)(r % Co);
-  int n = (int)(r / Co);
-  const int NP = KS * Co, half = KS / 2;
-  float s = bias ? bias[co] : 0.f;
-  const float* row = P + ((size_t)(n * H + h) * W) * NP;
-  for (int kw = 0; kw < KS; ++kw) {
-    int x = w + kw - half;
-    if ((unsigned)x < (unsigned)W) s += row[(size_t)x * NP + kw * Co + co];
+#define TAIL_MAX_ROW (160 * 37)      // floats of LDS per row: W (KS Co + 1) <= 5920 (the 32 x 128 output of the hot path: 128 x 37)
+
+template <bool NCHW_TANH>
+__global__ __launch_bounds__(256) void shiftsum_row_kernel(const float* __restrict__ P, const float* __restrict__ bias, int H, int W, int Co,
+                                                           int KS, float* __restrict__ out) {
+  __shared__ float row[TAIL_MAX_ROW];
+  const int NP = KS * Co, pitch = NP + 1, half = KS / 2;
+  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+  const float* src = P + (size_t)blockIdx.x * W * NP;
+  for (int e = threadIdx.x; e < (W * NP) >> 2; e += 256) {      // (NP % 4 == 0: the folded operands' column counts are multiples of 4)
+    const float4 v = *reinterpret_cast<const float4*>(src + 4 * e);
+    const int x = (4 * e) / NP, c = 4 * e - x * NP;
+    float* d = row + x * pitch + c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
-  out[i] = tanh_f(s);
+  __syncthreads();
+  for (int e = threadIdx.x; e < W * Co; e += 256) {
+    int co, w;
+    if (NCHW_TANH) {
+      co = e / W;
+      w = e - co * W;
+    } else {
+      w = e / Co;
+      co = e - w * Co;
+    }
+    float s = (NCHW_TANH && bias) ? bias[co] : 0.f;
+    for (int kw = 0; kw < KS; ++kw) {
+      const int x = w + kw - half;
+      if ((unsigned)x < (unsigned)W) s += row[x * pitch + kw * Co + co];
+    }
+    if (NCHW_TANH) out[(((size_t)n * Co + co) * H + h) * W + w] = tanh_f(s);
+    else out[((size_t)blockIdx.x * W + w) * Co + co] = s;
+  }
 }
 
 extern "C" int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,
                                         float* out_nchw, void* stream) {
   TPGSR_CHECK_ARG(P && out_nchw && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "tpgsr_tail_shiftsum_tanh: bad arguments");
-  long long total = (long long)N * Co * H * W;
-  hipLaunchKernelGGL(tail_shiftsum_tanh_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, P, bias, N, H, W,
-                     Co, KS, out_nchw);
+  TPGSR_CHECK_ARG(((KS * Co) & 3) == 0 && W * (KS * Co + 1) <= TAIL_MAX_ROW && (((uintptr_t)P) & 15) == 0,
+                  "tpgsr_tail_shiftsum_tanh: needs KS Co %% 4 == 0 and W (KS Co + 1) <= %d floats per row (got W %d, KS %d, Co %d)", TAIL_MAX_ROW, W, KS, Co);
+  hipLaunchKernelGGL(shiftsum_row_kernel<true>, dim3(N * H), dim3(256), 0, (hipStream_t)stream, P, bias, H, W, Co, KS, out_nchw);
   TPGSR_LAUNCH_CHECK("tpgsr_tail_shiftsum_tanh");
-}
-
-// the same sum without bias / tanh into an NHWC map: out[n][h][w][co] = sum_kw P[n][h][w+kw-KS/2][kw*Co+co] -- the second half of a
-// KS x KS convolution with few output channels run as a KS x 1 convolution with the kw taps folded into its columns (block1's data
-// gradient, model/tsrn.py:28: 64 -> 4 over 81 taps: on the matrix cores' 32-column blocks it ran at 2 % of its peak, 115 us)
-__global__ __launch_bounds__(256) void shiftsum_nhwc_kernel(const float* __restrict__ P, int N, int H, int W, int Co, int KS,
-                                                            float* __restrict__ out) {
-  const long long total = (long long)N * H * W * Co;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int co = (int)(i % Co);
-  const long long pix = i / Co;
-  const int w = (int)(pix % W);
-  const int NP = KS * Co, half = KS / 2;
-  const float* row = P + (size_t)(pix - w) * NP;
-  float s = 0.f;
-  for (int kw = 0; kw < KS; ++kw) {
-    const int x = w + kw - half;
-    if ((unsigned)x < (unsigned)W) s += row[(size_t)x * NP + kw * Co + co];
-  }
-  out[i] = s;
 }
 
 extern "C" int tpgsr_shiftsum_nhwc(const float* P, int N, int H, int W, int Co, int KS, float* out, void* stream) {
   TPGSR_CHECK_ARG(P && out && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "tpgsr_shiftsum_nhwc: bad arguments");
-  const long long total = (long long)N * H * W * Co;
-  hipLaunchKernelGGL(shiftsum_nhwc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, P, N, H, W, Co, KS, out);
+  TPGSR_CHECK_ARG(((KS * Co) & 3) == 0 && W * (KS * Co + 1) <= TAIL_MAX_ROW && (((uintptr_t)P) & 15) == 0,
+                  "tpgsr_shiftsum_nhwc: needs KS Co %% 4 == 0 and W (KS Co + 1) <= %d floats per row (got W %d, KS %d, Co %d)", TAIL_MAX_ROW, W, KS, Co);
+  hipLaunchKernelGGL(shiftsum_row_kernel<false>, dim3(N * H), dim3(256), 0, (hipStream_t)stream, P, nullptr, H, W, Co, KS, out);
   TPGSR_LAUNCH_CHECK("tpgsr_shiftsum_nhwc");
 }
 
-// dP[n][h][x][kw*Co+co] = dpre[n][co][h][x-kw+KS/2], dpre = dout*(1-out^2); dbias partial per block
-__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, int N,
-                                                       int H, int W, int Co, int KS, float* __restrict__ dP,
-                                                       float* __restrict__ dbp) {
-  // bias-gradient partial of the block in a FIXED order: per channel a shuffle tree inside every wave, then the four waves'
-  // sums added by one thread.  (Until round 4 this was an LDS atomicAdd from every thread: the order of the float additions
-  // followed the waves' timing, so the partial -- and with it the tail bias gradient -- could differ in its last bits from run
-  // to run whenever something else shared the CUs.  DESIGN section 5, "the bit flip of round 3".)
-  __shared__ float sb[4][8];
-  const int NP = KS * Co, half = KS / 2;
-  long long total = (long long)N * H * W * NP;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  float contrib = 0.f;
-  int cco = -1;
-  if (i < total) {
-    int np = (int)(i % NP);
-    long long r = i / NP;
-    int x = (int)(r % W);
-    r /= W;
-    int h = (int)(r % H);
-    int n = (int)(r / H);
-    int kw = np / Co, co = np - kw * Co;
-    int w = x - kw + half;
+// dP[n][h][x][kw*Co+co] = dpre[n][co][h][x-kw+KS/2], dpre = dout*(1-out^2); dbias partial per (n, h) row.
+// One workgroup per image row as well: the row's Co x W values of dpre are computed once (coalesced NCHW reads) into LDS with KS/2 zeros
+// on either side, the [W][KS Co] block of dP is written from there in coalesced order, and the bias-gradient partial of the row is each
+// channel's sum over w in a FIXED order (a shuffle tree per wave over a fixed assignment, the waves added in order -- until round 4's fix an
+// LDS atomicAdd: "the bit flip of round 3").  The first form spent its time in four 64-bit divisions per element (37 us).
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, int H, int W, int Co,
+                                                       int KS, float* __restrict__ dP, float* __restrict__ dbp) {
+  __shared__ float dpre[8 * (160 + 16)];
+  const int NP = KS * Co, half = KS / 2, pitch = W + 2 * half;
+  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+  for (int e = threadIdx.x; e < Co * pitch; e += 256) {
+    const int co = e / pitch, x = e - co * pitch - half;
     float v = 0.f;
-    if ((unsigned)w < (unsigned)W) {
-      size_t o = (((size_t)n * Co + co) * H + h) * W + w;
-      float y = out[o];
+    if ((unsigned)x < (unsigned)W) {
+      const size_t o = (((size_t)n * Co + co) * H + h) * W + x;
+      const float y = out[o];
       v = dout[o] * (1.f - y * y);
-      if (kw == half) {
-        contrib = v;
-        cco = co;
-      }
     }
-    dP[i] = v;
-  }
-  if (!dbp) return;                                    // (uniform)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = 0; c < Co; ++c) {
-    const float s = wave_sum(cco == c ? contrib : 0.f);
-    if (lane == 0) sb[wave][c] = s;
+    dpre[e] = v;
   }
   __syncthreads();
-  if (threadIdx.x < Co) dbp[(size_t)blockIdx.x * Co + threadIdx.x] = (sb[0][threadIdx.x] + sb[1][threadIdx.x]) + (sb[2][threadIdx.x] + sb[3][threadIdx.x]);
+  float* dst = dP + (size_t)blockIdx.x * W * NP;
+  for (int e = threadIdx.x; e < W * NP; e += 256) {
+    const int x = e / NP, np = e - x * NP;
+    const int kw = np / Co, co = np - kw * Co;
+    dst[e] = dpre[co * pitch + (x - kw + half) + half];      // (the zero margins stand for the positions outside the row)
+  }
+  if (!dbp) return;                                    // (uniform)
+  // bias-gradient partial of the row: wave `wv` sums channel co over w = lane, lane + 64, ... for co = wv, wv + 4, ...
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int co = wave; co < Co; co += 4) {
+    float s = 0.f;
+    for (int w = lane; w < W; w += 64) s += dpre[co * pitch + half + w];
+    s = wave_sum(s);
+    if (lane == 0) dbp[(size_t)blockIdx.x * Co + co] = s;
+  }
+}
+
+extern "C" int tpgsr_tail_bwd_blocks(int N, int H, int W, int Co, int KS) {
+  (void)W; (void)Co; (void)KS;
+  return N * H;      // one bias-gradient partial row per image row
 }
 
 extern "C" int tpgsr_tail_bwd(const float* out_nchw, const float* dout_nchw, int N, int H, int W, int Co, int KS, float* dP,
                               float* dbias_partial, int nblk, void* stream) {
-  TPGSR_CHECK_ARG(out_nchw && dout_nchw && dP && Co <= 8 && (KS & 1), "tpgsr_tail_bwd: bad arguments");
-  long long total = (long long)N * H * W * KS * Co;
-  int grid = cdiv(total, 256);
+  TPGSR_CHECK_ARG(out_nchw && dout_nchw && dP && Co <= 8 && (KS & 1) && KS <= 17 && W <= 160, "tpgsr_tail_bwd: bad arguments (Co <= 8, odd KS <= 17, W <= 160)");
+  const int grid = N * H;
   TPGSR_CHECK_ARG(!dbias_partial || nblk == grid, "tpgsr_tail_bwd: dbias_partial needs nblk == %d blocks (got %d)", grid, nblk);
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_nchw, dout_nchw, N, H, W, Co, KS, dP,
-                     dbias_partial);
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_nchw, dout_nchw, H, W, Co, KS, dP, dbias_partial);
   TPGSR_LAUNCH_CHECK("tpgsr_tail_bwd");
-}
-
-extern "C" int tpgsr_tail_bwd_blocks(int N, int H, int W, int Co, int KS) {
-  return cdiv((long long)N * H * W * KS * Co, 256);
 }
 
 // ------------------------------------------------------------------------------------------------------

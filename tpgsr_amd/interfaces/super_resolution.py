@@ -16,6 +16,8 @@ from ..engine import ArenaPool
 from ..optim import FusedAdam
 
 _NBLK = 128
+_NBLK_IMG = 1024     # partial rows of the image loss: 786 K elements with two 4-neighbour gradient magnitudes each -- at 128 workgroups the
+                     # launch was a 24-iteration latency chain per thread (29 us on the critical path between the SR forward and backward)
 
 
 def _warn_hw_queues(collective: bool):
@@ -56,7 +58,7 @@ class TSRNTrainStep:
         if self._static is None or self._static["dev"] != dev or self._static["shape"] != tuple(lr_img.shape):
             N, C, H, W = lr_img.shape
             self._static = dict(dev=dev, shape=tuple(lr_img.shape),
-                                part=torch.empty(_NBLK, 2, device=dev), loss=torch.zeros((), device=dev),
+                                part=torch.empty(_NBLK_IMG, 2, device=dev), loss=torch.zeros((), device=dev),
                                 dloss=torch.full((1,), 100.0, device=dev), dsr=torch.empty(N, C, 2 * H, 2 * W, device=dev),
                                 inv_world=torch.full((1,), 1.0 / self.world, device=dev))
         return self._static
@@ -71,9 +73,9 @@ class TSRNTrainStep:
         sr = eng.forward(lr_img, True)
         H2, W2 = 2 * H, 2 * W
         hr = hr_img.contiguous()
-        K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part"], _NBLK)
+        K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part"], _NBLK_IMG)
         n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
-        K.image_loss_finalize(st["part"], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["loss"])
+        K.image_loss_finalize(st["part"], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["loss"])
         K.image_loss_bwd(sr, hr, st["dloss"], N, C, H2, W2, self.gradient, self.w0, self.w1, st["dsr"])
         eng.backward(tuple(lr_img.shape), sr, st["dsr"])
         self.last_sr = sr
@@ -238,7 +240,7 @@ class TPGSRTrainStep:
             st = dict(key=(dev, tuple(lr_img.shape)), q=torch.empty(N, 26, 37, device=dev),
                       gray_hr=torch.empty(N, 1, 32, 100, device=dev), loss=torch.zeros((), device=dev),
                       dloss=torch.full((1,), 100.0, device=dev), inv_world=torch.full((1,), 1.0 / self.world, device=dev),
-                      part_img=[torch.empty(_NBLK, 2, device=dev) for _ in range(S)],
+                      part_img=[torch.empty(_NBLK_IMG, 2, device=dev) for _ in range(S)],
                       part_sem=[torch.empty(_NBLK, 2, device=dev) for _ in range(S)],
                       l_img=[torch.zeros((), device=dev) for _ in range(S)], l_sem=[torch.zeros((), device=dev) for _ in range(S)],
                       gray=[torch.empty(N, 1, 32, 100, device=dev) for _ in range(S)],
@@ -295,9 +297,9 @@ class TPGSRTrainStep:
                 K.order(main, side)
                 self._mark(f"wait SR prologue{i}")
             sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join, pre_done=pre_side)
-            K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK)
+            K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK_IMG)
             n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
-            K.image_loss_finalize(st["part_img"][i], _NBLK, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
+            K.image_loss_finalize(st["part_img"][i], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
             srs.append(sr)
             self._mark(f"SR{i} fwd + loss")
             cascade, ch, cw = sr, H2, W2

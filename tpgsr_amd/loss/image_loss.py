@@ -6,7 +6,7 @@ from torch import nn
 
 from .. import kernels as K
 
-_NBLK = 128
+_NBLK = 1024
 
 
 class _ImageLossFn(torch.autograd.Function):
