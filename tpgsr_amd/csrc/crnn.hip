@@ -210,31 +210,53 @@ extern "C" int tpgsr_pad_channels(const float* src, long long M, int Cs, int Cd,
 // ------------------------------------------------------------------------------------------------------
 // general max-pool (kernel KHxKW, stride SHxSW, zero... -inf padding PHxPW) of act(scale*x+shift), NHWC
 // ------------------------------------------------------------------------------------------------------
+// one thread = VEC consecutive channels of one output position (VEC = 4 when C % 4 == 0: 16-byte accesses, the window arithmetic shared
+// by the four channels, 32-bit index decoding -- the scalar form with its 64-bit divisions per element was 13-20 us per launch, four
+// launches in the text-prior generator's forward pass and four in the teacher's)
+template <int VEC>
 __global__ __launch_bounds__(256) void pool2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
                                                          const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                          int KH, int KW, int SH, int SW, int PH, int PW, int OH, int OW,
                                                          float* __restrict__ out) {
-  long long total = (long long)N * OH * OW * C;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    long long p = i / C;
-    int ow = (int)(p % OW);
-    p /= OW;
-    int oh = (int)(p % OH);
-    int n = (int)(p / OH);
-    float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
-    float best = -INFINITY;
+  const int CV = C / VEC;
+  const unsigned total = (unsigned)N * OH * OW * CV;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    unsigned p = i / (unsigned)CV;
+    const int c = (int)(i - p * CV) * VEC;
+    const unsigned p2 = p / (unsigned)OW;
+    const int ow = (int)(p - p2 * OW);
+    const int n = (int)(p2 / (unsigned)OH);
+    const int oh = (int)(p2 - (unsigned)n * OH);
+    float sc[VEC], sh[VEC], best[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      sc[v] = scale ? scale[c + v] : 1.f;
+      sh[v] = shift ? shift[c + v] : 0.f;
+      best[v] = -INFINITY;
+    }
     for (int a = 0; a < KH; ++a) {
-      int h = oh * SH - PH + a;
+      const int h = oh * SH - PH + a;
       if ((unsigned)h >= (unsigned)H) continue;
       for (int b = 0; b < KW; ++b) {
-        int w = ow * SW - PW + b;
+        const int w = ow * SW - PW + b;
         if ((unsigned)w >= (unsigned)W) continue;
-        float v = apply_act(x[((size_t)(n * H + h) * W + w) * C + c] * sc + sh, act);
-        if (v > best || v != v) best = v;
+        const size_t o = ((size_t)(n * H + h) * W + w) * C + c;
+        float xv[VEC];
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(x + o);
+          xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        } else {
+          xv[0] = x[o];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float val = apply_act(xv[v] * sc[v] + sh[v], act);
+          if (val > best[v] || val != val) best[v] = val;
+        }
       }
     }
-    out[i] = best;
+    if (VEC == 4) *reinterpret_cast<float4*>(out + (size_t)i * 4) = make_float4(best[0], best[1], best[2], best[3]);
+    else out[i] = best[0];
   }
 }
 
@@ -243,10 +265,16 @@ extern "C" int tpgsr_pool2d_fwd(const float* x, int N, int H, int W, int C, cons
   TPGSR_CHECK_ARG(x && out && KH > 0 && KW > 0 && SH > 0 && SW > 0 && PH >= 0 && PW >= 0, "tpgsr_pool2d_fwd: bad arguments");
   int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
   TPGSR_CHECK_ARG(OH > 0 && OW > 0, "tpgsr_pool2d_fwd: empty output");
-  long long total = (long long)N * OH * OW * C;
+  TPGSR_CHECK_ARG((long long)N * H * W * C < (1ll << 31) && (long long)N * OH * OW * C < (1ll << 31), "tpgsr_pool2d_fwd: map too large for the kernel's 32-bit indices");
+  const bool vec = (C & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+  long long total = (long long)N * OH * OW * (vec ? C / 4 : C);
   int grid = (int)min((long long)8192, (total + 255) / 256);
-  hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, scale, shift, act, KH, KW, SH, SW,
-                     PH, PW, OH, OW, out);
+  if (vec)
+    hipLaunchKernelGGL(pool2d_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, scale, shift, act, KH, KW, SH, SW,
+                       PH, PW, OH, OW, out);
+  else
+    hipLaunchKernelGGL(pool2d_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, scale, shift, act, KH, KW, SH, SW,
+                       PH, PW, OH, OW, out);
   TPGSR_LAUNCH_CHECK("tpgsr_pool2d_fwd");
 }
 
@@ -346,14 +374,14 @@ __global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const float* __restric
                                                           int W, int C, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act, float* __restrict__ dz) {
   const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
-  const long long total = (long long)N * OH * OW * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long p = i / C4;
-    const int ow = (int)(p % OW);
-    p /= OW;
-    const int oh = (int)(p % OH);
-    const int n = (int)(p / OH);
+  const unsigned total = (unsigned)N * OH * OW * C4;      // (< 2^31: the launcher checks; 64-bit divisions were a third of this kernel)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    unsigned p = i / (unsigned)C4;
+    const int c = (int)(i - p * C4) * 4;
+    const unsigned p2 = p / (unsigned)OW;
+    const int ow = (int)(p - p2 * OW);
+    const int n = (int)(p2 / (unsigned)OH);
+    const int oh = (int)(p2 - (unsigned)n * OH);
     const size_t base = ((size_t)(n * H + 2 * oh) * W + 2 * ow) * C + c;
     const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
     float4 xv[4];
@@ -394,14 +422,14 @@ __global__ __launch_bounds__(256) void pool2x2s21_bwd_kernel(const float* __rest
                                                              int W, int C, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int act, float* __restrict__ dz) {
   const int C4 = C >> 2, OH = H >> 1, OW = W + 1;
-  const long long total = (long long)N * OH * W * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long p = i / C4;
-    const int w = (int)(p % W);
-    p /= W;
-    const int oh = (int)(p % OH);
-    const int n = (int)(p / OH);
+  const unsigned total = (unsigned)N * OH * W * C4;       // (< 2^31: the launcher checks)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    unsigned p = i / (unsigned)C4;
+    const int c = (int)(i - p * C4) * 4;
+    const unsigned p2 = p / (unsigned)W;
+    const int w = (int)(p - p2 * W);
+    const int n = (int)(p2 / (unsigned)OH);
+    const int oh = (int)(p2 - (unsigned)n * OH);
     const size_t r0 = ((size_t)(n * H + 2 * oh) * W + w) * C + c, r1 = r0 + (size_t)W * C;
     const bool hasl = w > 0, hasr = w + 1 < W;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -456,6 +484,7 @@ extern "C" int tpgsr_pool2d_bwd(const float* x, const float* dout, int N, int H,
   int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
   const bool vec = (C & 3) == 0 && ((((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dz) & 15) == 0);
   long long total = (long long)N * H * W * (vec ? C / 4 : C);
+  TPGSR_CHECK_ARG((long long)N * H * W * C < (1ll << 31), "tpgsr_pool2d_bwd: map too large for the kernels' 32-bit indices");
   int grid = (int)min((long long)16384, (total + 255) / 256);
   static const bool fast2x2 = [] { const char* e = getenv("TPGSR_POOL2X2_FAST"); return !(e && e[0] == '0'); }();
   if (fast2x2 && vec && KH == 2 && KW == 2 && SH == 2 && SW == 2 && PH == 0 && PW == 0 && !(H & 1) && !(W & 1) &&

@@ -254,8 +254,16 @@ extern "C" int tpgsr_image_loss_bwd(const float* out, const float* tgt, const fl
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ partial) {
   __shared__ double red[4];
   double s = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float v = x[i];
+  // 16-byte loads, two in flight per thread (the scalar form read a 14 MB gradient arena in 23 us); x is 16-byte aligned (arena slices are)
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const float4 u = *reinterpret_cast<const float4*>(x + i * 4);
+    const float4 v = i + stride < n4 ? *reinterpret_cast<const float4*>(x + (i + stride) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += ((double)u.x * (double)u.x + (double)u.y * (double)u.y) + ((double)u.z * (double)u.z + (double)u.w * (double)u.w);
+    s += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = x[n4 * 4 + threadIdx.x];
     s += (double)v * (double)v;
   }
   s = wave_sum_d(s);
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 }
 
 extern "C" int tpgsr_sumsq_partial(const float* x, long long n, float* partial, int nblk, void* stream) {
-  TPGSR_CHECK_ARG(x && partial && n > 0 && nblk > 0, "tpgsr_sumsq_partial: bad arguments");
+  TPGSR_CHECK_ARG(x && partial && n > 0 && nblk > 0 && (((uintptr_t)x) & 15) == 0, "tpgsr_sumsq_partial: bad arguments (x must be 16-byte aligned)");
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n, partial);
   TPGSR_LAUNCH_CHECK("tpgsr_sumsq_partial");
 }

@@ -1110,7 +1110,7 @@ class TSRNEngine(_EngineBase):
         if have_B:
             K.add(gA, gB, P1 * Cc, gA)
         dc1 = ws("dc1", P1, Cc)
-        nb = 256
+        nb = 1024
         dap = self.scratch("prelu_dap" + K.stream_tag(), nb)
         K.prelu_bwd(t["c1"], self.P["block1.1.weight"], gA, d_s, P1 * Cc, dc1, dap, nb)
         with K.side():
