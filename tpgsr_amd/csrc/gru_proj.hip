@@ -4,7 +4,8 @@
 // projection was a launch of its own (the row-panel kernel, conv_panel.hip) that wrote gi [P][192] to HBM (37.7 MB at bs 48) for the
 // scan to read back through a prefetch ring: 10 launches and 0.75 GB per forward pass that need not exist.
 //
-// One wavefront = one workgroup = one sequence of T = 16 NRT steps (the 16 x 64 map: T = 16 along H, 64 along W), as in gru.hip.
+// One workgroup (four waves) = one sequence of T = 16 NRT steps (the 16 x 64 map: T = 16 along H, 64 along W); the four waves share
+// the projection, wave 0 scans (one wavefront per sequence, as in gru.hip).
 //   phase 1  the [T x Cin] input panel as MFMA fragments STRAIGHT FROM GLOBAL MEMORY: a 16x16x32 fragment is 8 consecutive channels of one
 //            pixel per lane (32 contiguous bytes), so no LDS transposition is needed; the fused prologue of the convolution loaders
 //            (BatchNorm affine, residual add, concatenated text strip: conv_loader.h's LD bits 1 / 4 / 16) is applied and the values are
@@ -48,15 +49,15 @@ __device__ __forceinline__ floatx4 gp_mfma_terms(const bf16x8 (&w)[TT], const bf
 
 // LD: 1 = per-channel affine (BatchNorm) on the image channels, 4 = residual add (in2), 16 = channels >= cin_a from the [N][W][.] strip
 template <int LD, int TT, int NRT, int NKS, bool TRAIN>
-__global__ __launch_bounds__(64) void bigru_proj_fwd_kernel(const tpgsr_bigru_proj_args p) {
+__global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_proj_args p) {
   constexpr int T = 16 * NRT;
   extern __shared__ __attribute__((aligned(16))) float gsm[];      // gi [T][GP_RS], then hs [2][64]
   float* const gi = gsm;
   float* const hs = gsm + T * GP_RS;
   const tpgsr_conv_args& a = p.c;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const SeqGeom g = seq_geom(blockIdx.x, a.N, a.H, a.W, p.axis);
-  if (!g.active) return;        // (one wave per workgroup: nobody waits for it)
+  if (!g.active) return;        // (workgroup-uniform)
   const int l16 = lane & 15, kq = lane >> 4;
 
   // ---- phase 1: the panel as split MFMA fragments: xf[rt][ks][term] = 8 channels 32 ks + 8 kq .. of time step 16 rt + l16 ----
@@ -130,8 +131,12 @@ __global__ __launch_bounds__(64) void bigru_proj_fwd_kernel(const tpgsr_bigru_pr
     // ct 16 + l16 -> block (ct >> 1), lane slot (ct & 1) 16 + l16 (+ 32 for the upper 8 of a 16-k block); k = 32 ks + 8 kq -> k-block
     // 2 ks + (kq >> 1), upper half when kq is odd
     const unsigned wlane = ((unsigned)l16 + 32u * (kq & 1)) * 16u + (unsigned)(kq >> 1) * 1024u;
-#pragma unroll 2
-    for (int ct = 0; ct < 12; ++ct) {
+    // FOUR waves share the projection: wave w computes column tiles 3 w .. 3 w + 2 for all time steps (every wave holds the whole panel
+    // as fragments -- the three redundant panel loads hit the L1 -- so nothing is exchanged before the barrier below); alone, one wave
+    // spent ~8 us here before its scan could start, with the other three SIMDs of the CU idle
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+      const int ct = 3 * wave + ci;
       bf16x8 wf[NKS][TT];
       const unsigned wbase = ((unsigned)(ct >> 1) * KB16) * 1024u + (unsigned)(ct & 1) * 256u + wlane;
 #pragma unroll
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(64) void bigru_proj_fwd_kernel(const tpgsr_bigru_pr
     }
   }
 
-  __syncthreads();      // (one wave: its LDS operations execute in order anyway; this makes the hand-over explicit for the compiler)
+  __syncthreads();      // all of gi is in LDS
+  if (wave != 0) return;      // the scan is one wave's work (LDS stays allocated until it is through)
 
   // ---- phase 3: the scan (bigru_fwd_kernel of gru.hip, the inputs out of LDS) ----
   const int d = lane >> 5, j = lane & 31;
@@ -270,7 +276,7 @@ extern "C" int tpgsr_bigru_proj_fwd(const tpgsr_bigru_proj_args* p, void* stream
   const size_t lds = ((size_t)T * GP_RS + 128) * sizeof(float);
   tpgsr_bigru_proj_args args = *p;
   void* params[] = {&args};
-  if (hipLaunchKernel(fn, dim3((unsigned)nseq), dim3(64), params, lds, (hipStream_t)stream) != hipSuccess) {
+  if (hipLaunchKernel(fn, dim3((unsigned)nseq), dim3(256), params, lds, (hipStream_t)stream) != hipSuccess) {
     tpgsr_set_error("tpgsr_bigru_proj_fwd: launch failed: %s", hipGetErrorString(hipGetLastError()));
     return TPGSR_ERR_LAUNCH;
   }
