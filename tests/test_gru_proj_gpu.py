@@ -114,3 +114,41 @@ def test_shapes_the_fused_kernel_does_not_take_fall_back_loudly():
     with K.conv_terms(0):                                        # fp32 matrix cores: no split planes
         pa = K.make_bigru_proj_args(K.make_conv_args(K.ConvGeom(3, 16, 64, 64, 192), t["x"], t["wc"], None, bias=t["bc"]), t["whh"], t["bhh"], 0, h, None)
         assert not K.bigru_proj_supported(pa)
+
+
+@pytest.mark.parametrize("axis,loader", [(1, "affine"), (1, "affine+strip"), (0, "residual")])
+def test_full_batch_is_bitwise_repeatable_and_per_sequence(axis, loader):
+    """bs 48 (3072 / 768 workgroups, several per CU): ten launches give the same bits, and a batch permutation permutes the result --
+    what tests/test_tsrn_gpu.py::test_full_size_properties_bs48 and the schedule tests need from every forward kernel.  (A first
+    four-wave form of the kernel passed every small test and failed exactly this.)"""
+    from tpgsr_amd import kernels as K
+    N, H, W = 48, 16, 64
+    Cin = 96 if loader == "affine+strip" else 64
+    t, kw = _case(N, H, W, Cin, loader, seed=5)
+    P = N * H * W
+    geom = K.ConvGeom(N, H, W, Cin, 192)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def permuted(v, rows_per_image):
+        return v.view(N, rows_per_image, -1)[perm].reshape(v.shape).contiguous()
+
+    with K.conv_terms(2):
+        K.make_bf_twin(t["wc"], 0)
+        outs = []
+        for rep in range(10):
+            h, gt = torch.full((P, 64), float("nan"), device=DEV), torch.full((P, 256), float("nan"), device=DEV)
+            K.bigru_proj_fwd(K.make_bigru_proj_args(K.make_conv_args(geom, t["x"], t["wc"], None, bias=t["bc"], **kw), t["whh"], t["bhh"], axis, h, gt))
+            outs.append((h, gt))
+        tp = dict(t)
+        tp["x"] = permuted(t["x"], H * W)
+        kwp = dict(kw)
+        if "x2" in t:
+            kwp["in2"] = permuted(t["x2"], H * W)
+        if "strip" in t:
+            kwp["in_b"] = permuted(t["strip"], W)
+        hp = torch.empty(P, 64, device=DEV)
+        K.bigru_proj_fwd(K.make_bigru_proj_args(K.make_conv_args(geom, tp["x"], t["wc"], None, bias=t["bc"], **kwp), t["whh"], t["bhh"], axis, hp, None))
+    torch.cuda.synchronize()
+    for h, gt in outs[1:]:
+        assert torch.equal(h, outs[0][0]) and torch.equal(gt, outs[0][1])
+    assert torch.equal(hp, permuted(outs[0][0], H * W))

@@ -131,12 +131,11 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     // ct 16 + l16 -> block (ct >> 1), lane slot (ct & 1) 16 + l16 (+ 32 for the upper 8 of a 16-k block); k = 32 ks + 8 kq -> k-block
     // 2 ks + (kq >> 1), upper half when kq is odd
     const unsigned wlane = ((unsigned)l16 + 32u * (kq & 1)) * 16u + (unsigned)(kq >> 1) * 1024u;
-    // FOUR waves share the projection: wave w computes column tiles 3 w .. 3 w + 2 for all time steps (every wave holds the whole panel
+    // the waves of the workgroup (four) share the projection: wave w computes column tiles w, w + 4, w + 8 for all time steps (every wave holds the whole panel
     // as fragments -- the three redundant panel loads hit the L1 -- so nothing is exchanged before the barrier below); alone, one wave
     // spent ~8 us here before its scan could start, with the other three SIMDs of the CU idle
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {
-      const int ct = 3 * wave + ci;
+    const int nw = blockDim.x >> 6;
+    for (int ct = wave; ct < 12; ct += nw) {
       bf16x8 wf[NKS][TT];
       const unsigned wbase = ((unsigned)(ct >> 1) * KB16) * 1024u + (unsigned)(ct & 1) * 256u + wlane;
 #pragma unroll
@@ -276,7 +275,8 @@ extern "C" int tpgsr_bigru_proj_fwd(const tpgsr_bigru_proj_args* p, void* stream
   const size_t lds = ((size_t)T * GP_RS + 128) * sizeof(float);
   tpgsr_bigru_proj_args args = *p;
   void* params[] = {&args};
-  if (hipLaunchKernel(fn, dim3((unsigned)nseq), dim3(256), params, lds, (hipStream_t)stream) != hipSuccess) {
+  static const int nthreads = [] { const char* e = getenv("TPGSR_GRU_PROJ_WAVES"); const int w = e ? atoi(e) : 4; return 64 * (w == 1 || w == 2 ? w : 4); }();
+  if (hipLaunchKernel(fn, dim3((unsigned)nseq), dim3(nthreads), params, lds, (hipStream_t)stream) != hipSuccess) {
     tpgsr_set_error("tpgsr_bigru_proj_fwd: launch failed: %s", hipGetErrorString(hipGetLastError()));
     return TPGSR_ERR_LAUNCH;
   }
