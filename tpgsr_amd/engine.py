@@ -765,6 +765,8 @@ class TSRNEngine(_EngineBase):
         # (measured on MI355X: 7.60 vs 7.55 ms per C3 step -- the longer leaf chain, whose weight gradients run in order with it, lands
         #  on the step's tail -- so it is opt-in: TPGSR_LEAF_EARLY=1)
         self.leaf_early = os.environ.get("TPGSR_LEAF_EARLY", "0") == "1"
+        # the text strip's data gradient (a 192 -> 32 projection + the sum over H, per residual block) on the leaf stream (TPGSR_LEAF_STRIP=0: caller's stream)
+        self.leaf_strip = os.environ.get("TPGSR_LEAF_STRIP", "1") != "0"
 
     def _build_layers(self):
         m = self.module
@@ -1079,9 +1081,13 @@ class TSRNEngine(_EngineBase):
                 # (leaf_early: block 0's BatchNorm backward runs on the leaf stream, its producer here -- no shared scratch across streams)
                 fz2 = None if (i == 0 and self.leaf_early) else L["bn2"].fuse_stats(y2, P1, "none", 192)
                 K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, Cc), dgi, g1.wc_d, da, wt_ld=g1.Cin, wt_coff=0, bnb=fz2))
-                dtb = ws("d_tb", P1, self.Ct)
-                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Ct), dgi, g1.wc_d, dtb, wt_ld=g1.Cin, wt_coff=Cc))
-                K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
+                # the text strip's share of the gradient (summed over the H rows it was broadcast to, accumulated over the blocks) only meets
+                # the caller's stream again at the InfoGen backward pass: it runs on the leaf stream (idle until the STN head's backward),
+                # block after block in order, next to the rest of this block on the caller's stream (round 5: -18 us per block there)
+                with (K.leaf() if self.leaf_strip else contextlib.nullcontext()):
+                    dtb = ws("d_tb", P1, self.Ct)
+                    K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, self.Ct), dgi, g1.wc_d, dtb, wt_ld=g1.Cin, wt_coff=Cc))
+                    K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
                 fz2 = None if (i == 0 and self.leaf_early) else L["bn2"].fuse_stats(y2, P1, "none", 192)
                 L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, da, dx_bnb=fz2, **L["bn2"].loader)
@@ -1103,6 +1109,11 @@ class TSRNEngine(_EngineBase):
             if (self.srb - 1 - i) % nbb == nbb - 1 or i == 0 or (i == 1 and self.leaf_early):
                 K.side_batch_end(sb)
                 sb = False
+        if self.tl and self.leaf_strip:
+            # dtemb is complete once the leaf stream is through block 0's strip gradient (recorded ~100 us of caller's-stream work ago).
+            # The edge goes HERE, before the STN head's backward chain is queued on the leaf stream: the InfoGen backward pass below must
+            # not wait for that
+            K.leaf_join()
         early = bool(self.srb and self.leaf_early)      # the leaf section is already open
         # block1's and InfoGen's weight gradients (+ the PReLU slope's reduce) behind one fork at the end of the plan
         sb = K.side_batch_begin() if (os.environ.get("TPGSR_SIDE_BATCH_TAIL", "1") != "0" and not early) else False

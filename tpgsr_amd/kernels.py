@@ -495,6 +495,13 @@ def leaf():
     return _REC.leaf() if _REC is not None and getattr(_REC, "overlap", False) and getattr(_REC, "use_leaf", False) else _NoSide()
 
 
+def leaf_join():
+    """the caller's stream waits for everything recorded on the leaf stream so far (no-op when nothing is pending there / outside a
+    recording): for leaf sections whose result the caller's stream needs later in the same plan"""
+    if _REC is not None and _REC.sid == 0 and _REC.leaf_pending:
+        _REC.ops.append(["edge", None, (2, 0), 0])
+
+
 def stream_tag() -> str:
     """suffix for stream-ordered scratch buffers: launches recorded on the leaf stream must not share them with the main stream's"""
     return "_leaf" if (_REC is not None and _REC.sid == 2) else ""
