@@ -73,11 +73,17 @@ class TSRNTrainStep:
         sr = eng.forward(lr_img, True)
         H2, W2 = 2 * H, 2 * W
         hr = hr_img.contiguous()
-        K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part"], _NBLK_IMG)
-        n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
-        K.image_loss_finalize(st["part"], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["loss"])
+        # the loss VALUE is for the caller's log (the gradient below does not read it): its pass over sr / hr and the single-wave finalize run
+        # on the auxiliary stream next to the backward pass, not in front of it
+        main, aux = K.current_stream(), K.aux_stream(lr_img.device)
+        K.order(aux, main)
+        with K.stream_ctx(aux):
+            K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part"], _NBLK_IMG)
+            n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
+            K.image_loss_finalize(st["part"], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["loss"])
         K.image_loss_bwd(sr, hr, st["dloss"], N, C, H2, W2, self.gradient, self.w0, self.w1, st["dsr"])
         eng.backward(tuple(lr_img.shape), sr, st["dsr"])
+        K.order(main, aux)
         self.last_sr = sr
         return st["loss"]
 
@@ -260,12 +266,14 @@ class TPGSRTrainStep:
         if self.collective:
             self._exchanger().begin()
         self._mark("start")
-        self.opt.zero_grad()
         # teacher on HR (eval mode, no gradient): independent of the student / SR forward until the semantic loss, so it runs
         # on its own stream next to them (interfaces/super_resolution.py:372-382 computes it inline)
         main, aux = K.current_stream(), K.aux_stream(lr_img.device)
         K.order(aux, main)
         with K.stream_ctx(aux):
+            # (zero_grad: one memset of the pooled gradient arena -- nothing writes a gradient before the caller's stream has waited for this
+            #  stream, below, for the teacher's distribution)
+            self.opt.zero_grad()
             K.bicubic_gray_fwd(hr, N, C, H2, W2, 32, 100, st["gray_hr"])
             t_logits = self.teacher._engine().forward(st["gray_hr"], False)
             K.softmax_prior_fwd(t_logits, None, N, 26, 37, 0, st["q"], None, None, _NBLK)
@@ -292,23 +300,30 @@ class TPGSRTrainStep:
                 K.order(main, aux)              # the teacher's distribution q is needed from here on
                 self._mark("wait teacher")
             K.softmax_prior_fwd(logits, st["q"], N, 26, 37, N // 4, st["p"][i], st["prior"][i], st["part_sem"][i], _NBLK)
-            K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
             if pre_side:
                 K.order(main, side)
                 self._mark(f"wait SR prologue{i}")
             sr = srm._engine().forward(lr_img, True, st["prior"][i], slot=i, defer_join=self._defer_join, pre_done=pre_side)
-            K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK_IMG)
-            n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
-            K.image_loss_finalize(st["part_img"][i], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
+            # The loss VALUE is for the caller's log: no gradient depends on it (image_loss_bwd / softmax_prior_bwd recompute what they
+            # need from sr, hr, p, q).  Its launches -- a full pass over sr and hr + two single-wave finalizes per stage -- run on the teacher's
+            # stream, idle by now, instead of between the SR network's forward and backward passes (-30 us on the caller's stream per stage);
+            # _join_side() orders the caller's stream after it before the step returns
+            K.order(aux, main)
+            with K.stream_ctx(aux):
+                K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
+                K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK_IMG)
+                n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
+                K.image_loss_finalize(st["part_img"][i], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
             srs.append(sr)
             self._mark(f"SR{i} fwd + loss")
             cascade, ch, cw = sr, H2, W2
-        # total loss (device scalar) = sum of the 2*stu_iter scalars
-        K.copy(st["l_img"][0], st["loss"], 1)
-        for i in range(self.stu_iter):
-            if i > 0:
-                K.add(st["loss"], st["l_img"][i], 1, st["loss"])
-            K.add(st["loss"], st["l_sem"][i], 1, st["loss"])
+        # total loss (device scalar) = sum of the 2*stu_iter scalars (same stream as its addends, same order as before)
+        with K.stream_ctx(aux):
+            K.copy(st["l_img"][0], st["loss"], 1)
+            for i in range(self.stu_iter):
+                if i > 0:
+                    K.add(st["loss"], st["l_img"][i], 1, st["loss"])
+                K.add(st["loss"], st["l_sem"][i], 1, st["loss"])
         # backward, last stage first
         for i in range(self.stu_iter - 1, -1, -1):
             stu = self.stu[0 if self.tpg_share else i]
@@ -416,10 +431,13 @@ class TPGSRTrainStep:
             self._exchanger().finish()
 
     def _join_side(self, device):
-        if self._defer_join and not K.DRYRUN:
+        if K.DRYRUN:
+            return
+        if self._defer_join:
             K.order(K.current_stream(), K.side_stream(device))
-            # the SR network's backward plan leaves its leaf stream (STN head backward + the slab reduce of its weight gradients) unjoined too
-            K.order(K.current_stream(), K.aux_stream(device))
+        # the SR network's backward plan leaves its leaf stream (STN head backward + the slab reduce of its weight gradients) unjoined too,
+        # and the loss value is computed there (always: with and without the deferred join)
+        K.order(K.current_stream(), K.aux_stream(device))
 
     def _phase_b(self):
         self.opt.step()
