@@ -270,7 +270,7 @@ class BNLayer:
     def partial(self, M):
         """scratch for the producing conv's epilogue statistics"""
         nblk = (M + 63) // 64
-        return self.eng.scratch("bn_partial", nblk * 2 * self.C), nblk
+        return self.eng.scratch("bn_partial" + K.stream_tag(), nblk * 2 * self.C), nblk
 
     def finalize(self, M, conv_bias, training, row_tiles=1):
         if training:
@@ -767,6 +767,10 @@ class TSRNEngine(_EngineBase):
         self.leaf_early = os.environ.get("TPGSR_LEAF_EARLY", "0") == "1"
         # the text strip's data gradient (a 192 -> 32 projection + the sum over H, per residual block) on the leaf stream (TPGSR_LEAF_STRIP=0: caller's stream)
         self.leaf_strip = os.environ.get("TPGSR_LEAF_STRIP", "1") != "0"
+        # InfoGen's forward pass on the weight-gradient stream next to block 0's convolutions: opt-in (TPGSR_SIDE_INFOGEN=1) -- measured
+        # 5.614 / 5.598 vs 5.614 / 5.618 ms per C3 step (gpurun_out/r05w): its tile-loop workgroups sit on CUs the trunk's whole-CU
+        # convolutions then wait for, and what the caller's stream saves it loses again
+        self.side_infogen = os.environ.get("TPGSR_SIDE_INFOGEN", "0") == "1"
 
     def _build_layers(self):
         m = self.module
@@ -831,6 +835,7 @@ class TSRNEngine(_EngineBase):
         pre, fwd, bwd, pack = Plan("tsrn_fwd_pre"), Plan("tsrn_fwd"), Plan("tsrn_bwd"), Plan("tsrn_pack")
         pre.final = fwd.final = bwd.final = pack.final = final
         bwd.overlap = self.overlap_wgrad
+        fwd.overlap = self.overlap_wgrad      # (its one side section: InfoGen's forward pass)
         bwd.deferred = [] if self.defer_reduce else None
         bwd.use_leaf = self.leaf_stn and self.overlap_wgrad and self.defer_reduce
         self._cur_ws, self._wg_idx, self._compose = ws, 0, []
@@ -881,7 +886,14 @@ class TSRNEngine(_EngineBase):
     def _record_fwd(self, N, H, W, training, ws, b1):
         Cc, Ci = self.C, self.in_planes
         P1 = N * H * W
-        temb = self._record_infogen_fwd(N, W, training, ws) if self.tl else None
+        temb = None
+        if self.tl:
+            # InfoGen (four strip convolutions + BatchNorms + the resample: ~160 us of small launches) only depends on the text prior, and
+            # nothing needs its output before block 0's first GruBlock: it CAN run on the weight-gradient stream -- idle during a forward
+            # pass -- next to block 0's two 3x3 convolutions, the caller's stream joining in front of that GruBlock (side_infogen: off by
+            # default, it bought nothing)
+            with (K.side() if self.side_infogen else contextlib.nullcontext()):
+                temb = self._record_infogen_fwd(N, W, training, ws)
         cur = b1
         for i, L in enumerate(self.rrb):
             t = f"r{i}_"
@@ -906,11 +918,15 @@ class TSRNEngine(_EngineBase):
             if fin is None:
                 L["bn2"].finalize(P1, L["conv2"].b, training, g2.bn_row_tiles)
             if self.tl:   # torch.cat([bn2(y2), text strip], 1) inside the 1x1 conv's loader (model/tsrn.py:419-423)
+                if i == 0 and self.side_infogen and K._REC is not None and K._REC.forks:
+                    K._REC.join()          # the text strip comes off the other stream
                 L["gru1"].fwd(N, H, W, y2, gi1, h1, gt1, in_b=temb, cin_a=Cc, **L["bn2"].loader)
             else:
                 L["gru1"].fwd(N, H, W, y2, gi1, h1, gt1, **L["bn2"].loader)
             L["gru2"].fwd(N, H, W, cur, gi2, out, gt2, in2=h1)
             cur = out
+        if K._REC is not None and K._REC.forks:
+            K._REC.join()                  # (a network without residual blocks: nobody has waited for InfoGen yet)
         y7 = ws("y7", P1, Cc)
         part, _ = self.bn7.partial(P1)
         fin = self.bn7.fin(P1, self.conv7.b) if training else None

@@ -503,8 +503,8 @@ def leaf_join():
 
 
 def stream_tag() -> str:
-    """suffix for stream-ordered scratch buffers: launches recorded on the leaf stream must not share them with the main stream's"""
-    return "_leaf" if (_REC is not None and _REC.sid == 2) else ""
+    """suffix for stream-ordered scratch buffers: launches recorded on the leaf / side stream must not share them with the main stream's"""
+    return "_leaf" if (_REC is not None and _REC.sid == 2) else "_side" if (_REC is not None and _REC.sid == 1) else ""
 
 
 class DynPtr:
