@@ -516,7 +516,11 @@ def main():
     if rank == 0:
         ms = 1e3 * dt / args.steps
         value = B * world * args.steps / dt
-        n_launch = sum(len(pl[k]) for m in nets for pl in m._engine()._plans.values() for k in ("pack_late", "pre", "fwd", "fwd_b", "bwd", "bwd_b") if k in pl)
+        # the step's recorded plans: kernel launches, and plan operations = launches + stream edges (fork / join / edge); the ~25 launches the
+        # step makes outside plans (losses, softmax / prior, optimiser) are not in either count
+        _plans = [pl[k] for m in nets for pl in m._engine()._plans.values() for k in ("pack", "pack_late", "pre", "fwd", "fwd_b", "bwd", "bwd_b") if k in pl]
+        n_ops = sum(len(p.ops) for p in _plans)
+        n_launch = sum(1 for p in _plans for op in p.ops if op[1] is not None)
         out = {
             "metric": "training img/s (16x64->32x128, bs=%d/GPU), %s full train step" % (B, "TPGSR-TSRN" if cfg["tl"] else "TSRN"),
             "value": round(value, 1), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -526,7 +530,7 @@ def main():
                                                   "student instead of CRNN: NOT BASELINE's configuration"), "tpg": args.tpg, "batch_per_gpu": B, "global_batch": B * world,
                        "lr_hw": list(LR_HW), "hr_hw": [32, 128], "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if args.graph else "recorded plans, plain launches: main + weight-gradient + teacher streams",
-                       "kernel_launches_per_step": n_launch, "arithmetic": ARITH[K_POLICY],
+                       "kernel_launches_per_step": n_launch, "plan_ops_per_step": n_ops, "arithmetic": ARITH[K_POLICY],
                        "gradient_exchange": _exchange_note(ts, world, args.force_collectives)},
             "final_loss": round(final_loss, 5),
         }
