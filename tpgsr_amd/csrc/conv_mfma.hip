@@ -635,7 +635,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(tpgsr_wgrad_args w, int
 
 static void wgrad_plan(long long M, int K, int Cout, int* Z, int* MB) {
   int kb = cdiv(K, WK), nb = cdiv(Cout, BN);
-  long long target = 1024;  // ~4 blocks per CU
+  // ~4 blocks per CU (TPGSR_WGRAD_TARGET: experiment switch -- fewer, longer splits write fewer slabs for the reduce to read back)
+  static const long long target_env = [] { const char* e = getenv("TPGSR_WGRAD_TARGET"); return e ? atoll(e) : 0ll; }();
+  long long target = target_env > 0 ? target_env : 1024;
   long long z = (target + (long long)kb * nb - 1) / ((long long)kb * nb);
   long long maxz = (M + 255) / 256;  // at least 256 pixels per split
   if (maxz > 256) maxz = 256;
