@@ -574,7 +574,10 @@ def main():
             # timed region: what the faster headline arithmetic buys against the fp32-equivalent one
             K.set_conv_prec(args.alt_prec)
             ts2, _nets2 = build_step(args.config, dev, world, pg)
-            for _ in range(max(8, args.warmup)):      # fresh plans + first use of this policy's kernel instantiations (code-object loads)
+            # fresh plans + first use of this policy's kernel instantiations (code-object loads) -- and the GPU has just idled through the
+            # PMC passes' child processes: 40 steps (~0.3 s) bring its clocks back before the timed region (with 8, this line came out
+            # ~0.35 ms per step above the same policy measured as the headline of its own run: 7.05 vs 6.69 ms, gpurun_out/r05x3)
+            for _ in range(max(40, args.warmup)):
                 ts2.step(lr_img, hr_img)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
