@@ -327,6 +327,45 @@ def test_tail_fold_matches_conv9x9(prec):
     assert relerr(from_nhwc(dx, N, H, W, C), xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("W", [128, 200, 333])
+def test_tail_shiftsum_and_backward_rows_wider_than_one_workgroup(W):
+    """rows wider than the LDS block (W (KS Co + 1) > 5920 floats forward, W > 160 backward) are cut into chunks: the same sums in the same
+    order as the one-workgroup form -- checked EXACTLY against torch evaluating the same kw = 0 .. KS-1 sum in fp32"""
+    k = K()
+    N, H, Co, KS = 2, 3, 4, 9
+    NP, half = KS * Co, KS // 2
+    g = torch.Generator().manual_seed(41 + W)
+    P = torch.randn(N, H, W, NP, generator=g)
+    bias = torch.randn(Co, generator=g)
+    s = bias.view(1, 1, 1, Co).expand(N, H, W, Co).clone()
+    s0 = torch.zeros(N, H, W, Co)
+    Pp = F.pad(P.view(N, H, W, KS, Co), (0, 0, 0, 0, half, half))            # zero columns either side of the row
+    for kw in range(KS):                                                       # s[w] += P[w + kw - half][kw]
+        s = s + Pp[:, :, kw:kw + W, kw, :]
+        s0 = s0 + Pp[:, :, kw:kw + W, kw, :]
+    Pd, bd = P.to(DEV), bias.to(DEV)
+    out = torch.empty(N, Co, H, W, device=DEV)
+    k.tail_shiftsum_tanh(Pd, bd, N, H, W, Co, KS, out)
+    nh = torch.empty(N, H, W, Co, device=DEV)
+    k.shiftsum_nhwc(Pd, N, H, W, Co, KS, nh)
+    torch.cuda.synchronize()
+    assert torch.equal(nh.cpu(), s0)                                           # same addends, same order: same bits
+    assert relerr(out.cpu(), torch.tanh(s.double()).permute(0, 3, 1, 2)) < 2e-6
+    # backward: dP[n][h][x][kw Co + co] = dpre[n][co][h][x - kw + half]; the bias-gradient partials add up to dpre's sum
+    dout = torch.randn(N, Co, H, W, generator=g).to(DEV)
+    nblk = k.tail_bwd_blocks(N, H, W, Co, KS)
+    dP = torch.empty(N, H, W, NP, device=DEV); dbp = torch.empty(nblk, Co, device=DEV)
+    k.tail_bwd(out, dout, N, H, W, Co, KS, dP, dbp, nblk)
+    db = torch.zeros(Co, device=DEV)
+    k.reduce_partials(dbp, nblk, Co, db, accumulate=False)
+    torch.cuda.synchronize()
+    dpre = (dout * (1.0 - out * out)).cpu()                                    # same fp32 expression as the kernel
+    dpp = F.pad(dpre.permute(0, 2, 3, 1), (0, 0, half, half))                  # [N][H][W + 2 half][Co]
+    want = torch.stack([dpp[:, :, 2 * half - kw:2 * half - kw + W, :] for kw in range(KS)], dim=3).reshape(N, H, W, NP)
+    assert relerr(dP.cpu(), want) < 1e-6
+    assert relerr(db.cpu(), dpre.double().sum((0, 2, 3))) < 1e-5
+
+
 @pytest.mark.parametrize("act", ["none", "mish", "relu"])
 def test_bn_backward(act):
     k = K()

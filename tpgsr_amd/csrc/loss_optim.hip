@@ -7,60 +7,78 @@
 //
 // Round 5: ONE WORKGROUP PER IMAGE ROW (n, h).  The first form gave every output element a thread that decoded its position with three
 // 64-bit divisions and read its KS addends 144 bytes apart (33 us for 28 MB in, 3 MB out); here the row's [W][KS Co] block of P is staged
-// into LDS by coalesced 16-byte loads (row pitch KS Co + 1 floats: the strided reads that follow are conflict-free) and summed from there.
+// into LDS by coalesced 16-byte loads (row pitch KS Co + 1 floats: the strided reads that follow are conflict-free) and summed from there;
+// a row too wide for the LDS block is cut into chunks (one workgroup each).
 // The same code without bias / tanh into an NHWC map is tpgsr_shiftsum_nhwc (block1's folded data gradient).  Sums run kw = 0 .. KS-1
 // as before: same bits.
 // ------------------------------------------------------------------------------------------------------
 #define TAIL_MAX_ROW (160 * 37)      // floats of LDS per row: W (KS Co + 1) <= 5920 (the 32 x 128 output of the hot path: 128 x 37)
 
+// rows wider than the LDS block are cut into chunks of WC output columns (a workgroup per (row, chunk) stages WC + KS - 1 columns)
+static inline int tail_chunk(int W, int pitch, int half) {
+  if (W * pitch <= TAIL_MAX_ROW) return W;
+  return TAIL_MAX_ROW / pitch - 2 * half;
+}
+
 template <bool NCHW_TANH>
 __global__ __launch_bounds__(256) void shiftsum_row_kernel(const float* __restrict__ P, const float* __restrict__ bias, int H, int W, int Co,
-                                                           int KS, float* __restrict__ out) {
+                                                           int KS, int WC, int nchunk, float* __restrict__ out) {
   __shared__ float row[TAIL_MAX_ROW];
   const int NP = KS * Co, pitch = NP + 1, half = KS / 2;
-  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
-  const float* src = P + (size_t)blockIdx.x * W * NP;
-  for (int e = threadIdx.x; e < (W * NP) >> 2; e += 256) {      // (NP % 4 == 0: the folded operands' column counts are multiples of 4)
+  const int rid = blockIdx.x / nchunk, x0 = (blockIdx.x - rid * nchunk) * WC;      // (nchunk == 1 on the hot path)
+  const int n = rid / H, h = rid - n * H;
+  const int xs0 = max(0, x0 - half), xs1 = min(W, x0 + WC + half), wc = min(WC, W - x0);
+  const float* src = P + ((size_t)rid * W + xs0) * NP;
+  for (int e = threadIdx.x; e < ((xs1 - xs0) * NP) >> 2; e += 256) {      // (NP % 4 == 0: the folded operands' column counts are multiples of 4)
     const float4 v = *reinterpret_cast<const float4*>(src + 4 * e);
     const int x = (4 * e) / NP, c = 4 * e - x * NP;
     float* d = row + x * pitch + c;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < W * Co; e += 256) {
+  for (int e = threadIdx.x; e < wc * Co; e += 256) {
     int co, w;
     if (NCHW_TANH) {
-      co = e / W;
-      w = e - co * W;
+      co = e / wc;
+      w = e - co * wc;
     } else {
       w = e / Co;
       co = e - w * Co;
     }
+    w += x0;
     float s = (NCHW_TANH && bias) ? bias[co] : 0.f;
     for (int kw = 0; kw < KS; ++kw) {
       const int x = w + kw - half;
-      if ((unsigned)x < (unsigned)W) s += row[x * pitch + kw * Co + co];
+      if ((unsigned)x < (unsigned)W) s += row[(x - xs0) * pitch + kw * Co + co];
     }
     if (NCHW_TANH) out[(((size_t)n * Co + co) * H + h) * W + w] = tanh_f(s);
-    else out[((size_t)blockIdx.x * W + w) * Co + co] = s;
+    else out[((size_t)rid * W + w) * Co + co] = s;
   }
+}
+
+static int shiftsum_launch(const char* who, bool tail, const float* P, const float* bias, int N, int H, int W, int Co, int KS, float* out,
+                           void* stream) {
+  TPGSR_CHECK_ARG(P && out && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "%s: bad arguments", who);
+  const int pitch = KS * Co + 1, half = KS / 2, WC = tail_chunk(W, pitch, half);
+  TPGSR_CHECK_ARG(((KS * Co) & 3) == 0 && WC >= 1 && (((uintptr_t)P) & 15) == 0,
+                  "%s: needs KS Co %% 4 == 0, a 16-byte aligned P and KS (KS Co + 1) <= %d (got KS %d, Co %d)", who, TAIL_MAX_ROW, KS, Co);
+  const int nchunk = (W + WC - 1) / WC;
+  if (tail)
+    hipLaunchKernelGGL(shiftsum_row_kernel<true>, dim3(N * H * nchunk), dim3(256), 0, (hipStream_t)stream, P, bias, H, W, Co, KS, WC, nchunk,
+                       out);
+  else
+    hipLaunchKernelGGL(shiftsum_row_kernel<false>, dim3(N * H * nchunk), dim3(256), 0, (hipStream_t)stream, P, nullptr, H, W, Co, KS, WC,
+                       nchunk, out);
+  TPGSR_LAUNCH_CHECK(who);
 }
 
 extern "C" int tpgsr_tail_shiftsum_tanh(const float* P, const float* bias, int N, int H, int W, int Co, int KS,
                                         float* out_nchw, void* stream) {
-  TPGSR_CHECK_ARG(P && out_nchw && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "tpgsr_tail_shiftsum_tanh: bad arguments");
-  TPGSR_CHECK_ARG(((KS * Co) & 3) == 0 && W * (KS * Co + 1) <= TAIL_MAX_ROW && (((uintptr_t)P) & 15) == 0,
-                  "tpgsr_tail_shiftsum_tanh: needs KS Co %% 4 == 0 and W (KS Co + 1) <= %d floats per row (got W %d, KS %d, Co %d)", TAIL_MAX_ROW, W, KS, Co);
-  hipLaunchKernelGGL(shiftsum_row_kernel<true>, dim3(N * H), dim3(256), 0, (hipStream_t)stream, P, bias, H, W, Co, KS, out_nchw);
-  TPGSR_LAUNCH_CHECK("tpgsr_tail_shiftsum_tanh");
+  return shiftsum_launch("tpgsr_tail_shiftsum_tanh", true, P, bias, N, H, W, Co, KS, out_nchw, stream);
 }
 
 extern "C" int tpgsr_shiftsum_nhwc(const float* P, int N, int H, int W, int Co, int KS, float* out, void* stream) {
-  TPGSR_CHECK_ARG(P && out && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "tpgsr_shiftsum_nhwc: bad arguments");
-  TPGSR_CHECK_ARG(((KS * Co) & 3) == 0 && W * (KS * Co + 1) <= TAIL_MAX_ROW && (((uintptr_t)P) & 15) == 0,
-                  "tpgsr_shiftsum_nhwc: needs KS Co %% 4 == 0 and W (KS Co + 1) <= %d floats per row (got W %d, KS %d, Co %d)", TAIL_MAX_ROW, W, KS, Co);
-  hipLaunchKernelGGL(shiftsum_row_kernel<false>, dim3(N * H), dim3(256), 0, (hipStream_t)stream, P, nullptr, H, W, Co, KS, out);
-  TPGSR_LAUNCH_CHECK("tpgsr_shiftsum_nhwc");
+  return shiftsum_launch("tpgsr_shiftsum_nhwc", false, P, nullptr, N, H, W, Co, KS, out, stream);
 }
 
 // dP[n][h][x][kw*Co+co] = dpre[n][co][h][x-kw+KS/2], dpre = dout*(1-out^2); dbias partial per (n, h) row.
@@ -68,13 +86,15 @@ extern "C" int tpgsr_shiftsum_nhwc(const float* P, int N, int H, int W, int Co, 
 // on either side, the [W][KS Co] block of dP is written from there in coalesced order, and the bias-gradient partial of the row is each
 // channel's sum over w in a FIXED order (a shuffle tree per wave over a fixed assignment, the waves added in order -- until round 4's fix an
 // LDS atomicAdd: "the bit flip of round 3").  The first form spent its time in four 64-bit divisions per element (37 us).
+#define TAIL_BWD_WC 160      // output columns per workgroup (wider rows are cut into chunks; the hot path's 128 is one)
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, int H, int W, int Co,
-                                                       int KS, float* __restrict__ dP, float* __restrict__ dbp) {
-  __shared__ float dpre[8 * (160 + 16)];
-  const int NP = KS * Co, half = KS / 2, pitch = W + 2 * half;
-  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+                                                       int KS, int WC, int nchunk, float* __restrict__ dP, float* __restrict__ dbp) {
+  __shared__ float dpre[8 * (TAIL_BWD_WC + 16)];
+  const int NP = KS * Co, half = KS / 2;
+  const int rid = blockIdx.x / nchunk, x0 = (blockIdx.x - rid * nchunk) * WC, wc = min(WC, W - x0), pitch = wc + 2 * half;
+  const int n = rid / H, h = rid - n * H;
   for (int e = threadIdx.x; e < Co * pitch; e += 256) {
-    const int co = e / pitch, x = e - co * pitch - half;
+    const int co = e / pitch, x = x0 + e - co * pitch - half;
     float v = 0.f;
     if ((unsigned)x < (unsigned)W) {
       const size_t o = (((size_t)n * Co + co) * H + h) * W + x;
@@ -84,34 +104,38 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
     dpre[e] = v;
   }
   __syncthreads();
-  float* dst = dP + (size_t)blockIdx.x * W * NP;
-  for (int e = threadIdx.x; e < W * NP; e += 256) {
+  float* dst = dP + ((size_t)rid * W + x0) * NP;
+  for (int e = threadIdx.x; e < wc * NP; e += 256) {
     const int x = e / NP, np = e - x * NP;
     const int kw = np / Co, co = np - kw * Co;
-    dst[e] = dpre[co * pitch + (x - kw + half) + half];      // (the zero margins stand for the positions outside the row)
+    dst[e] = dpre[co * pitch + (x - kw + half) + half];      // (the margins: zeros outside the row, the neighbours' values inside it)
   }
   if (!dbp) return;                                    // (uniform)
-  // bias-gradient partial of the row: wave `wv` sums channel co over w = lane, lane + 64, ... for co = wv, wv + 4, ...
+  // bias-gradient partial of the (row, chunk): wave `wv` sums channel co over w = lane, lane + 64, ... for co = wv, wv + 4, ...
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int co = wave; co < Co; co += 4) {
     float s = 0.f;
-    for (int w = lane; w < W; w += 64) s += dpre[co * pitch + half + w];
+    for (int w = lane; w < wc; w += 64) s += dpre[co * pitch + half + w];
     s = wave_sum(s);
     if (lane == 0) dbp[(size_t)blockIdx.x * Co + co] = s;
   }
 }
 
+static inline int tail_bwd_chunks(int W) { return (W + TAIL_BWD_WC - 1) / TAIL_BWD_WC; }
+
 extern "C" int tpgsr_tail_bwd_blocks(int N, int H, int W, int Co, int KS) {
-  (void)W; (void)Co; (void)KS;
-  return N * H;      // one bias-gradient partial row per image row
+  (void)Co; (void)KS;
+  return N * H * tail_bwd_chunks(W);      // one bias-gradient partial row per (image row, chunk)
 }
 
 extern "C" int tpgsr_tail_bwd(const float* out_nchw, const float* dout_nchw, int N, int H, int W, int Co, int KS, float* dP,
                               float* dbias_partial, int nblk, void* stream) {
-  TPGSR_CHECK_ARG(out_nchw && dout_nchw && dP && Co <= 8 && (KS & 1) && KS <= 17 && W <= 160, "tpgsr_tail_bwd: bad arguments (Co <= 8, odd KS <= 17, W <= 160)");
-  const int grid = N * H;
+  TPGSR_CHECK_ARG(out_nchw && dout_nchw && dP && N > 0 && H > 0 && W > 0 && Co > 0 && Co <= 8 && (KS & 1) && KS <= 17,
+                  "tpgsr_tail_bwd: bad arguments (Co <= 8, odd KS <= 17)");
+  const int nchunk = tail_bwd_chunks(W), grid = N * H * nchunk;
   TPGSR_CHECK_ARG(!dbias_partial || nblk == grid, "tpgsr_tail_bwd: dbias_partial needs nblk == %d blocks (got %d)", grid, nblk);
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_nchw, dout_nchw, H, W, Co, KS, dP, dbias_partial);
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_nchw, dout_nchw, H, W, Co, KS,
+                     nchunk == 1 ? W : TAIL_BWD_WC, nchunk, dP, dbias_partial);
   TPGSR_LAUNCH_CHECK("tpgsr_tail_bwd");
 }
 
