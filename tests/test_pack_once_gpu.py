@@ -124,3 +124,20 @@ def test_graph_replay_then_eval_sees_the_updated_parameters():
         net._engine().invalidate_packed()
         fresh_out = net(lr).clone()
     assert torch.equal(stale, e1) and not torch.equal(fresh_out, e1)
+
+
+def test_pack_check_catches_a_write_behind_the_version_counters(monkeypatch):
+    """TPGSR_PACK_CHECK=1 (debugging aid): a skipped pack whose arena no longer holds the packed bits raises instead of
+    running on stale operands; after invalidate_packed() the forward packs again and passes"""
+    monkeypatch.setenv("TPGSR_PACK_CHECK", "1")
+    gray = torch.rand(2, 1, 32, 100, generator=torch.Generator().manual_seed(3)).to(DEV)
+    a, _ = _crnn(9)
+    with torch.no_grad():
+        y0 = a(gray).clone()
+        assert torch.equal(a(gray), y0)                      # unchanged: the check passes silently
+        next(a.parameters()).data.mul_(1.25)                 # no version counter moves
+        with pytest.raises(RuntimeError, match="invalidate_packed"):
+            a(gray)
+        a._engine().invalidate_packed()
+        y1 = a(gray).clone()
+    assert not torch.equal(y0, y1)

@@ -683,16 +683,31 @@ class _EngineBase:
     def pack_if_stale(self, pack_plan):
         capturing = (not K.DRYRUN) and torch.cuda.is_current_stream_capturing()   # a captured graph must contain its own pack
         key = self._param_key()
+        check = (not K.DRYRUN) and (not capturing) and os.environ.get("TPGSR_PACK_CHECK") == "1"
         if capturing or key != self._packed_key or os.environ.get("TPGSR_PACK_ALWAYS") == "1":
             pack_plan.run()
             self._packed_key = None if capturing else key
+            if check:
+                self._packed_sum = self._arena_checksum()
+        elif check and getattr(self, "_packed_sum", None) is not None and self._arena_checksum() != self._packed_sum:
+            # debugging aid: the pack was skipped on an unchanged key, yet the arena's bits are not those that were packed
+            raise RuntimeError(f"{type(self.module).__name__}: the parameters changed behind torch's version counters since the operands were "
+                               "packed (a write through p.data / a raw pointer / a flat arena view?) -- call module._engine().invalidate_packed() "
+                               "after such writes (TPGSR_PACK_CHECK=1 found this)")
+
+    def _arena_checksum(self):
+        """(TPGSR_PACK_CHECK=1 only: one device reduction + a host sync per eval forward) an order-independent fingerprint of the parameter
+        arena's BITS: the wrapping int64 sum of its words and of their squares' low bits"""
+        w = self.arena.flat.view(torch.int32).to(torch.int64)
+        return (int(w.sum().item()), int((w * w).sum().item()))
 
     def invalidate_packed(self):
         """The parameters changed in a way no version counter sees -- a write through `p.data` (`p.data.copy_/mul_/clamp_`: EMA, weight
         clipping), through a raw pointer or a flat view of the arena, a hipGraph replay containing the optimiser: the next eval-mode
         forward re-packs its operands.  FusedAdam, the flat broadcasts and the train steps' `replay()` call this themselves
         (`load_state_dict` / `p.copy_` bump torch's version counters, which the key sums); code that writes parameters behind torch's back must too (`module._engine().invalidate_packed()`).
-        TPGSR_PACK_ALWAYS=1 re-packs on every forward (debugging aid)."""
+        TPGSR_PACK_ALWAYS=1 re-packs on every forward; TPGSR_PACK_CHECK=1 fingerprints the arena at every pack and raises when a skipped pack
+        finds other bits (debugging aids)."""
         self._kernel_writes += 1
         self._packed_key = None
 
