@@ -26,6 +26,19 @@ extern "C" int tpgsr_gru_gate_math_probe(const float* x, float* sg, float* th, i
   TPGSR_LAUNCH_CHECK("tpgsr_gru_gate_math_probe");
 }
 
+// LAB BUILDS ONLY (-DTPGSR_LAB, tools/lab/gru_bwd_probe.py): parts of bigru_bwd_kernel switched off to time the rest -- bit 0 = operands not
+// loaded (constants), 1 = nothing stored, 2 = no LDS exchange / W_hh^T product (dh_carry = dh z), 3 = no time steps at all (launch + W_hh
+// load).  Results are garbage with any bit set.
+#ifdef TPGSR_LAB
+__device__ int g_gru_dbg = 0;
+extern "C" int tpgsr_gru_debug(int bits) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gru_dbg), &bits, sizeof(bits)) == hipSuccess ? 0 : TPGSR_ERR_LAUNCH;
+}
+#define GRU_DBG() __builtin_amdgcn_readfirstlane(g_gru_dbg)
+#else
+#define GRU_DBG() 0
+#endif
+
 // EXACT: T is a multiple of PF (both scan lengths of the 16 x 64 map with the default PF = 8): no per-step bounds tests, the ring's
 // refill is switched off per group of PF steps.  Offsets are running 32-bit element indices advanced by a constant per step.
 template <int PF, bool EXACT>
@@ -95,10 +108,10 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
       }
       const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
       const float an = bn + (nn.x + nn.y);
-      const float r = gru_sigmoid(c.r + (br + rz.x));
-      const float z = gru_sigmoid(c.z + (bz + rz.y));
-      const float n = gru_tanh(c.n + r * an);
-      h = (1.f - z) * n + z * h;
+      const f2 sg = gru_sigmoid2(mk2(c.r + (br + rz.x), c.z + (bz + rz.y)));      // both gates in lock step (gru_common.h)
+      const float r = sg.x, z = sg.y;
+      const float n = gru_tanh(__builtin_fmaf(r, an, c.n));
+      h = __builtin_fmaf(z, h, (1.f - z) * n);      // (explicit: the same contraction in every kernel that runs this step)
       hs[(i + 1) & 1][lane] = h;
       h_out[pix * 64 + d * 32 + j] = h;
       if (gates) {
@@ -164,7 +177,15 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < GRU_H / 2; ++i)
     tn2[i] = mk2(w_hh[((size_t)(d * 96 + 2 * 32 + 2 * i)) * GRU_H + j], w_hh[((size_t)(d * 96 + 2 * 32 + 2 * i + 1)) * GRU_H + j]);
+  const int dbg = GRU_DBG();      // (0 in a release build)
   const int T = g.T;
+  if (dbg & 8) {      // (the loads above must stay alive)
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < GRU_H; ++i) acc += trz[i].x + trz[i].y + (i < GRU_H / 2 ? tn2[i].x + tn2[i].y : 0.f);
+    if (acc == 12345.678f) dgi[0] = acc;
+    return;
+  }
   float dh_carry = 0.f;
   // steps run from the direction's LAST step to its first; dpix = pixel step in that order (the previous state sits one step further)
   const int dpix = d == 0 ? -g.stride : g.stride;
@@ -179,6 +200,12 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
     StepIn s;
     s.hprev = 0.f;
     s.dho2 = 0.f;
+    if (dbg & 1) {
+      s.r = 0.4f; s.z = 0.6f; s.n = 0.1f; s.an = 0.2f; s.dho = 0.3f;
+      fpix += dpix;
+      --fstep;
+      return s;
+    }
     if (fstep > 0) s.hprev = h_out[(fpix + dpix) * 64 + d * 32 + j];
     const float* p = gates + fpix * 256 + d * 128 + j;
     s.r = p[0]; s.z = p[32]; s.n = p[64]; s.an = p[96];
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
       const int par = i & 1;                     // (PF is even; only the alternation matters)
       *reinterpret_cast<float2*>(&g_rz[par][d][2 * j]) = make_float2(dr_pre, dz_pre);
       g_n[par][lane] = dghn;
-      {
+      if (!(dbg & 2)) {
         float* q = dgi + pix * 192 + d * 96 + j;
         q[0] = dr_pre; q[32] = dz_pre; q[64] = dn_pre;
         if (COMPACT) {
@@ -220,6 +247,10 @@ __global__ __launch_bounds__(64) void bigru_bwd_kernel(const float* __restrict__
         }
       }
       pix += dpix;
+      if (dbg & 4) {
+        dh_carry = dh * c.z + dghn;
+        continue;
+      }
       __builtin_amdgcn_wave_barrier();   // one wave: its LDS operations execute in order; the parity double buffer is kept anyway
       const float4* prz = reinterpret_cast<const float4*>(&g_rz[par][d][0]);
       const float4* pn = reinterpret_cast<const float4*>(&g_n[par][d * 32]);

@@ -52,19 +52,6 @@ __device__ __forceinline__ float gru_rcp(float d) {      // d finite, |d| in [2^
   const float r = __builtin_amdgcn_rcpf(d);
   return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
 }
-__device__ __forceinline__ float gru_sigmoid(float x) { return gru_rcp(1.f + gru_exp(fminf(-x, 80.f))); }
-__device__ __forceinline__ float gru_tanh(float x) {
-  const float q = gru_exp(-2.f * fabsf(x));
-  const float big = (1.f - q) * gru_rcp(1.f + q);
-  const float x2 = x * x;
-  float p = __builtin_fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
-  p = __builtin_fmaf(x2, p, -17.f / 315.f);
-  p = __builtin_fmaf(x2, p, 2.f / 15.f);
-  p = __builtin_fmaf(x2, p, -1.f / 3.f);
-  p = __builtin_fmaf(x2, p, 1.f);
-  return fabsf(x) < 0.35f ? x * p : copysignf(big, x);
-}
-
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 mk2(float x, float y) {
@@ -72,4 +59,37 @@ __device__ __forceinline__ f2 mk2(float x, float y) {
   v.x = x;
   v.y = y;
   return v;
+}
+
+// TWO sigmoids in lock step (the r and z gates of a time step), component for component the operations of gru_rcp(1 + gru_exp(min(-x, 80)))
+// as packed instructions (v_pk_mul / v_pk_fma / v_pk_add; v_exp and v_rcp back to back).  A lone wave pays ~10 cycles per DEPENDENT VALU
+// instruction and 3-5 per independent one (tools/lab/valu_rate.hip): the two sigmoids one after the other -- the compiler even scheduled the
+// second one behind the tanh that needs only the first -- were ~250 cycles of a ~1350-cycle step; in lock step they are one chain.
+__device__ __forceinline__ f2 gru_sigmoid2(f2 x) {
+  const f2 nx = mk2(fminf(-x.x, 80.f), fminf(-x.y, 80.f));
+  const f2 l2e = mk2(1.44269504088896341f, 1.44269504088896341f);
+  const f2 t = nx * l2e;
+  f2 lo = pk_fma(nx, l2e, -t);
+  lo = pk_fma(nx, mk2(1.925963033500011e-08f, 1.925963033500011e-08f), lo);
+  const f2 e = mk2(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y));
+  const f2 d = mk2(1.f, 1.f) + pk_fma(e, lo * mk2(0.6931471805599453f, 0.6931471805599453f), e);
+  const f2 r = mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+  return pk_fma(pk_fma(-d, r, mk2(1.f, 1.f)), r, r);
+}
+__device__ __forceinline__ float gru_sigmoid(float x) { return gru_sigmoid2(mk2(x, x)).x; }
+// BRANCH-FREE: both forms are computed and one is selected.  Left to itself the compiler sinks them into the two sides of a divergent
+// branch (s_cbranch_execz): a scheduling barrier in the middle of the step, with both sides executed by every wave anyway (the lanes of a
+// wave are 64 different hidden units).  The empty asm pins both values in front of the select.
+__device__ __forceinline__ float gru_tanh(float x) {
+  const float q = gru_exp(-2.f * fabsf(x));
+  float big = (1.f - q) * gru_rcp(1.f + q);
+  const float x2 = x * x;
+  float p = __builtin_fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
+  p = __builtin_fmaf(x2, p, -17.f / 315.f);
+  p = __builtin_fmaf(x2, p, 2.f / 15.f);
+  p = __builtin_fmaf(x2, p, -1.f / 3.f);
+  p = __builtin_fmaf(x2, p, 1.f);
+  float small = x * p;
+  asm volatile("" : "+v"(small), "+v"(big));
+  return fabsf(x) < 0.35f ? small : copysignf(big, x);
 }

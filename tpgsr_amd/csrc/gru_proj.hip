@@ -202,10 +202,10 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     }
     const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
     const float an = bn + (nn.x + nn.y);
-    const float r = gru_sigmoid(ir + (br + rz.x));
-    const float z = gru_sigmoid(iz + (bz + rz.y));
-    const float n = gru_tanh(in_ + r * an);
-    h = (1.f - z) * n + z * h;
+    const f2 sg = gru_sigmoid2(mk2(ir + (br + rz.x), iz + (bz + rz.y)));      // both gates in lock step (gru_common.h)
+    const float r = sg.x, z = sg.y;
+    const float n = gru_tanh(__builtin_fmaf(r, an, in_));
+    h = __builtin_fmaf(z, h, (1.f - z) * n);      // (explicit: the same contraction in every kernel that runs this step)
     hs[((step + 1) & 1) * 64 + lane] = h;
     p.h_out[pix * 64 + d * 32 + j] = h;
     if (TRAIN) {
