@@ -27,6 +27,20 @@
 
 #define GP_RS 196     // floats per gi row in LDS
 
+// LAB BUILDS ONLY (-DTPGSR_LAB, tools/lab/gp_probe.py): parts of the kernel switched off to time the rest -- bit 0 = no scan (wave 0 leaves
+// after the barrier), 1 = the panel is not loaded (zeros), 2 = no MFMAs / gi stores of phase 2, 3 = W_hh not loaded (constants), 4 = the scan
+// stores nothing to global memory, 5 = the scan's gate math replaced by two multiplies.  Results are garbage with any bit set; in a release
+// build the switch is the constant 0 and every test of it folds away (the ISA is the same with and without these lines).
+#ifdef TPGSR_LAB
+__device__ int g_gp_dbg = 0;
+extern "C" int tpgsr_gp_debug(int bits) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gp_dbg), &bits, sizeof(bits)) == hipSuccess ? 0 : TPGSR_ERR_LAUNCH;
+}
+#define GP_DBG() __builtin_amdgcn_readfirstlane(g_gp_dbg)
+#else
+#define GP_DBG() 0
+#endif
+
 __device__ __forceinline__ floatx4 gp_mfma(const bf16x8 a, const bf16x8 b, const floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -59,6 +73,7 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
   const SeqGeom g = seq_geom(blockIdx.x, a.N, a.H, a.W, p.axis);
   if (!g.active) return;        // (workgroup-uniform)
   const int l16 = lane & 15, kq = lane >> 4;
+  const int dbg = GP_DBG();
 
   // ---- phase 1: the panel as split MFMA fragments: xf[rt][ks][term] = 8 channels 32 ks + 8 kq .. of time step 16 rt + l16 ----
   bf16x8 xf[NRT][NKS][TT];
@@ -77,6 +92,10 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
           src = a.in_b + (size_t)(n * a.W + w) * a.in_b_ld + (c - a.cin_a);
         } else {
           src = a.in + (size_t)pix * a.in_ld + a.in_coff + c;
+        }
+        if (dbg & 2) {
+          lo[rt][ks] = hi[rt][ks] = lo2[rt][ks] = hi2[rt][ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+          continue;
         }
         lo[rt][ks] = *reinterpret_cast<const float4*>(src);
         hi[rt][ks] = *reinterpret_cast<const float4*>(src + 4);
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     // as fragments -- the three redundant panel loads hit the L1 -- so nothing is exchanged before the barrier below); alone, one wave
     // spent ~8 us here before its scan could start, with the other three SIMDs of the CU idle
     const int nw = blockDim.x >> 6;
-    for (int ct = wave; ct < 12; ct += nw) {
+    for (int ct = wave; ct < 12 && !(dbg & 4); ct += nw) {
       bf16x8 wf[NKS][TT];
       const unsigned wbase = ((unsigned)(ct >> 1) * KB16) * 1024u + (unsigned)(ct & 1) * 256u + wlane;
 #pragma unroll
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
   }
 
   __syncthreads();      // all of gi is in LDS
-  if (wave != 0) return;      // the scan is one wave's work (LDS stays allocated until it is through)
+  if (wave != 0 || (dbg & 1)) return;      // the scan is one wave's work (LDS stays allocated until it is through)
 
   // ---- phase 3: the scan (bigru_fwd_kernel of gru.hip, the inputs out of LDS) ----
   const int d = lane >> 5, j = lane & 31;
@@ -167,10 +186,17 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     const float* pr = p.w_hh + ((size_t)(d * 96 + 0 * 32 + j)) * GRU_H;
     const float* pz = p.w_hh + ((size_t)(d * 96 + 1 * 32 + j)) * GRU_H;
     const float* pn = p.w_hh + ((size_t)(d * 96 + 2 * 32 + j)) * GRU_H;
+    if (dbg & 8) {
 #pragma unroll
-    for (int k = 0; k < GRU_H; ++k) wrz[k] = mk2(pr[k], pz[k]);
+      for (int k = 0; k < GRU_H; ++k) wrz[k] = mk2(0.01f * k, 0.02f);
 #pragma unroll
-    for (int k = 0; k < GRU_H / 2; ++k) wn2[k] = mk2(pn[2 * k], pn[2 * k + 1]);
+      for (int k = 0; k < GRU_H / 2; ++k) wn2[k] = mk2(0.03f, 0.01f * k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < GRU_H; ++k) wrz[k] = mk2(pr[k], pz[k]);
+#pragma unroll
+      for (int k = 0; k < GRU_H / 2; ++k) wn2[k] = mk2(pn[2 * k], pn[2 * k + 1]);
+    }
   }
   const float br = p.b_hh[d * 96 + j], bz = p.b_hh[d * 96 + 32 + j], bn = p.b_hh[d * 96 + 64 + j];
   float h = 0.f;
@@ -202,13 +228,20 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     }
     const f2 rz = (a0 + a1) + (a2 + a3), nn = n0 + n1;
     const float an = bn + (nn.x + nn.y);
-    const f2 sg = gru_sigmoid2(mk2(ir + (br + rz.x), iz + (bz + rz.y)));      // both gates in lock step (gru_common.h)
+    f2 sg;
+    float n;
+    if (dbg & 32) {
+      sg = mk2(ir + (br + rz.x), iz + (bz + rz.y)) * mk2(0.25f, 0.25f);
+      n = __builtin_fmaf(sg.x, an, in_) * 0.5f;
+    } else {
+      sg = gru_sigmoid2(mk2(ir + (br + rz.x), iz + (bz + rz.y)));      // both gates in lock step (gru_common.h)
+      n = gru_tanh(__builtin_fmaf(sg.x, an, in_));
+    }
     const float r = sg.x, z = sg.y;
-    const float n = gru_tanh(__builtin_fmaf(r, an, in_));
     h = __builtin_fmaf(z, h, (1.f - z) * n);      // (explicit: the same contraction in every kernel that runs this step)
     hs[((step + 1) & 1) * 64 + lane] = h;
-    p.h_out[pix * 64 + d * 32 + j] = h;
-    if (TRAIN) {
+    if (!(dbg & 16)) p.h_out[pix * 64 + d * 32 + j] = h;
+    if (TRAIN && !(dbg & 16)) {
       float* q = p.gates + pix * 256 + d * 128 + j;
       q[0] = r; q[32] = z; q[64] = n; q[96] = an;
     }
