@@ -29,6 +29,16 @@ def test_header_symbols_exported(lib):
     assert not missing, missing
 
 
+def test_release_build_has_no_lab_switches(lib):
+    """the kernels' debug switches (parts of a kernel switched off for timing: results are garbage with any bit set) exist in LAB builds only
+    (-DTPGSR_LAB, tools/lab/*_probe.py): a release library neither exports them nor declares them"""
+    if os.environ.get("TPGSR_LAB"):
+        pytest.skip("this IS a lab build")
+    for name in ("tpgsr_wgh_debug", "tpgsr_gp_debug", "tpgsr_gru_debug"):
+        assert not hasattr(lib, name), f"{name} is exported by a release build"
+        assert name not in declared_symbols()
+
+
 def test_binding_table_matches_header():
     from tpgsr_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
