@@ -1,0 +1,84 @@
+"""CPU: host logic changed in round 6 (dry-run plans, no GPU):
+  * three-channel networks (mask=False, the reference's `--mask` default) record again: block1's folded data gradient and the tail take any
+    channel count;
+  * TPGSR_LEAF_EARLY=1 together with the text strip's gradient on the leaf stream: the leaf -> caller edge is recorded BEFORE the early leaf
+    section opens, so the InfoGen backward never reads dtemb unordered."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+_MASK_FALSE = r'''
+import json, sys, torch
+sys.path.insert(0, %(root)r)
+from oracle import tpgsr_oracle as O
+from tpgsr_amd import kernels as K
+assert K.DRYRUN
+from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+from tpgsr_amd.model import tsrn
+out = {}
+for stn in (True, False):
+    sr = tsrn.TSRN(STN=stn, mask=False).train()
+    lr, hr = O.synthetic_batch(2, 1)
+    ts = TSRNTrainStep(sr)
+    ts.step(lr[:, :3].contiguous(), hr[:, :3].contiguous())
+    pl = [p for p in sr._engine()._plans.values() if "bwd" in p and len(p["bwd"])][0]
+    fwd, bwd = [op[0] for op in pl["fwd"].ops], [op[0] for op in pl["bwd"].ops]
+    out["stn%%d" %% stn] = dict(tail=fwd.count("tpgsr_tail_shiftsum_tanh"), folded=bwd.count("tpgsr_shiftsum_nhwc"), tail_bwd=bwd.count("tpgsr_tail_bwd"))
+print("JSON" + json.dumps(out))
+'''
+
+_LEAF_EARLY = r'''
+import json, sys, torch
+sys.path.insert(0, %(root)r)
+from oracle import tpgsr_oracle as O
+from tpgsr_amd import kernels as K
+assert K.DRYRUN
+from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+from tpgsr_amd.model import tsrn
+from tpgsr_amd.model.crnn import crnn
+sr = tsrn.TSRN_TL(STN=True, mask=True).train()
+teacher, stu = crnn.CRNN(32, 1, 37, 256).eval(), crnn.CRNN(32, 1, 37, 256).train()
+lr, hr = O.synthetic_batch(4, 1)
+ts = TPGSRTrainStep([sr], [stu], teacher, stu_iter=1)
+ts.step(lr, hr)
+pl = [p for p in sr._engine()._plans.values() if "bwd" in p and len(p["bwd"])][0]
+bwd = pl["bwd"].ops
+hs = [i for i, op in enumerate(bwd) if op[0] == "tpgsr_hsum"]
+joins = [i for i, op in enumerate(bwd) if op[0] == "edge" and tuple(op[2]) == (2, 0)]
+first_ig = min(i for i, op in enumerate(bwd) if op[0] == "tpgsr_strip_resample_bwd")
+out = dict(hsum_streams=[bwd[i][3] for i in hs], joins_after_last_hsum_before_infogen=[j for j in joins if max(hs) < j < first_ig],
+           infogen_stream=bwd[first_ig][3], n_leaf_ops_between=sum(1 for op in bwd[max(hs) + 1:first_ig] if op[0].startswith("tpgsr_") and op[3] == 2))
+print("JSON" + json.dumps(out))
+'''
+
+
+def _run(script, **env):
+    e = dict(os.environ, TPGSR_PLAN_DRYRUN="1", **env)
+    e.pop("TPGSR_CONV_PREC", None)
+    r = subprocess.run([sys.executable, "-c", script % dict(root=ROOT)], capture_output=True, text=True, env=e, timeout=550)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("JSON")][-1][4:])
+
+
+@pytest.mark.timeout(600)
+def test_three_channel_networks_record_a_train_step():
+    """TSRN(mask=False) -- in_planes 3, the reference's default (main.py: `--mask` is a store_true flag; model/tsrn.py:24-26) -- with and
+    without the STN: the plans record (round 5's FoldedDgrad asserted KS Ci % 4 == 0 and the shift-sum launcher rejected KS Co = 27)."""
+    res = _run(_MASK_FALSE)
+    assert res["stn1"] == dict(tail=1, folded=1, tail_bwd=1), res
+    assert res["stn0"] == dict(tail=1, folded=0, tail_bwd=1), res
+
+
+@pytest.mark.timeout(600)
+def test_leaf_early_with_the_strip_on_the_leaf_stream_orders_dtemb():
+    """TPGSR_LEAF_EARLY=1 + TPGSR_LEAF_STRIP=1 (default): the strip's H-sums run on the leaf stream (2), block 0's part of the backward pass
+    follows on the leaf stream as well, and a 2 -> 0 edge sits between the last H-sum and the InfoGen backward (caller's stream)."""
+    res = _run(_LEAF_EARLY, TPGSR_LEAF_EARLY="1")
+    assert res["hsum_streams"] == [2] * 5, res
+    assert res["infogen_stream"] == 0 and res["n_leaf_ops_between"] > 0, res
+    assert len(res["joins_after_last_hsum_before_infogen"]) >= 1, res

@@ -29,11 +29,18 @@ __global__ __launch_bounds__(256) void shiftsum_row_kernel(const float* __restri
   const int n = rid / H, h = rid - n * H;
   const int xs0 = max(0, x0 - half), xs1 = min(W, x0 + WC + half), wc = min(WC, W - x0);
   const float* src = P + ((size_t)rid * W + xs0) * NP;
-  for (int e = threadIdx.x; e < ((xs1 - xs0) * NP) >> 2; e += 256) {      // (NP % 4 == 0: the folded operands' column counts are multiples of 4)
-    const float4 v = *reinterpret_cast<const float4*>(src + 4 * e);
-    const int x = (4 * e) / NP, c = 4 * e - x * NP;
-    float* d = row + x * pitch + c;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  if ((NP & 3) == 0) {      // (workgroup-uniform) the hot path: KS Co = 36, rows start 16-byte aligned and a 16-byte group never straddles two pixels
+    for (int e = threadIdx.x; e < ((xs1 - xs0) * NP) >> 2; e += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * e);
+      const int x = (4 * e) / NP, c = 4 * e - x * NP;
+      float* d = row + x * pitch + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {                  // any other column count (three-channel networks, mask=False: KS Co = 27): element by element, still coalesced
+    for (int e = threadIdx.x; e < (xs1 - xs0) * NP; e += 256) {
+      const int x = e / NP;
+      row[x * pitch + (e - x * NP)] = src[e];
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < wc * Co; e += 256) {
@@ -60,8 +67,8 @@ static int shiftsum_launch(const char* who, bool tail, const float* P, const flo
                            void* stream) {
   TPGSR_CHECK_ARG(P && out && N > 0 && H > 0 && W > 0 && Co > 0 && (KS & 1), "%s: bad arguments", who);
   const int pitch = KS * Co + 1, half = KS / 2, WC = tail_chunk(W, pitch, half);
-  TPGSR_CHECK_ARG(((KS * Co) & 3) == 0 && WC >= 1 && (((uintptr_t)P) & 15) == 0,
-                  "%s: needs KS Co %% 4 == 0, a 16-byte aligned P and KS (KS Co + 1) <= %d (got KS %d, Co %d)", who, TAIL_MAX_ROW, KS, Co);
+  TPGSR_CHECK_ARG(WC >= 1 && (((uintptr_t)P) & 15) == 0,
+                  "%s: needs a 16-byte aligned P and KS (KS Co + 1) <= %d (got KS %d, Co %d)", who, TAIL_MAX_ROW, KS, Co);
   const int nchunk = (W + WC - 1) / WC;
   if (tail)
     hipLaunchKernelGGL(shiftsum_row_kernel<true>, dim3(N * H * nchunk), dim3(256), 0, (hipStream_t)stream, P, bias, H, W, Co, KS, WC, nchunk,

@@ -230,7 +230,7 @@ class FoldedDgrad:
     def __init__(self, eng, wname: str):
         w = eng.P[wname]
         self.Cout, self.Ci, self.KS = w.shape[0], w.shape[1], w.shape[2]
-        assert w.shape[2] == w.shape[3] and self.KS % 2 == 1 and (self.KS * self.Ci) % 4 == 0
+        assert w.shape[2] == w.shape[3] and self.KS % 2 == 1      # (any channel count: the shift-sum stages rows element by element when KS Ci % 4 != 0)
         self.NP = self.KS * self.Ci
         self.wt = torch.empty(self.KS * self.Cout, self.NP, dtype=F32, device=eng.device)
         eng.add_pack(w, self.wt, None, Cout=self.Cout, Cin=self.Ci, KH=self.KS, KW=self.KS, kind=7)
@@ -1125,7 +1125,12 @@ class TSRNEngine(_EngineBase):
             if i == 0 and self.leaf_early:
                 # Everything below only feeds parameter gradients (block 0's convolutions, block1, the STN head): the text-strip gradient
                 # dtemb is final here, so the caller's stream goes straight on to the InfoGen backward and the text-prior generator's
-                # backward pass while this tail runs on the leaf stream
+                # backward pass while this tail runs on the leaf stream.  With the text strip's gradient on the leaf stream (leaf_strip) the
+                # caller's stream must first see block 0's strip section finish: the 2 -> 0 edge goes in HERE, while this recording is
+                # still on the caller's stream (leaf_join() is a no-op once the leaf section is open, and the InfoGen backward reads dtemb
+                # on the caller's stream after the section closes -- ADVICE round 5)
+                if self.tl and self.leaf_strip:
+                    K.leaf_join()
                 leaf.enter_context(K.leaf())
             dy = buf("dy", p + "c2_", Cc)
             L["bn2"].backward(da, None, y2, P1, "none", dy, fused=fz2)
