@@ -107,6 +107,59 @@ def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False, tpg="crn
     return ts, [sr] + students + [teacher]
 
 
+def module_api_bench(cfg_key, dev, images_lr, images_hr, steps=20, warmup=6):
+    """One C3 step as a user of the REFERENCE writes it (interfaces/super_resolution.py:295-424, verbatim but for the imports): the drop-in
+    modules driven by torch autograd, `clip_grad_norm_` and `torch.optim.Adam` -- tests/test_crnn_gpu.py::test_dropin_module_api_c3_step is
+    the same loop against the reference's recorded numbers.  Same networks / weights recipe / batch as the fused step of this line."""
+    from tpgsr_amd.interfaces.super_resolution import parse_crnn_data
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    from tpgsr_amd.loss.semantic_loss import SemanticLoss
+    from tpgsr_amd.model import tsrn
+    from tpgsr_amd.model.crnn import crnn
+    from tpgsr_amd.utils.synthetic import init_by_recipe
+    model = init_by_recipe(tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32), 11).to(dev).train()
+    aster = init_by_recipe(crnn.CRNN(32, 1, 37, 256), 12).to(dev).eval()           # the frozen teacher (the reference calls it `aster`)
+    stu_model = init_by_recipe(crnn.CRNN(32, 1, 37, 256), 13).to(dev).train()
+    for q in aster.parameters():
+        q.requires_grad = False
+    image_crit, sem_loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4]), SemanticLoss()
+    optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu_model.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    drop_vec = torch.ones(images_lr.shape[0]).float()
+    drop_vec[:int(images_lr.shape[0] // 4)] = 0.
+    drop_vec = drop_vec.to(dev).view(-1, 1, 1, 1)
+
+    def loop_body():
+        label_vecs_hr = torch.nn.functional.softmax(aster(parse_crnn_data(images_hr[:, :3, :, :])).detach(), -1)
+        label_vecs_logits = stu_model(parse_crnn_data(images_lr[:, :3, :, :]))
+        label_vecs = torch.nn.functional.softmax(label_vecs_logits, -1)
+        label_vecs_final = label_vecs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+        loss_recog_distill = sem_loss(label_vecs, label_vecs_hr) * 100
+        label_vecs_final = label_vecs_final * drop_vec
+        cascade_images = model(images_lr, label_vecs_final)
+        loss_img = image_crit(cascade_images, images_hr).mean() * 100
+        loss_im = loss_img + loss_recog_distill
+        optimizer_G.zero_grad()
+        loss_im.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+        optimizer_G.step()
+        return loss_im
+
+    for _ in range(warmup):
+        loop_body()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = loop_body()
+    t_sub = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    B = images_lr.shape[0]
+    return {"workload": "the same C3 step as the reference's loop body on the drop-in nn.Modules (model(images_lr, prior), loss.backward(), "
+                        "clip_grad_norm_, torch.optim.Adam.step): autograd hands the HIP plans over, ATen runs softmax / permute / the per-tensor Adam",
+            "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4), "value": round(B * steps / dt, 1), "unit": "img/s",
+            "host_submission_ms_per_step": round(1e3 * t_sub / steps, 4), "final_loss": round(float(loss.item()), 5), "arithmetic_policy": K_POLICY}
+
+
 def _exchange_note(ts, world, forced):
     if world == 1 and not forced:
         return None
@@ -425,6 +478,7 @@ def main():
                          "faster because ROCm executes the graph's fork/join branches serially)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-module-api", action="store_true", help="skip the `module_api` leg (the reference's loop body on the drop-in modules: torch autograd + torch.optim.Adam)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic (~1 min)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--eval", action="store_true", help="time the EVALUATION pass instead (TextSREvaluator.eval_batch, bs 48, one GPU): its own "
@@ -616,6 +670,14 @@ def main():
                 del ts3, _n3
             except Exception as e:      # reported, never hidden
                 out["tpg_opt"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if world == 1 and cfg["tl"] and cfg["stu_iter"] == 1 and args.tpg == "crnn" and not args.no_module_api:
+            # THE DROP-IN PATH: the reference's own loop body (interfaces/super_resolution.py:295-424) on the module API -- model(images_lr, prior),
+            # loss.backward() through torch autograd, clip_grad_norm_, torch.optim.Adam.step -- instead of the fused TPGSRTrainStep above
+            try:
+                out["module_api"] = module_api_bench(args.config, dev, lr_img, hr_img, steps=20, warmup=6)
+                out["module_api"]["vs_fused_step"] = round(out["module_api"]["ms_per_step"] / ms, 3)
+            except Exception as e:      # reported, never hidden
+                out["module_api"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args.config)

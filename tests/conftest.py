@@ -34,3 +34,30 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+class _GoldenPolicy:
+    """what a reference-fixture test needs to know about the arithmetic policy it runs under"""
+
+    def __init__(self, name):
+        self.name = name
+        # two-term split operands carry 16 significand bits: 3 * 2^-18 ~ 1.1e-5 per product at worst, ~4e-6 typically (DESIGN 4.1), against
+        # ~1e-7 of the fp32-equivalent policy.  Forward-value tolerances written for x3 are widened by this factor under x2; the gates that
+        # the north star sets (PSNR within 1e-3 dB, identical arg-max priors) and the gradient-NORM tolerances are NOT widened.
+        self.fwd = 1.0 if name == "x3" else 8.0
+
+    def tol(self, x3_tolerance):
+        return x3_tolerance * self.fwd
+
+
+@pytest.fixture(params=["x3", "x2"])
+def golden_policy(request):
+    """The tests against data the REFERENCE produced (tests/golden/model_*.npz, op_*.npz, train_c3.npz) run under the fp32-equivalent
+    policy AND under the benchmarked two-term policy (until round 6 `x2` was checked through the oracle only)."""
+    from tpgsr_amd import kernels as K
+    prev = K.POLICY
+    K.set_conv_prec(request.param)
+    try:
+        yield _GoldenPolicy(request.param)
+    finally:
+        K.set_conv_prec(prev)

@@ -82,3 +82,29 @@ def test_leaf_early_with_the_strip_on_the_leaf_stream_orders_dtemb():
     assert res["hsum_streams"] == [2] * 5, res
     assert res["infogen_stream"] == 0 and res["n_leaf_ops_between"] > 0, res
     assert len(res["joins_after_last_hsum_before_infogen"]) >= 1, res
+
+
+@pytest.mark.timeout(900)
+def test_no_scan_instruction_takes_its_low_half_from_the_odd_register_of_an_lds_pair():
+    """Root cause of round 5's unrepeatable GruBlock forward (profiles/r06_gru_proj_root_cause.md): `v_pk_fma_f32 ... op_sel:[0,1,0]` on a
+    register pair a ds_read_b128 had just returned read the odd register as zero in lanes 48-63 under three scanning waves per SIMD.  The
+    scans build (v, v) from odd components through a v_mov (gru_common.h: gru_dup_odd).  This compiles the two scan sources for gfx950
+    (no GPU needed) and checks that NO packed instruction carries an op_sel that selects the high register for the low half."""
+    import re
+    import tempfile
+    from tpgsr_amd import build as B
+    csrc = os.path.join(ROOT, "tpgsr_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        procs = []
+        for src in ("gru.hip", "gru_proj.hip"):
+            out = os.path.join(td, src + ".s")
+            cmd = [B._hipcc()] + B.FLAGS + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", out]
+            procs.append((src, out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        for src, out, p in procs:
+            log, _ = p.communicate(timeout=850)
+            assert p.returncode == 0, log.decode()[-3000:]
+            isa = open(out).read()
+            packed = re.findall(r"^\s*v_pk_\w+ .*$", isa, flags=re.M)
+            assert len(packed) > 100, (src, len(packed))             # the scans ARE packed multiply-adds
+            bad = [ln.strip() for ln in packed if re.search(r"op_sel:\[(0|1),1", ln) or re.search(r"op_sel:\[1", ln)]
+            assert not bad, f"{src}: {len(bad)} packed instructions read a high register for their low half, e.g. {bad[:3]}"

@@ -13,4 +13,7 @@ import os as _os
 # size 1: 7.39 ms per step on four queues, 6.21 on eight; profiles/r05a_hw_queues_probe.md).  The package asks for eight unless the caller
 # chose a value.  Measured on this ROCm (same file): the setting takes effect when made before the process creates its streams -- also
 # after `import torch`, and even after torch.cuda.init() -- so importing the package is enough; a trainer need not export anything.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# TPGSR_NO_ENV_DEFAULTS=1: the package leaves the process environment alone (the variable is process-wide: it also applies to torch's and any
+# other HIP user's streams; and "effective when set before the streams exist" is a measured property of this ROCm build, not a contract).
+if _os.environ.get("TPGSR_NO_ENV_DEFAULTS", "0") != "1":
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -100,9 +100,9 @@ __global__ __launch_bounds__(64) void bigru_fwd_kernel(const float* __restrict__
       for (int k = 0; k < GRU_H / 4; ++k) {
         const float4 hv = hp[k];
         a0 = pk_fma(wrz[4 * k], mk2(hv.x, hv.x), a0);
-        a1 = pk_fma(wrz[4 * k + 1], mk2(hv.y, hv.y), a1);
+        a1 = pk_fma(wrz[4 * k + 1], gru_dup_odd(hv.y), a1);      // (NOT mk2(hv.y, hv.y): gru_common.h)
         a2 = pk_fma(wrz[4 * k + 2], mk2(hv.z, hv.z), a2);
-        a3 = pk_fma(wrz[4 * k + 3], mk2(hv.w, hv.w), a3);
+        a3 = pk_fma(wrz[4 * k + 3], gru_dup_odd(hv.w), a3);
         n0 = pk_fma(wn2[2 * k], mk2(hv.x, hv.y), n0);
         n1 = pk_fma(wn2[2 * k + 1], mk2(hv.z, hv.w), n1);
       }

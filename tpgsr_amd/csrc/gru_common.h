@@ -61,6 +61,18 @@ __device__ __forceinline__ f2 mk2(float x, float y) {
   return v;
 }
 
+// (v, v) for a packed multiply-add when v is an ODD component (.y / .w) of a float4 an LDS read has just returned.  mk2(v, v) compiles to
+// v_pk_fma_f32 ... op_sel:[0,1,0] on the returned register pair -- the LOW half of the instruction takes the pair's ODD register -- and
+// that form read the register as ZERO in lanes 48-63 (while the high half of the same instruction read it correctly) once in ~10^4
+// time steps when three scanning waves shared a SIMD: measured term by term in round 6 (profiles/r06_gru_proj_root_cause.md; every other
+// operand form of the scans -- even components with op_sel_hi, natural (x, y) pairs, a component copied by v_mov -- never failed in
+// 10^6 sequence launches).  The copy costs one v_mov_b32 per use; results are the same bits.
+__device__ __forceinline__ f2 gru_dup_odd(float v) {
+  float c;
+  asm("v_mov_b32 %0, %1" : "=v"(c) : "v"(v));
+  return mk2(c, c);
+}
+
 // TWO sigmoids in lock step (the r and z gates of a time step), component for component the operations of gru_rcp(1 + gru_exp(min(-x, 80)))
 // as packed instructions (v_pk_mul / v_pk_fma / v_pk_add; v_exp and v_rcp back to back).  A lone wave pays ~10 cycles per DEPENDENT VALU
 // instruction and 3-5 per independent one (tools/lab/valu_rate.hip): the two sigmoids one after the other -- the compiler even scheduled the

@@ -4,22 +4,33 @@
 // projection was a launch of its own (the row-panel kernel, conv_panel.hip) that wrote gi [P][192] to HBM (37.7 MB at bs 48) for the
 // scan to read back through a prefetch ring: 10 launches and 0.75 GB per forward pass that need not exist.
 //
-// One workgroup (four waves) = one sequence of T = 16 NRT steps (the 16 x 64 map: T = 16 along H, 64 along W); the four waves share
-// the projection, wave 0 scans (one wavefront per sequence, as in gru.hip).
-//   phase 1  the [T x Cin] input panel as MFMA fragments STRAIGHT FROM GLOBAL MEMORY: a 16x16x32 fragment is 8 consecutive channels of one
-//            pixel per lane (32 contiguous bytes), so no LDS transposition is needed; the fused prologue of the convolution loaders
-//            (BatchNorm affine, residual add, concatenated text strip: conv_loader.h's LD bits 1 / 4 / 16) is applied and the values are
-//            split into bf16 terms in registers (conv_xbf_common.h: exact three-term or two-term split-operand arithmetic);
+// One workgroup (four waves) = 64 time steps: ONE sequence of T = 64 (the 16 x 64 map along W: the four waves share the projection, wave 0
+// scans -- one wavefront per sequence, as in gru.hip) or FOUR sequences of T = 16 (along H: the waves share the projection of all four --
+// one fetch of the weight fragments instead of four -- and each scans one).
+//   phase 1  the [64 x Cin] input panel as MFMA fragments: a 16x16x32 fragment is 8 consecutive channels of one pixel per lane (32
+//            contiguous bytes), so no transposition is needed.  Wave w fetches row tile w ONLY, applies the fused prologue of the
+//            convolution loaders (BatchNorm affine, residual add, concatenated text strip: conv_loader.h's LD bits 1 / 4 / 16), splits
+//            the values into bf16 terms (conv_xbf_common.h: exact three-term or two-term split-operand arithmetic) and passes the
+//            fragments on through LDS -- the staging area is the gi block itself, not yet written -- so the panel crosses the L1 once per
+//            workgroup, not once per wave (round 5's form: ~10 of the 45 us of a launch, 100 MB through the L1s for 25 MB of input);
 //   phase 2  gi^T tiles = Wc^T-tile x panel^T: the weight fragment is the A operand, the panel the B operand, so a lane ends up with FOUR
-//            CONSECUTIVE gate columns of one time step -> one ds_write_b128 per 16 x 16 tile into gi [T][196] (row pitch 196 floats: the
+//            CONSECUTIVE gate columns of one time step -> one ds_write_b128 per 16 x 16 tile into gi [64][196] (row pitch 196 floats: the
 //            sixteen time steps of a tile land in distinct bank quads).  Weight fragments come from the planes tpgsr_split_bf_program
 //            wrote for the 32x32x16 kernels ([term][n/32][k/16][lane][8]); a 16x16x32 fragment is a different 16-byte gather of the same
-//            bytes.  288 MFMAs per 64-step sequence in two-term arithmetic (~2 us), the weights stay L2-resident.
+//            bytes.  288 MFMAs per workgroup in two-term arithmetic (~2 us), the weights stay L2-resident.
 //   phase 3  the scan of bigru_fwd_kernel, value for value (same gate functions, same packed-FMA order), with the step's three input
 //            projections read from LDS one step ahead instead of from HBM eight steps ahead.
-// LDS: 4 T x 196 B + 512 B = 49.5 KB per 64-step sequence (three per CU = the 768 sequences of the W-axis scan in one round), 12.8 KB per
-// 16-step sequence.  Forward only: back-propagation through time keeps its own kernels (the weight-gradient stream's workgroups leave
-// no room for 50 KB workgroups next to them, profiles/r05e_bn_derive_ab.md tells that story for BatchNorm).
+// LDS: 64 x 196 x 4 B + 512 B per scanning wave = 49.5 / 51 KB per workgroup (three per CU = the 768 workgroups of either scan in one
+// round).  Forward only: back-propagation through time keeps its own kernels.
+//
+// REPEATABILITY (round 6; profiles/r06_gru_proj_root_cause.md).  Round 5 built this staged form and took it back: with three workgroups
+// per CU, 2-5 of 3072 sequences came out different from launch to launch.  Found: nothing was wrong with the staging, the barriers or LDS
+// (gi right before and after every scan, fragments identical in all four waves, W_hh intact in the registers afterwards).  One packed
+// multiply-add of the scan -- v_pk_fma_f32 ... op_sel:[0,1,0], the form that takes its LOW half from the ODD register of a pair, here h.y
+// of a broadcast ds_read_b128 that had just returned -- read that register as ZERO in lanes 48-63 of one time step (the high half of the
+// SAME instruction read it correctly), whenever three scanning waves shared a SIMD.  gru_common.h's gru_dup_odd() takes the odd
+// component through a v_mov first; no packed instruction of the scans carries that op_sel any more (tests/test_round6_cpu.py checks the
+// ISA), and tests/test_gru_soak_gpu.py launches the kernels 1000 times next to a co-running load: same bits.
 #include "conv_xbf_common.h"
 #include "gru_common.h"
 #include <mutex>
@@ -64,46 +75,49 @@ __device__ __forceinline__ floatx4 gp_mfma_terms(const bf16x8 (&w)[TT], const bf
 // LD: 1 = per-channel affine (BatchNorm) on the image channels, 4 = residual add (in2), 16 = channels >= cin_a from the [N][W][.] strip
 template <int LD, int TT, int NRT, int NKS, bool TRAIN>
 __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_proj_args p) {
-  constexpr int T = 16 * NRT;
-  extern __shared__ __attribute__((aligned(16))) float gsm[];      // gi [T][GP_RS], then hs [2][64]
+  // T = 64: one sequence per workgroup (four row tiles of 16 steps, wave 0 scans).  T = 16: FOUR sequences per workgroup -- one row tile and
+  // one scanning wave each: the weight fragments of phase 2 (49-74 KB per workgroup from L2, 221 MB per launch when every 16-step sequence
+  // fetched them for itself: 7.6 of that launch's 43 us, tools/lab/gp_probe.py) serve four sequences, and no wave idles through the scan
+  constexpr int T = 16 * NRT, SPW = NRT == 1 ? 4 : 1, RT = NRT * SPW;
+  extern __shared__ __attribute__((aligned(16))) float gsm[];      // gi [64][GP_RS], then hs [SPW][2][64]
   float* const gi = gsm;
-  float* const hs = gsm + T * GP_RS;
+  float* const hs = gsm + 16 * RT * GP_RS;
   const tpgsr_conv_args& a = p.c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const SeqGeom g = seq_geom(blockIdx.x, a.N, a.H, a.W, p.axis);
-  if (!g.active) return;        // (workgroup-uniform)
+  const SeqGeom g = seq_geom(SPW * blockIdx.x + (SPW > 1 ? wave : 0), a.N, a.H, a.W, p.axis);      // (SPW > 1: the sequence this wave scans)
+  if (!g.active) return;        // (workgroup-uniform: the launcher sends whole workgroups only)
   const int l16 = lane & 15, kq = lane >> 4;
-  const int dbg = GP_DBG();
+  const int dbg = GP_DBG();      // (0 in a release build: every test below folds away)
 
-  // ---- phase 1: the panel as split MFMA fragments: xf[rt][ks][term] = 8 channels 32 ks + 8 kq .. of time step 16 rt + l16 ----
-  bf16x8 xf[NRT][NKS][TT];
+  // ---- phase 1: the panel as split MFMA fragments: xf[rt][ks][term] = 8 channels 32 ks + 8 kq .. of row 16 rt + l16 (time step 16 rt + l16 of
+  // the one sequence, or step l16 of sequence rt of the four).  Wave w fetches, finishes (prologue) and splits row tile w and stages it ----
+  bf16x8 xf[RT][NKS][TT];
   {
+    u32x4* const stage = reinterpret_cast<u32x4*>(gsm);      // [rt][ks][term][lane] 16-byte pieces: RT NKS TT KB <= 36 KB of the 49 KB gi block
     const int hw = a.H * a.W;
-    float4 lo[NRT][NKS], hi[NRT][NKS], lo2[NRT][NKS], hi2[NRT][NKS];
+    float4 lo[NKS], hi[NKS], lo2[NKS], hi2[NKS];
+    // (SPW > 1: g is this wave's own sequence = row tile `wave`)
+    const int pix = SPW == 1 ? g.base + (16 * wave + l16) * g.stride : g.base + l16 * g.stride;
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      const int pix = g.base + (16 * rt + l16) * g.stride;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int c = 32 * ks + 8 * kq;
-        const float* src;
-        if ((LD & 16) && c >= a.cin_a) {        // the text strip: one row per (image, column), shared by all H rows
-          const int n = pix / hw, w = pix % a.W;
-          src = a.in_b + (size_t)(n * a.W + w) * a.in_b_ld + (c - a.cin_a);
-        } else {
-          src = a.in + (size_t)pix * a.in_ld + a.in_coff + c;
-        }
-        if (dbg & 2) {
-          lo[rt][ks] = hi[rt][ks] = lo2[rt][ks] = hi2[rt][ks] = make_float4(0.f, 0.f, 0.f, 0.f);
-          continue;
-        }
-        lo[rt][ks] = *reinterpret_cast<const float4*>(src);
-        hi[rt][ks] = *reinterpret_cast<const float4*>(src + 4);
-        if (LD & 4) {
-          const float* s2 = a.in2 + (size_t)pix * a.in2_ld + c;
-          lo2[rt][ks] = *reinterpret_cast<const float4*>(s2);
-          hi2[rt][ks] = *reinterpret_cast<const float4*>(s2 + 4);
-        }
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int c = 32 * ks + 8 * kq;
+      const float* src;
+      if ((LD & 16) && c >= a.cin_a) {        // the text strip: one row per (image, column), shared by all H rows
+        const int n = pix / hw, w = pix % a.W;
+        src = a.in_b + (size_t)(n * a.W + w) * a.in_b_ld + (c - a.cin_a);
+      } else {
+        src = a.in + (size_t)pix * a.in_ld + a.in_coff + c;
+      }
+      if (dbg & 2) {
+        lo[ks] = hi[ks] = lo2[ks] = hi2[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
+      lo[ks] = *reinterpret_cast<const float4*>(src);
+      hi[ks] = *reinterpret_cast<const float4*>(src + 4);
+      if (LD & 4) {
+        const float* s2 = a.in2 + (size_t)pix * a.in2_ld + c;
+        lo2[ks] = *reinterpret_cast<const float4*>(s2);
+        hi2[ks] = *reinterpret_cast<const float4*>(s2 + 4);
       }
     }
 #pragma unroll
@@ -117,31 +131,36 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
         t0 = *reinterpret_cast<const float4*>(a.in_shift + c);
         t1 = *reinterpret_cast<const float4*>(a.in_shift + c + 4);
       }
+      float4 u = lo[ks], v = hi[ks];
+      if (LD & 1) {      // (identity on the strip's channels: 1 * x + 0 is exact)
+        u.x = u.x * s0.x + t0.x; u.y = u.y * s0.y + t0.y; u.z = u.z * s0.z + t0.z; u.w = u.w * s0.w + t0.w;
+        v.x = v.x * s1.x + t1.x; v.y = v.y * s1.y + t1.y; v.z = v.z * s1.z + t1.z; v.w = v.w * s1.w + t1.w;
+      }
+      if (LD & 4) {
+        u.x += lo2[ks].x; u.y += lo2[ks].y; u.z += lo2[ks].z; u.w += lo2[ks].w;
+        v.x += hi2[ks].x; v.y += hi2[ks].y; v.z += hi2[ks].z; v.w += hi2[ks].w;
+      }
+      uint2 hu[TT], hv[TT];
+      split4<TT>(u, hu);
+      split4<TT>(v, hv);
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        float4 u = lo[rt][ks], v = hi[rt][ks];
-        if (LD & 1) {      // (identity on the strip's channels: 1 * x + 0 is exact)
-          u.x = u.x * s0.x + t0.x; u.y = u.y * s0.y + t0.y; u.z = u.z * s0.z + t0.z; u.w = u.w * s0.w + t0.w;
-          v.x = v.x * s1.x + t1.x; v.y = v.y * s1.y + t1.y; v.z = v.z * s1.z + t1.z; v.w = v.w * s1.w + t1.w;
-        }
-        if (LD & 4) {
-          u.x += lo2[rt][ks].x; u.y += lo2[rt][ks].y; u.z += lo2[rt][ks].z; u.w += lo2[rt][ks].w;
-          v.x += hi2[rt][ks].x; v.y += hi2[rt][ks].y; v.z += hi2[rt][ks].z; v.w += hi2[rt][ks].w;
-        }
-        uint2 hu[TT], hv[TT];
-        split4<TT>(u, hu);
-        split4<TT>(v, hv);
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-          u32x4 q;
-          q.x = hu[t].x; q.y = hu[t].y; q.z = hv[t].x; q.w = hv[t].y;
-          xf[rt][ks][t] = __builtin_bit_cast(bf16x8, q);
-        }
+      for (int t = 0; t < TT; ++t) {
+        u32x4 q;
+        q.x = hu[t].x; q.y = hu[t].y; q.z = hv[t].x; q.w = hv[t].y;
+        stage[((wave * NKS + ks) * TT + t) * 64 + lane] = q;
       }
     }
+    __syncthreads();      // the four row tiles' fragments are staged
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) xf[rt][ks][t] = __builtin_bit_cast(bf16x8, stage[((rt * NKS + ks) * TT + t) * 64 + lane]);
+    __syncthreads();      // everybody holds the whole panel: phase 2 may overwrite the staging area with gi
   }
 
-  // ---- phase 2: gi [t][col] = bc[col] + sum_k panel[t][k] Wc[k][col], twelve 16-column tiles ----
+  // ---- phase 2: gi [row][col] = bc[col] + sum_k panel[row][k] Wc[k][col], twelve 16-column tiles ----
   {
     constexpr int KB16 = 2 * NKS;                       // k-blocks of 16 in the split planes (kp = 32 NKS)
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const float*>(a.wt_bf), (size_t)TT * 6 * 32 * (32 * NKS) / 2);
@@ -150,11 +169,9 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     // ct 16 + l16 -> block (ct >> 1), lane slot (ct & 1) 16 + l16 (+ 32 for the upper 8 of a 16-k block); k = 32 ks + 8 kq -> k-block
     // 2 ks + (kq >> 1), upper half when kq is odd
     const unsigned wlane = ((unsigned)l16 + 32u * (kq & 1)) * 16u + (unsigned)(kq >> 1) * 1024u;
-    // the waves of the workgroup (four) share the projection: wave w computes column tiles w, w + 4, w + 8 for all time steps (every wave holds the whole panel
-    // as fragments -- the three redundant panel loads hit the L1 -- so nothing is exchanged before the barrier below); alone, one wave
-    // spent ~8 us here before its scan could start, with the other three SIMDs of the CU idle
-    const int nw = blockDim.x >> 6;
-    for (int ct = wave; ct < 12 && !(dbg & 4); ct += nw) {
+    // the four waves share the projection: wave w computes column tiles w, w + 4, w + 8 for all 64 rows (alone, one wave spent ~8 us here
+    // before its scan could start, with the other three SIMDs of the CU idle)
+    for (int ct = wave; ct < 12 && !(dbg & 4); ct += 4) {
       bf16x8 wf[NKS][TT];
       const unsigned wbase = ((unsigned)(ct >> 1) * KB16) * 1024u + (unsigned)(ct & 1) * 256u + wlane;
 #pragma unroll
@@ -164,11 +181,11 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
           wf[ks][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase + t * plane_w + (unsigned)ks * 2048u), 0, 0));
       const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 16 + 4 * kq);
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) acc = gp_mfma_terms<TT>(wf[ks], xf[rt][ks], acc);
-        // lane: time step 16 rt + l16, gate columns ct 16 + 4 kq .. + 3
+        // lane: row 16 rt + l16, gate columns ct 16 + 4 kq .. + 3
         float4 o;
         o.x = acc[0] + b4.x; o.y = acc[1] + b4.y; o.z = acc[2] + b4.z; o.w = acc[3] + b4.w;
         *reinterpret_cast<float4*>(gi + (16 * rt + l16) * GP_RS + ct * 16 + 4 * kq) = o;
@@ -177,7 +194,9 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
   }
 
   __syncthreads();      // all of gi is in LDS
-  if (wave != 0 || (dbg & 1)) return;      // the scan is one wave's work (LDS stays allocated until it is through)
+  if (wave >= SPW || (dbg & 1)) return;      // a scan is one wave's work (LDS stays allocated until the last one is through)
+  float* const hsw = hs + (SPW > 1 ? wave * 128 : 0);                      // this wave's exchange slot [2][64]
+  const float* const giw = gi + (SPW > 1 ? wave * T * GP_RS : 0);          // ... and its rows of gi
 
   // ---- phase 3: the scan (bigru_fwd_kernel of gru.hip, the inputs out of LDS) ----
   const int d = lane >> 5, j = lane & 31;
@@ -200,12 +219,12 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
   }
   const float br = p.b_hh[d * 96 + j], bz = p.b_hh[d * 96 + 32 + j], bn = p.b_hh[d * 96 + 64 + j];
   float h = 0.f;
-  hs[lane] = 0.f;
+  hsw[lane] = 0.f;
   __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order; this only pins the compiler's order
   const int dpix = d == 0 ? g.stride : -g.stride;
   int pix = g.base + (d == 0 ? 0 : (T - 1) * g.stride);
   const int drow = d == 0 ? GP_RS : -GP_RS;
-  const float* gp = gi + (d == 0 ? 0 : (T - 1) * GP_RS) + d * 96 + j;      // this lane's r-gate input of the current step
+  const float* gp = giw + (d == 0 ? 0 : (T - 1) * GP_RS) + d * 96 + j;      // this lane's r-gate input of the current step
   float cr = gp[0], cz = gp[32], cn = gp[64];
 #pragma unroll 2
   for (int step = 0; step < T; ++step) {
@@ -215,14 +234,14 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
       cr = gp[0]; cz = gp[32]; cn = gp[64];
     }
     f2 a0 = mk2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, n0 = a0, n1 = a0;
-    const float4* hp = reinterpret_cast<const float4*>(&hs[(step & 1) * 64 + d * 32]);
+    const float4* hp = reinterpret_cast<const float4*>(&hsw[(step & 1) * 64 + d * 32]);
 #pragma unroll
     for (int k = 0; k < GRU_H / 4; ++k) {
       const float4 hv = hp[k];
       a0 = pk_fma(wrz[4 * k], mk2(hv.x, hv.x), a0);
-      a1 = pk_fma(wrz[4 * k + 1], mk2(hv.y, hv.y), a1);
+      a1 = pk_fma(wrz[4 * k + 1], gru_dup_odd(hv.y), a1);      // (NOT mk2(hv.y, hv.y): gru_common.h)
       a2 = pk_fma(wrz[4 * k + 2], mk2(hv.z, hv.z), a2);
-      a3 = pk_fma(wrz[4 * k + 3], mk2(hv.w, hv.w), a3);
+      a3 = pk_fma(wrz[4 * k + 3], gru_dup_odd(hv.w), a3);
       n0 = pk_fma(wn2[2 * k], mk2(hv.x, hv.y), n0);
       n1 = pk_fma(wn2[2 * k + 1], mk2(hv.z, hv.w), n1);
     }
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(256) void bigru_proj_fwd_kernel(const tpgsr_bigru_p
     }
     const float r = sg.x, z = sg.y;
     h = __builtin_fmaf(z, h, (1.f - z) * n);      // (explicit: the same contraction in every kernel that runs this step)
-    hs[((step + 1) & 1) * 64 + lane] = h;
+    hsw[((step + 1) & 1) * 64 + lane] = h;
     if (!(dbg & 16)) p.h_out[pix * 64 + d * 32 + j] = h;
     if (TRAIN && !(dbg & 16)) {
       float* q = p.gates + pix * 256 + d * 128 + j;
@@ -259,7 +278,7 @@ static int gp_loader_bits(const tpgsr_conv_args* a) {
 }
 
 /* 1 when tpgsr_bigru_proj_fwd takes this GruBlock: split-operand arithmetic (terms 1..3 with the pre-split weight planes), Cin 64 or 96,
- * 192 gate columns, scan length 16 or 64, a loader it has (plain, BatchNorm affine, residual add, affine + text strip) */
+ * 192 gate columns, scan length 16 (a multiple of four sequences) or 64, a loader it has (plain, BatchNorm affine, residual add, affine + text strip) */
 extern "C" int tpgsr_bigru_proj_supported(const tpgsr_bigru_proj_args* p) {
   if (!p || !g_gp_on) return 0;
   const tpgsr_conv_args* a = &p->c;
@@ -267,6 +286,7 @@ extern "C" int tpgsr_bigru_proj_supported(const tpgsr_bigru_proj_args* p) {
   if (a->terms < 1 || a->terms > 3 || !a->wt_bf || a->wt_bf_cin != 0 || a->Cout != 192 || (a->Cin != 64 && a->Cin != 96) || a->kp != a->Cin) return 0;
   if (a->KH * a->KW != 1 || a->wt_ld || a->wt_coff || a->in_coff || a->stride_w > 1 || a->in_dil_w > 1) return 0;
   if (T != 16 && T != 64) return 0;
+  if (T == 16 && ((p->axis == 0 ? a->N * a->H : a->N * a->W) & 3)) return 0;      // (16-step sequences go four to a workgroup)
   if (!(ld == 0 || ld == 1 || ld == 4 || ld == 17)) return 0;
   if ((ld & 16) && (a->cin_a != 64 || a->Cin != 96)) return 0;
   return 1;
@@ -305,11 +325,11 @@ extern "C" int tpgsr_bigru_proj_fwd(const tpgsr_bigru_proj_args* p, void* stream
 #undef GP_PICK1
 #undef GP_PICK2
 #undef GP_PICK3
-  const size_t lds = ((size_t)T * GP_RS + 128) * sizeof(float);
+  const int spw = T == 16 ? 4 : 1;
+  const size_t lds = ((size_t)64 * GP_RS + spw * 128) * sizeof(float);
   tpgsr_bigru_proj_args args = *p;
   void* params[] = {&args};
-  static const int nthreads = [] { const char* e = getenv("TPGSR_GRU_PROJ_WAVES"); const int w = e ? atoi(e) : 4; return 64 * (w == 1 || w == 2 ? w : 4); }();
-  if (hipLaunchKernel(fn, dim3((unsigned)nseq), dim3(nthreads), params, lds, (hipStream_t)stream) != hipSuccess) {
+  if (hipLaunchKernel(fn, dim3((unsigned)(nseq / spw)), dim3(256), params, lds, (hipStream_t)stream) != hipSuccess) {      // (four waves: the kernel's row-tile split)
     tpgsr_set_error("tpgsr_bigru_proj_fwd: launch failed: %s", hipGetErrorString(hipGetLastError()));
     return TPGSR_ERR_LAUNCH;
   }

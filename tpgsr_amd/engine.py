@@ -518,6 +518,7 @@ class _EngineBase:
         self._gen = 0
         self._kernel_writes = 0              # bumped by whoever rewrites the parameter arena through a raw pointer (FusedAdam)
         self._packed_key = None              # (arena version, kernel writes) the packed / split operands were built from
+        self._packed_split = False           # ... and whether that pack rebuilt the bf16 twins too
 
     # ---- workspace slots of the nn.Module API --------------------------------------------------------------------
     # A training-mode forward saves its activations / BN statistics / GRU-LSTM gates in a workspace slot until its
@@ -680,13 +681,30 @@ class _EngineBase:
         # (+ whether the bf16 twins exist: an engine bound under "f32" grows them when a split-operand policy records its first plan)
         return (sum(p._version for p in self.P.values()), self._kernel_writes, self.arena.flat.data_ptr(), bool(getattr(self, "_split_tabs", None)))
 
+    @staticmethod
+    def _plan_splits(plan) -> bool:
+        """does this pack plan rebuild the bf16 twins as well (recorded under a split-operand policy) or the fp32 operands only (`f32`)?"""
+        v = getattr(plan, "_tpgsr_splits", None)
+        if v is None:
+            v = any(op[0] == "tpgsr_split_bf_program" for op in plan.ops)
+            try:
+                plan._tpgsr_splits = v
+            except AttributeError:
+                pass
+        return v
+
     def pack_if_stale(self, pack_plan):
         capturing = (not K.DRYRUN) and torch.cuda.is_current_stream_capturing()   # a captured graph must contain its own pack
         key = self._param_key()
         check = (not K.DRYRUN) and (not capturing) and os.environ.get("TPGSR_PACK_CHECK") == "1"
-        if capturing or key != self._packed_key or os.environ.get("TPGSR_PACK_ALWAYS") == "1":
+        # plans (and pack plans) are cached per arithmetic policy: one eval-mode engine may serve an `f32` evaluator (its pack plan has no
+        # split program) AND a split-operand train step.  The twins are current only if the LAST pack of these parameters split them too
+        # (ADVICE round 5: an f32 pack after load_state_dict stored the key, the next x2 forward skipped its pack and multiplied stale twins)
+        splits = self._plan_splits(pack_plan)
+        if capturing or key != self._packed_key or (splits and not self._packed_split) or os.environ.get("TPGSR_PACK_ALWAYS") == "1":
             pack_plan.run()
             self._packed_key = None if capturing else key
+            self._packed_split = splits
             if check:
                 self._packed_sum = self._arena_checksum()
         elif check and getattr(self, "_packed_sum", None) is not None and self._arena_checksum() != self._packed_sum:
@@ -712,8 +730,9 @@ class _EngineBase:
         self._packed_key = None
 
     def note_packed(self):
-        """a training-mode forward has just packed the current parameters"""
+        """a training-mode forward has just packed the current parameters (under the policy it was recorded with)"""
         self._packed_key = self._param_key()
+        self._packed_split = bool(K.CONV_TERMS)
 
     def bind(self, device):
         rebuilt = self.arena.ensure(device)

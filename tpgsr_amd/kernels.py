@@ -1160,16 +1160,34 @@ def lstm_seq_coresident(device) -> bool:
         return True                       # (plans are recorded by the eager warm-up steps before a capture; a capture cannot synchronise)
     key = str(device)
     if key not in _LSTM_CORESIDENT:
-        words = torch.zeros(2, dtype=torch.int32, device=device)
-        rc = _lib.load().tpgsr_lstm_seq_probe(words.data_ptr(), _stream())
-        if rc < 0:
-            check(rc, "tpgsr_lstm_seq_probe")
+        rc = 0
+        for attempt in range(2):          # a negative answer is asked again once, on a drained device: the first plan is recorded while the
+            words = torch.zeros(2, dtype=torch.int32, device=device)      # step's other streams may still be busy
+            rc = _lib.load().tpgsr_lstm_seq_probe(words.data_ptr(), _stream())
+            if rc < 0:
+                check(rc, "tpgsr_lstm_seq_probe")
+            if rc:
+                break
+            torch.cuda.synchronize(device)
         _LSTM_CORESIDENT[key] = bool(rc)
         if not rc:
             import warnings
             warnings.warn("tpgsr_amd: the persistent BiLSTM kernels' 64 workgroups do not become co-resident on %s (a shared or partitioned GPU?): "
                           "recording the per-step recurrence instead (slower, never wrong)" % key, RuntimeWarning, stacklevel=2)
     return _LSTM_CORESIDENT[key]
+
+
+def lstm_seq_probe_reset(device=None):
+    """forget the cached co-residency answer (of one device, or of all): the next recorded plan asks again -- for a process whose GPU
+    becomes shared or un-shared during its lifetime.  Plans already recorded keep the form they were recorded with (clear the engines'
+    plan caches, `engine._plans.clear()`, to re-record).  Under a stream capture the question cannot be asked (a capture cannot
+    synchronise) and the answer is taken as yes: capture relies on the eager warm-up steps having probed."""
+    if device is None:
+        _LSTM_CORESIDENT.clear()
+    else:
+        _LSTM_CORESIDENT.pop(str(device), None)
+
+
 # the five weight-gradient GEMMs of a BidirectionalLSTM layer as one launch (tpgsr_conv_wgrad_batch); 0: five launches
 LSTM_WGRAD_BATCH = os.environ.get("TPGSR_LSTM_WGRAD_BATCH", "1") == "1"
 
