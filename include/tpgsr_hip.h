@@ -130,7 +130,14 @@ typedef struct {
    *     tpgsr_conv_bn_row_tiles() first, a launch that lands on any other kernel with 3 set is refused.  Not with fin_mode. --- */
   int bn_row_tiles;
   int reserved1;
+  /* --- scaled residual operand (round 6): a = in * in_scale[c] + in_shift[c] + in2 * in2_scale[c].  What it is for: the apply pass of
+   *     batch_norm_backward, dy = c0 dz + c1 y + c2 (model/tsrn.py:376-380's BatchNorms in the backward pass), folded into the loader of
+   *     the data-gradient convolution that consumes dy (in = dz, in2 = y, in_scale = c0, in_shift = c2, in2_scale = c1): the caller's
+   *     stream no longer runs tpgsr_bn_bwd_apply in front of it.  Whole-CU halo kernel only: ask tpgsr_conv_in2_scale_ok() first. --- */
+  const float* in2_scale;    /* optional [Cin], 16-byte aligned; needs in2 and in_scale / in_shift, no in_act / in_b / in_ps */
 } tpgsr_conv_args;
+/* 1 when tpgsr_conv_fwd(a) with a->in2_scale set will be taken (by the whole-CU halo kernel), else 0 */
+int tpgsr_conv_in2_scale_ok(const tpgsr_conv_args* a);
 /* 3 when tpgsr_conv_fwd(a) will run on the whole-CU halo kernel (which can leave one bn_partial row per 192 pixels), else 1 */
 int tpgsr_conv_bn_row_tiles(const tpgsr_conv_args* a);
 

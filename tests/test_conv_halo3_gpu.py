@@ -124,3 +124,55 @@ def test_halo3_is_the_kernel_that_runs_for_the_trunk():
             a = K.make_conv_args(geom, x, wf, out)
         assert fn(C.byref(a), geom.M, 0, torch.cuda.current_stream().cuda_stream) == want
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("terms", [1, 2])
+@pytest.mark.parametrize("N,H,W", [(48, 16, 64), (5, 16, 64), (40, 15, 62)])
+def test_scaled_residual_loader_is_the_batchnorm_backward_apply(N, H, W, terms):
+    """tpgsr_conv_args.in2_scale (round 6): a = in * s + t + in2 * s2 in the loader of the whole-CU kernel == the convolution of the
+    MATERIALISED dy = c0 dz + c1 y + c2 (tpgsr_bn_bwd_apply, then the plain loader) -- the folded form of the BatchNorm backward's apply
+    (model/tsrn.py:376-380 in the backward pass), with the BatchNorm-backward epilogue of the NEXT BatchNorm riding along as in the trunk.
+    Shapes: the trunk's, a ragged batch, and a map whose super-tiles span rows and images."""
+    from tpgsr_amd import kernels as K
+    g = torch.Generator().manual_seed(7)
+    C_ = 64
+    M = N * H * W
+    dz, y = torch.randn(M, C_, generator=g).to(DEV), torch.randn(M, C_, generator=g).to(DEV)
+    coef = torch.stack([torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.3, torch.randn(C_, generator=g) * 0.1]).to(DEV).contiguous()
+    w = (torch.randn(9 * C_, C_, generator=g) / math.sqrt(9 * C_)).to(DEV)
+    geom = K.ConvGeom(N, H, W, C_, C_, 3, 3, 1, 1)
+    y1 = torch.randn(M, C_, generator=g).to(DEV)
+    mean, rstd = (torch.randn(C_, generator=g) * 0.1).to(DEV), (torch.rand(C_, generator=g) + 0.5).to(DEV)
+    bsc, bsh = (torch.rand(C_, generator=g) + 0.5).to(DEV), (torch.randn(C_, generator=g) * 0.2).to(DEV)
+    with K.conv_terms(terms):
+        K.make_bf_twin(w, C_)
+        nblk = (M + 63) // 64
+        outs = []
+        for folded in (True, False):
+            out = torch.full((M, C_), float("nan"), device=DEV)
+            part = torch.full((nblk, 2, C_), float("nan"), device=DEV)
+            bnb = dict(y=y1, mean=mean, rstd=rstd, scale=bsc, shift=bsh, act="mish", partial=part, store_dz=True)
+            if folded:
+                a = K.make_conv_args(geom, dz, w, out, in_scale=coef[0], in_shift=coef[2], in2=y, in2_scale=coef[1], bnb=bnb)
+                ok = K.conv_in2_scale_ok(a)
+                if M < 192 * 192:       # fewer super-tiles than the whole-CU kernel asks for: the launch is not its own, and says so
+                    assert not ok
+                    with pytest.raises(Exception, match="in2_scale"):
+                        K.conv_fwd(a)
+                    return
+                assert ok
+                K.conv_fwd(a)
+            else:
+                dy = torch.empty(M, C_, device=DEV)
+                K.bn_bwd_apply(dz, None, y, M, C_, None, None, "none", coef, dy)
+                K.conv_fwd(K.make_conv_args(geom, dy, w, out, bnb=bnb))
+            outs.append((out, part[:K.bn_rows(M, bnb.get("row_tiles", 1))].clone()))
+    torch.cuda.synchronize()
+    (o1, p1), (o0, p0) = outs
+    scale = o0.abs().max().item()
+    e = (o1 - o0).abs().max().item() / scale
+    ep = (p1 - p0).abs().max().item() / max(p0.abs().max().item(), 1e-6)
+    print(f"folded apply vs materialised dy (terms {terms}, N {N} {H}x{W}): out {e:.2e}, BatchNorm-backward sums {ep:.2e}")
+    # the two forms round dy differently (fma chain in the loader vs the apply kernel) before the same split: a few bf16-term ulps
+    tol = 2e-2 if terms == 1 else 2e-4
+    assert e < tol and ep < 10 * tol and not torch.isnan(o1).any()

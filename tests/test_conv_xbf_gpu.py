@@ -174,18 +174,24 @@ def test_error_vs_fp64_truth_per_mode():
 # ---- whole networks on the fp32 matrix cores (every other GPU test runs the default split-operand path): same gates -----------
 def test_tsrn_golden_f32_matrix_cores(golden_dir, f32):
     import test_tsrn_gpu as T
-    T.test_tsrn_forward_backward_vs_golden(golden_dir)
+    from conftest import _GoldenPolicy
+    fp = _GoldenPolicy("x3")       # (fp32 tolerances; the fixture `f32` has selected the fp32 matrix-core kernels)
+    fp.name = "f32"
+    T.test_tsrn_forward_backward_vs_golden(golden_dir, fp)
     T.test_tsrn_gradients_vs_oracle_nostn()
     T.test_train_trajectory_nostn(golden_dir)
-    T.test_tsrn_tl_vs_golden(golden_dir)
+    T.test_tsrn_tl_vs_golden(golden_dir, fp)
     T.test_tsrn_tl_gradients_vs_oracle_nostn()
 
 
 def test_crnn_golden_f32_matrix_cores(golden_dir, f32):
     import test_crnn_gpu as T
-    T.test_crnn_vs_golden(golden_dir)
+    from conftest import _GoldenPolicy
+    fp = _GoldenPolicy("x3")
+    fp.name = "f32"
+    T.test_crnn_vs_golden(golden_dir, fp)
     T.test_crnn_gradients_vs_oracle()
-    T.test_train_c3_step_vs_golden(golden_dir)
+    T.test_train_c3_step_vs_golden(golden_dir, fp)
     T.test_cascade_two_stages_vs_oracle()
 
 

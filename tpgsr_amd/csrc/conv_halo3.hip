@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
     };
     constexpr bool DB = !(LD & 4);       // (the residual-add loader carries two quads per entry: one register set only)
     ARaw hr[DB ? 2 : 1][H3_NE];
-    float4 qs[2], qt[2];
+    float4 qs[2], qt[2], q2 = make_float4(1.f, 1.f, 1.f, 1.f);      // (q2: per-channel scale of the residual operand, LD bit 32 -- one register set)
     qs[0] = qs[1] = make_float4(1.f, 1.f, 1.f, 1.f);
     qt[0] = qt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_item = [&](auto set_tag, const int cc) __attribute__((always_inline)) {
@@ -113,13 +113,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_xbf_kernel(tpgsr_conv_args 
         qs[S] = *reinterpret_cast<const float4*>(a.in_scale + c);
         qt[S] = *reinterpret_cast<const float4*>(a.in_shift + c);
       }
+      if (LD & 32) q2 = *reinterpret_cast<const float4*>(a.in2_scale + c);
     };
     auto store_item = [&](auto set_tag, const int j) __attribute__((always_inline)) {
       constexpr int S = decltype(set_tag)::value;
       unsigned char* buf = hsm + (j & 1) * BUF;
 #pragma unroll
       for (int i = 0; i < H3_NE; ++i) {
-        const float4 v = finish_a<LD>(a, hr[S][i], qs[S], qt[S]);
+        const float4 v = finish_a<LD>(a, hr[S][i], qs[S], qt[S], q2);
         uint2 h[T];
         split4<T>(v, h);
         const int e = er * H3_NE + i;      // every one of the 480 entries of the plane is written (zeros past the halo's end)
@@ -575,13 +576,13 @@ static int g_h3_on = [] { const char* e = getenv("TPGSR_XBF_HALO3"); return (e &
 /* experiment / test switch: 0 sends every convolution back to the two-workgroup halo kernel */
 extern "C" void tpgsr_halo3_set_enabled(int on) { g_h3_on = on ? 1 : 0; }
 
-#define H3_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
+#define H3_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7) X(37)
 
 // > 0 (the halo capacity) when the shape is this kernel's, else 0
 static int halo3_takes(const tpgsr_conv_args* a, long long M, int ld) {
   const int T = a->terms;
   if (!g_h3_on || T < 1 || T > 2 || a->KH * a->KW < 3 || !((a->KH * a->KW) & 1) || a->wt_bf_cin != a->Cin || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 || a->in_b ||
-      a->in_ps || (ld & ~7) || ld == 6 || a->OW + a->KW - 1 < 8)
+      a->in_ps || ((ld & ~7) && ld != 37) || ld == 6 || a->OW + a->KW - 1 < 8)
     return 0;
   // the residual-add loader carries two quads per entry and has ONE register set (no load of the next block in flight), and a
   // pixel-shuffled store goes out four bytes at a time: with both (the up-sampling convolution: 102 us here, 87 us there) the
@@ -601,6 +602,12 @@ static int halo3_takes(const tpgsr_conv_args* a, long long M, int ld) {
     return Lcap;
     default: return 0;
   }
+}
+
+/* 1 when a launch with a scaled residual operand (tpgsr_conv_args.in2_scale) is this kernel's -- the only one whose loader has it */
+extern "C" int tpgsr_conv_in2_scale_ok(const tpgsr_conv_args* a) {
+  if (!a || !(a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) || a->fin_mode || !a->in2 || !a->in_scale || a->in_act || a->in_b) return 0;
+  return halo3_takes(a, (long long)a->N * a->OH * a->OW, 37) > 0 ? 1 : 0;
 }
 
 /* tpgsr_conv_args.bn_row_tiles: 3 when tpgsr_conv_fwd(a) lands here (the dispatch of conv_mfma.hip / conv_xbf.hip up to this kernel) */

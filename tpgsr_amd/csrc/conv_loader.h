@@ -206,8 +206,11 @@ __device__ __forceinline__ ARaw load_a_raw(const tpgsr_conv_args& a, __amdgpu_bu
 }
 
 // apply the fused prologue to a landed quad (called right before the LDS store)
+// LD bit 32 (the whole-CU halo kernel only): the residual operand is scaled per channel, a = in * s + t + in2 * s2 -- the BatchNorm-backward
+// apply dy = c0 dz + c1 y + c2 (in = dz, in2 = y) folded into the loader of the data-gradient convolution that consumes dy
 template <int LD>
-__device__ __forceinline__ float4 finish_a(const tpgsr_conv_args& a, const ARaw& r, const float4& s, const float4& t) {
+__device__ __forceinline__ float4 finish_a(const tpgsr_conv_args& a, const ARaw& r, const float4& s, const float4& t,
+                                           const float4& s2 = make_float4(1.f, 1.f, 1.f, 1.f)) {
   float4 v = r.v;
   if ((LD & 16) && r.raw) return v;   // hardware zero fill already handled padding
   if (LD & 1) {
@@ -222,7 +225,12 @@ __device__ __forceinline__ float4 finish_a(const tpgsr_conv_args& a, const ARaw&
     v.z = apply_act(v.z, a.in_act);
     v.w = apply_act(v.w, a.in_act);
   }
-  if (LD & 4) {
+  if (LD & 32) {
+    v.x = __builtin_fmaf(r.v2.x, s2.x, v.x);
+    v.y = __builtin_fmaf(r.v2.y, s2.y, v.y);
+    v.z = __builtin_fmaf(r.v2.z, s2.z, v.z);
+    v.w = __builtin_fmaf(r.v2.w, s2.w, v.w);
+  } else if (LD & 4) {
     v.x += r.v2.x;
     v.y += r.v2.y;
     v.z += r.v2.z;

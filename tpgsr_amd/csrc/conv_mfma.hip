@@ -336,6 +336,8 @@ static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
                     "%s: vector loader needs 16-byte aligned rows", who);
   if (a->in2) TPGSR_CHECK_ARG(a->in2_ld >= a->Cin && ((a->Cin & 3) || (a->in2_ld & 3) == 0), "%s: bad in2_ld", who);
   TPGSR_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "%s: in_scale/in_shift must come together", who);
+  TPGSR_CHECK_ARG(!a->in2_scale || (a->in2 && a->in_scale && !a->in_act && !a->in_b && !a->in_ps && (((uintptr_t)a->in2_scale) & 15) == 0),
+                  "%s: in2_scale goes with in2 + in_scale / in_shift and nothing else (a = in * s + t + in2 * s2)", who);
   // the loaders address their operands through buffer resources: 32-bit byte offsets inside a 2 GiB window (make_rsrc).  Fail
   // loudly instead of reading zeros past it (one operand of bs x 64 channels x 32x128 reaches 2 GiB at bs = 2048).
   const long long pix = (long long)a->N * a->H * a->W, win = 0x7fffffffll;
@@ -347,7 +349,7 @@ static int check_conv_args(const tpgsr_conv_args* a, const char* who) {
 
 // compile-time loader variant: 1 affine, 2 activation, 4 residual add, 8 pixel-shuffle gather
 static int loader_bits(const tpgsr_conv_args* a) {
-  return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0);
+  return (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0) | (a->in2_scale ? 32 : 0);
 }
 
 // set by a launcher whose kernel finalizes the BatchNorm itself (tpgsr_conv_args.fin_mode): per host thread, valid for the current call

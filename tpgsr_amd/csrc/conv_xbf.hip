@@ -718,6 +718,8 @@ extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, 
   const int h3 = tpgsr_conv_halo3_xbf_launch(a, M, ld, st);      // whole-CU kernel: three tiles per workgroup, one round of the chip
   if (h3 < 0) return h3;
   if (h3 > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA, whole-CU halo)");
+  TPGSR_CHECK_ARG(!(ld & 32), "tpgsr_conv_fwd: a scaled residual operand (in2_scale) exists in the whole-CU halo kernel's loader only, which does not "
+                  "take this launch (ask tpgsr_conv_in2_scale_ok first)");
   TPGSR_CHECK_ARG(a->bn_row_tiles <= 1, "tpgsr_conv_fwd: bn_row_tiles %d is the whole-CU halo kernel's, which does not take this launch "
                   "(ask tpgsr_conv_bn_row_tiles first)", a->bn_row_tiles);
   const int h = conv_halo_xbf_launch(a, M, ld, st);

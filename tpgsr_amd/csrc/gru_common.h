@@ -89,6 +89,8 @@ __device__ __forceinline__ f2 gru_sigmoid2(f2 x) {
   return pk_fma(pk_fma(-d, r, mk2(1.f, 1.f)), r, r);
 }
 __device__ __forceinline__ float gru_sigmoid(float x) { return gru_sigmoid2(mk2(x, x)).x; }
+// one sigmoid, the same operations as a component of gru_sigmoid2 (the LSTM cells of lstm_seq.hip / crnn.hip: four gates per unit)
+__device__ __forceinline__ float gru_sigmoid1(float x) { return gru_rcp(1.f + gru_exp(fminf(-x, 80.f))); }
 // BRANCH-FREE: both forms are computed and one is selected.  Left to itself the compiler sinks them into the two sides of a divergent
 // branch (s_cbranch_execz): a scheduling barrier in the middle of the step, with both sides executed by every wave anyway (the lanes of a
 // wave are 64 different hidden units).  The empty asm pins both values in front of the select.

@@ -27,6 +27,7 @@
 // and POISONS its outputs with NaN from then on (see LS_SPINS below): a timed-out hand-off ends in a NaN loss, never in a silently
 // wrong one.
 #include "common.h"
+#include "gru_common.h"   // the recurrences' gate functions: compensated v_exp_f32 + v_rcp_f32 with a Newton step (<= 4.5 ulp, a third of libm's instructions)
 #include <mutex>
 
 #define LS_NW 32
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(float* __restrict__ G
           p[q] = pre[it][q] + bsm[q * 8 + ul];
           if (s > 0) p[q] += red[n * 32 + q * 8 + ul] + red[(64 + n) * 32 + q * 8 + ul];
         }
-        const float ig = sigmoid_f(p[0]), fg = sigmoid_f(p[1]), gg = tanh_f(p[2]), og = sigmoid_f(p[3]);
+        const float ig = gru_sigmoid1(p[0]), fg = gru_sigmoid1(p[1]), gg = gru_tanh(p[2]), og = gru_sigmoid1(p[3]);
         const float c = fg * cst[item] + ig * gg;
-        const float h = og * tanh_f(c);
+        const float h = og * gru_tanh(c);
         cst[item] = c;
         unsigned short hv[3];
         ls_split3(h, hv);
@@ -362,9 +363,9 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
           p[q] = pre[it][q] + bsm[q * 8 + ul];
           if (s > 0) p[q] += red[n * 32 + q * 8 + ul] + red[(64 + n) * 32 + q * 8 + ul];
         }
-        const float ig = sigmoid_f(p[0]), fg = sigmoid_f(p[1]), gg = tanh_f(p[2]), og = sigmoid_f(p[3]);
+        const float ig = gru_sigmoid1(p[0]), fg = gru_sigmoid1(p[1]), gg = gru_tanh(p[2]), og = gru_sigmoid1(p[3]);
         const float c = fg * cst[item] + ig * gg;
-        const float h = og * tanh_f(c);
+        const float h = og * gru_tanh(c);
         cst[item] = c;
         unsigned short hv[3];
         ls_split3(h, hv);
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(float* __restrict__ G
           dhh += rsum[ul * 64 + n] + rsum[(8 + ul) * 64 + n];
           dc = dcc[item];
         }
-        const float tc = tanh_f(cc[it]);
+        const float tc = gru_tanh(cc[it]);
         const float dog = dhh * tc * og * (1.f - og);
         dc += dhh * og * (1.f - tc * tc);
         const float dig = dc * gg * ig * (1.f - ig);
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwdg_kernel(float* __restrict__ 
           dhh += rsum[ul * 64 + n] + rsum[(8 + ul) * 64 + n];
           dc = dcc[item];
         }
-        const float tc = tanh_f(cc[it]);
+        const float tc = gru_tanh(cc[it]);
         const float dog = dhh * tc * og * (1.f - og);
         dc += dhh * og * (1.f - tc * tc);
         const float dig = dc * gg * ig * (1.f - ig);

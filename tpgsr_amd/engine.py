@@ -207,6 +207,14 @@ class ConvLayer:
         """dx[N][H][W][Cin] = conv(dy[N][OH][OW][Cout], wt_d)"""
         K.conv_fwd(K.make_conv_args(self.geom(N, H, W).dgrad(), dy, self.wt_d, dx, **kw))
 
+    def dgrad_takes_folded_apply(self, N, H, W, dz, y, coef) -> bool:
+        """can this layer's data gradient take dy = c0 dz + c1 y + c2 (a BatchNorm's backward apply) through its LOADER -- i.e. does the
+        launch land on the whole-CU halo kernel, whose loader has the scaled residual operand (tpgsr_conv_args.in2_scale)?"""
+        if not (K.BNB_APPLY_FOLD and K.CONV_TERMS and not K.DRYRUN_NO_LIB()):
+            return False
+        a = K.make_conv_args(self.geom(N, H, W).dgrad(), dz, self.wt_d, dz, in_scale=coef[0], in_shift=coef[2], in2=y, in2_scale=coef[1])
+        return K.conv_in2_scale_ok(a)
+
     def wgrad(self, N, H, W, x, dy, *, loader: dict = None, dy_kw: dict = None):
         """dW += A^T dy and db += colsum(dy), straight into the gradient arena."""
         eng = self.eng
@@ -305,7 +313,7 @@ class BNLayer:
     def loader(self):
         return dict(in_scale=self.scale, in_shift=self.shift)
 
-    def fuse_stats(self, y, M, act, cin):
+    def fuse_stats(self, y, M, act, cin, store_dz=False):
         """kwargs (`bnb=`) for the convolution over `cin` channels that PRODUCES this BatchNorm's incoming gradient: its epilogue then
         leaves the reduction sums of the backward pass behind and backward(..., fused=True) skips the statistics launch.  None when
         the launch would not run on a kernel that has the epilogue (fp32 policy, switch off)."""
@@ -314,11 +322,32 @@ class BNLayer:
         nblk = (M + 63) // 64
         part = self.eng.scratch("bnb_partial" + K.stream_tag(), nblk * 2 * self.C)
         d = dict(y=y, mean=self.save_mean, rstd=self.save_rstd, scale=self.scale, shift=self.shift, act=act, partial=part,
+                 store_dz=bool(store_dz),          # the producer stores dz = da act'(.) instead of da (what backward_folded consumes)
                  coarse=not K.bn_fin_fused())      # (make_conv_args writes the granularity it settled on back as d["row_tiles"])
         if K.bn_fin_fused():       # the producing launch also reduces the sums (backward(..., fused=) then records the apply only)
             d["fin"] = dict(mode=2, count=M, counter=self.tickets[1:2], gamma=self.gamma, coef=self.coef,
                             dgamma=self.eng.G[self.prefix + ".weight"], dbeta=self.eng.G[self.prefix + ".bias"], accumulate=True)
         return d
+
+    def backward_folded(self, dz, y, M, dy, fused):
+        """The backward pass with its apply launch OFF the caller's stream (round 6).  `dz` = the incoming gradient
+        with the activation's derivative already in it (the producer's epilogue: fuse_stats(..., store_dz=True), or no activation), its
+        statistics in fused["partial"].  Records the finalize (coefficients, dgamma / dbeta) on the caller's stream, the apply
+        dy = c0 dz + c1 y + c2 on the WEIGHT-GRADIENT stream (the weight gradient that follows there is its only reader), and returns the
+        loader kwargs with which the consuming data-gradient convolution reads `dz` as if it were dy.  `dz` must not be recycled before the
+        weight-gradient stream is joined (the engines give it a buffer of its own)."""
+        eng = self.eng
+        assert fused is not None and fused["y"] is y and (fused["act"] in (None, "none") or fused.get("store_dz"))
+        nblk, part = K.bn_rows(M, fused.get("row_tiles", 1)), fused["partial"]
+        K.bn_bwd_finalize(part, nblk, self.C, M, self.gamma, self.save_mean, self.save_rstd, eng.G[self.prefix + ".weight"],
+                          eng.G[self.prefix + ".bias"], self.coef, accumulate=True)
+        with K.side():
+            K.bn_bwd_apply(dz, None, y, M, self.C, self.scale, self.shift, "none", self.coef, dy)
+        return dict(in_scale=self.coef[0], in_shift=self.coef[2], in2=y, in2_scale=self.coef[1])
+
+    def can_fold(self, M):
+        """the folded form replaces finalize + apply as recorded by backward(): not with the experimental in-launch finalizes"""
+        return K.BNB_APPLY_FOLD and not K.BN_FIN_FUSE and not K.bn_derive_ok(self.C, M) and self.C % 4 == 0
 
     def backward(self, da, da2, y, M, act, dy, fused=None):
         """dy = dL/d(pre-BN y) from da (+da2) = dL/d act(BN(y)); accumulates dgamma/dbeta into the arena.
@@ -1097,11 +1126,17 @@ class TSRNEngine(_EngineBase):
             return ws(tag + name if uniq else name, P1, C_)
 
         dy = buf("dy", "b7_", Cc)
-        self.bn7.backward(d_s, None, t["y7"], P1, "none", dy, fused=fz7)
         gA, gB = ws("gA", P1, Cc), ws("gB", P1, Cc)
         last_out = t[f"r{self.srb - 1}_out"] if self.srb else t["b1"]
-        self.conv7.wgrad(N, H, W, last_out, dy)
-        self.conv7.dgrad(N, H, W, dy, gA)
+        if fz7 is not None and self.bn7.can_fold(P1) and self.conv7.dgrad_takes_folded_apply(N, H, W, d_s, t["y7"], self.bn7.coef):
+            # the apply (dy for the weight gradient) on the weight-gradient stream; the data gradient reads d_s through the folded loader
+            ld7 = self.bn7.backward_folded(d_s, t["y7"], P1, dy, fz7)
+            self.conv7.wgrad(N, H, W, last_out, dy)
+            self.conv7.dgrad(N, H, W, d_s, gA, **ld7)
+        else:
+            self.bn7.backward(d_s, None, t["y7"], P1, "none", dy, fused=fz7)
+            self.conv7.wgrad(N, H, W, last_out, dy)
+            self.conv7.dgrad(N, H, W, dy, gA)
         have_B = False
         da = ws("da", P1, Cc)
         leaf = contextlib.ExitStack()
@@ -1130,7 +1165,9 @@ class TSRNEngine(_EngineBase):
                 # data gradient of the composed 96->192 projection in two column blocks: image features and text strip
                 # (leaf_early: block 0's BatchNorm backward runs on the leaf stream, its producer here -- no shared scratch across streams)
                 fz2 = None if (i == 0 and self.leaf_early) else L["bn2"].fuse_stats(y2, P1, "none", 192)
-                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, Cc), dgi, g1.wc_d, da, wt_ld=g1.Cin, wt_coff=0, bnb=fz2))
+                fold2 = fz2 is not None and L["bn2"].can_fold(P1) and L["conv2"].dgrad_takes_folded_apply(N, H, W, da, y2, L["bn2"].coef)
+                dz2 = ws(p + "c2_dz", P1, Cc) if fold2 else da      # (folded: the weight-gradient stream reads it later -- a buffer of its own)
+                K.conv_fwd(K.make_conv_args(ConvGeom(N, H, W, 192, Cc), dgi, g1.wc_d, dz2, wt_ld=g1.Cin, wt_coff=0, bnb=fz2))
                 # the text strip's share of the gradient (summed over the H rows it was broadcast to, accumulated over the blocks) only meets
                 # the caller's stream again at the InfoGen backward pass: it runs on the leaf stream (idle until the STN head's backward),
                 # block after block in order, next to the rest of this block on the caller's stream (round 5: -18 us per block there)
@@ -1140,7 +1177,9 @@ class TSRNEngine(_EngineBase):
                     K.hsum(dtb, N, H, W, self.Ct, ws("dtemb", N * W, self.Ct), accumulate=(i != self.srb - 1))
             else:
                 fz2 = None if (i == 0 and self.leaf_early) else L["bn2"].fuse_stats(y2, P1, "none", 192)
-                L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, da, dx_bnb=fz2, **L["bn2"].loader)
+                fold2 = fz2 is not None and L["bn2"].can_fold(P1) and L["conv2"].dgrad_takes_folded_apply(N, H, W, da, y2, L["bn2"].coef)
+                dz2 = ws(p + "c2_dz", P1, Cc) if fold2 else da
+                L["gru1"].bwd(N, H, W, y2, gt1, h1, gA, None, dgi, dgh, dz2, dx_bnb=fz2, **L["bn2"].loader)
             if i == 0 and self.leaf_early:
                 # Everything below only feeds parameter gradients (block 0's convolutions, block1, the STN head): the text-strip gradient
                 # dtemb is final here, so the caller's stream goes straight on to the InfoGen backward and the text-prior generator's
@@ -1152,14 +1191,29 @@ class TSRNEngine(_EngineBase):
                     K.leaf_join()
                 leaf.enter_context(K.leaf())
             dy = buf("dy", p + "c2_", Cc)
-            L["bn2"].backward(da, None, y2, P1, "none", dy, fused=fz2)
-            L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
-            fz1 = L["bn1"].fuse_stats(y1, P1, "mish", L["conv2"].Cout)
-            L["conv2"].dgrad(N, H, W, dy, da, bnb=fz1)                     # d mish(bn1(y1))
+            fold1 = (K.bnb_fusable(L["conv2"].Cout) and not (i == 0 and self.leaf_early) and L["bn1"].can_fold(P1) and
+                     L["conv1"].dgrad_takes_folded_apply(N, H, W, da, y1, L["bn1"].coef))
+            fz1 = L["bn1"].fuse_stats(y1, P1, "mish", L["conv2"].Cout, store_dz=fold1)
+            dz1 = ws(p + "c1_dz", P1, Cc) if fold1 else da
+            if fold2:
+                # bn2's apply runs on the weight-gradient stream (dy for conv2's weight gradient); conv2's data gradient reads dz2 + y2 with
+                # the three coefficients in its loader (csrc/conv_loader.h, LD bit 32): one launch less on the caller's stream per BatchNorm
+                ld2 = L["bn2"].backward_folded(dz2, y2, P1, dy, fz2)
+                L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
+                L["conv2"].dgrad(N, H, W, dz2, dz1, bnb=fz1, **ld2)      # d mish(bn1(y1)) (fold1: times mish', i.e. dz of bn1)
+            else:
+                L["bn2"].backward(dz2, None, y2, P1, "none", dy, fused=fz2)
+                L["conv2"].wgrad(N, H, W, t[p + "a1"], dy)
+                L["conv2"].dgrad(N, H, W, dy, dz1, bnb=fz1)                # d mish(bn1(y1))
             dy = buf("dy", p + "c1_", Cc)
-            L["bn1"].backward(da, None, y1, P1, "mish", dy, fused=fz1)
-            L["conv1"].wgrad(N, H, W, X, dy)
-            L["conv1"].dgrad(N, H, W, dy, gB)                              # second gradient path into X
+            if fold1:
+                ld1 = L["bn1"].backward_folded(dz1, y1, P1, dy, fz1)
+                L["conv1"].wgrad(N, H, W, X, dy)
+                L["conv1"].dgrad(N, H, W, dz1, gB, **ld1)                  # second gradient path into X
+            else:
+                L["bn1"].backward(dz1, None, y1, P1, "mish", dy, fused=fz1)
+                L["conv1"].wgrad(N, H, W, X, dy)
+                L["conv1"].dgrad(N, H, W, dy, gB)                          # second gradient path into X
             have_B = True
             if (self.srb - 1 - i) % nbb == nbb - 1 or i == 0 or (i == 1 and self.leaf_early):
                 K.side_batch_end(sb)

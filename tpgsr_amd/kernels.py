@@ -615,13 +615,14 @@ class ConvGeom:
 def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, in_scale=None, in_shift=None, in_act=None,
                    in_ps=False, in_ld=None, in_coff=0, in2_ld=None, out_act=None, out_ps=False, out_ld=None, out_coff=0,
                    bn_partial=None, in_b=None, cin_a=0, in_b_ld=None, in_dil_w=1, wt_ld=0, wt_coff=0, stride_w=1, bnb=None, bn_fin=None,
-                   bn_coarse=False) -> ConvArgs:
+                   bn_coarse=False, in2_scale=None) -> ConvArgs:
     """`bnb` (a dict from engine.BNLayer.fuse_stats): this convolution produces the gradient that enters a BatchNorm's backward pass --
     its epilogue also writes that BatchNorm's two reduction sums per 64-pixel row block (tpgsr_conv_args.bnb_y).
     `bn_fin` (a dict from engine.BNLayer.fin / fuse_stats(...)["fin"]): the launch also FINALIZES the BatchNorm whose statistics it
     leaves in bn_partial -- by its last workgroup where the kernel can, by an appended launch otherwise (tpgsr_conv_args.fin_mode)"""
     a = ConvArgs()
     a.in_, a.in2, a.in_scale, a.in_shift = _p(inp), _p(in2), _p(in_scale), _p(in_shift)
+    a.in2_scale = _p(in2_scale)        # a = in * in_scale + in_shift + in2 * in2_scale (whole-CU halo kernel only: conv_in2_scale_ok)
     a.wt, a.bias, a.out, a.bn_partial = _p(wt), _p(bias), _p(out), _p(bn_partial)
     a.N, a.H, a.W, a.Cin = g.N, g.H, g.W, g.Cin
     a.in_ld = (cin_a if in_b is not None else g.Cin) if in_ld is None else in_ld
@@ -682,6 +683,23 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
     return a
 
 
+def DRYRUN_NO_LIB() -> bool:
+    """a dry run (TPGSR_PLAN_DRYRUN=1) still loads the library for host-side queries; kept as a function so engines can ask in one place"""
+    return False
+
+
+def conv_in2_scale_ok(a: ConvArgs) -> bool:
+    """will tpgsr_conv_fwd take this launch with its scaled residual operand (in2_scale)?  Only the whole-CU halo kernel's loader has it"""
+    return bool(_lib.load().tpgsr_conv_in2_scale_ok(C.byref(a)))
+
+
+# TPGSR_BNB_APPLY_FOLD=1 (round 6, VERDICT round 5 item 4; OFF by default): the apply pass of a BatchNorm's backward runs on the
+# WEIGHT-GRADIENT stream only (it still produces dy for the weight gradient) and the caller's stream takes dy through the loader of the
+# consuming data-gradient convolution (tpgsr_conv_args.in2_scale, whole-CU halo kernel).  Built, tested (tests/test_conv_halo3_gpu.py,
+# the parity suite under the switch), measured on one box, interleaved: 5.456 / 5.492 ms per C3 step folded against 5.439 / 5.441 with
+# the eleven apply launches in place (profiles/r06i_bnb_apply_fold_ab.md) -- the two-operand loader has ONE register set (no load of the
+# next channel block in flight while this one is split), which costs the trunk's data gradient more than the 6-us launch it replaces.
+BNB_APPLY_FOLD = os.environ.get("TPGSR_BNB_APPLY_FOLD", "0") == "1"
 BN_COARSE_ROWS = os.environ.get("TPGSR_BN_COARSE_ROWS", "1") != "0"
 
 
