@@ -309,6 +309,10 @@ int tpgsr_softmax_max(const float* logits, int N, int C, int* ids, float* score,
 /* the whole-CU halo kernel (csrc/conv_halo3.hip: one workgroup per CU on three 64-pixel tiles at once, T <= 2) takes the KH x KW > 1 x 1
  * convolutions whose 192-pixel halo fits LDS and that fill the chip; 0 sends them back to the two-workgroup halo kernel (tests, A/B) */
 void tpgsr_halo3_set_enabled(int on);
+/* the tile-loop weight gradient with THREE 64-row k-blocks per workgroup (csrc/conv_xbf.hip: conv_wgrad_xbf3_kernel, round 6) takes the
+ * launches of tpgsr_conv_wgrad whose K is a multiple of 192 (plain / affine loader, dense dy, terms 1 or 2); 0 sends them back to the
+ * one-block kernel (tests, A/B).  Same slabs, same summation order. */
+void tpgsr_wgrad3_set_enabled(int on);
 /* tuning knob of the halo forward kernel: weight-plane bytes above which tiles are walked column-major per XCD (keeps an XCD's slice of
  * the weights in its L2); -1 never, 0 whenever the column-tile count allows, default 3 MB.  Results do not depend on it. */
 void tpgsr_halo_set_colmajor_min_bytes(long long v);
@@ -684,6 +688,11 @@ int tpgsr_ctc_greedy_decode(const float* logits, int N, int T, int C, int* label
 int tpgsr_psnr(const float* a, const float* b, int N, int Ctot, int H, int W, double* partial, int nblk, float* out, void* stream);
 int tpgsr_ssim(const float* a, const float* b, const float* window, int KS, int N, int Ctot, int H, int W, double* partial, int nblk,
                float* out, void* stream);
+/* SSIM as a loss (`--ssim_loss`, interfaces/super_resolution.py:388-391: loss_ssim = (1 - ssim(sr, hr).mean()) * 10): the gradient of the SSIM
+ * map's sum with respect to the first image, da[:, :min(Ctot,3)] (+)= mult * coef[0] * d(sum ssim_map)/da (NCHW; channels >= 3 untouched).
+ * gm: scratch of 3 * N * min(Ctot,3) * H * W floats; coef: optional device scalar (upstream gradient).  utils/ssim_psnr.py:30-50. */
+int tpgsr_ssim_bwd(const float* a, const float* b, const float* window, int KS, int N, int Ctot, int H, int W, float* gm,
+                   const float* coef, float mult, float* da, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser -- clip_grad_norm_(0.25) + Adam(lr 1e-3, betas (0.5,0.999)) over flat arenas

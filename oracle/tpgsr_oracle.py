@@ -613,7 +613,7 @@ def tsrn_train_step(p, opt: AdamState, lr_img: Tensor, hr_img: Tensor, *, stn=Tr
 
 def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dict, opt: AdamState,
                      lr_img: Tensor, hr_img: Tensor, *, stu_iter=1, sr_share=True, tpg_share=False, stn=True,
-                     srb_nums=5, gradient=True, explicit_rnn=False, grid_align_corners=False, tpg_forward=None):
+                     srb_nums=5, gradient=True, explicit_rnn=False, grid_align_corners=False, tpg_forward=None, ssim_loss=False):
     """Configs C3-C5: ``tsrn_tl_cascade`` branch, super_resolution.py:295-406 + :419-424.
     teacher(HR).detach -> per stage: student(prev image) -> softmax -> distill loss -> (N,37,1,26)
     -> zero the prior of samples [0, N//4) -> SR net -> image loss; sum; backward;
@@ -643,6 +643,8 @@ def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dic
         cascade = tsrn_forward(srp, lr_img, prior, training=True, stn=stn, srb_nums=srb_nums, text_prior=True,
                                explicit_rnn=explicit_rnn, grid_align_corners=grid_align_corners)
         loss_img = loss_img + image_loss(cascade, hr_img, gradient).mean() * 100
+        if ssim_loss:      # `--ssim_loss`, super_resolution.py:388-391: loss_ssim = (1 - ssim(cascade_images, images_hr).mean()) * 10.
+            loss_img = loss_img + (1 - ssim(cascade, hr_img).mean()) * 10.
     loss = loss_img + loss_distill
     groups = [[(m, k) for k in trainable_keys(m)] for m in sr_params] + \
              [[(m, k) for k in trainable_keys(m)] for m in stu_params]

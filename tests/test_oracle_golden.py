@@ -169,3 +169,27 @@ def test_eval_metrics_oracle_vs_reference_fixture(golden_dir):
     a, b = torch.tensor(g["a"]), torch.tensor(g["b"])
     assert abs(float(O.calculate_psnr(a, b)) - float(g["psnr"])) < 1e-5
     assert abs(float(O.ssim(a, b)) - float(g["ssim"])) < 1e-6
+
+
+def test_ssim_loss_branch_oracle_vs_reference_fixture(golden_dir):
+    """`--ssim_loss` (interfaces/super_resolution.py:388-391): the oracle's SSIM, its gradient and the C3-shaped step with the SSIM term
+    against tests/golden/ssim_loss.npz (written by make_golden_ssim.py from the imported reference)"""
+    import os
+    import numpy as np
+    import torch
+    from oracle import tpgsr_oracle as O
+    g = np.load(os.path.join(golden_dir, "ssim_loss.npz"))
+    for case in ("noise", "near"):
+        x = torch.tensor(g[f"{case}_x"]).requires_grad_(True)
+        v = O.ssim(x, torch.tensor(g[f"{case}_y"])).mean()
+        (gr,) = torch.autograd.grad((1 - v) * 10., x)
+        assert abs(v.item() - float(g[f"{case}_value"])) < 1e-6
+        assert (gr - torch.tensor(g[f"{case}_grad"])).abs().max() < 1e-7
+    lr, hr = torch.tensor(g["lr"]), torch.tensor(g["hr"])
+    ps = O.as_params(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 301, tps_hw=(16, 64)))
+    pt, pu = O.as_params(O.recipe_state_dict(O.crnn_spec(), 302), False), O.as_params(O.recipe_state_dict(O.crnn_spec(), 303))
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [pu[k] for k in O.trainable_keys(pu)])
+    r = O.tpgsr_train_step([ps], [pu], pt, opt, lr, hr, stu_iter=1, ssim_loss=True)
+    assert abs(float(r["loss"]) - g["loss"][0]) < 1e-4 * g["loss"][0]
+    assert abs(float(r["grad_norms"][0]) - g["gnorm"][0]) < 1e-3 * g["gnorm"][0]
+    assert (r["priors"][0].argmax(-1).numpy() == g["prior_argmax_step0"]).all()

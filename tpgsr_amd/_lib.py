@@ -220,6 +220,7 @@ _SIGS = {
     "tpgsr_ctc_greedy_decode": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "tpgsr_psnr": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
     "tpgsr_ssim": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp]),
+    "tpgsr_ssim_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, cf, vp, ci, vp]),
     "tpgsr_split_bf_blocks": (ci, [ci, ci]),
     "tpgsr_split_bf_program": (ci, [vp, ci, ci, vp]),
     "tpgsr_tr_probe": (ci, [vp, vp]),
@@ -236,6 +237,7 @@ _SIGS = {
     "tpgsr_halo_set_min_taps": (None, [ci]),
     "tpgsr_halo_set_ne9": (None, [ci]),
     "tpgsr_halo3_set_enabled": (None, [ci]),
+    "tpgsr_wgrad3_set_enabled": (None, [ci]),
     "tpgsr_panel_set_enabled": (None, [ci]),
     "tpgsr_panel_set_min_m": (None, [C.c_longlong]),
     "tpgsr_panel_set_k192": (None, [ci]),

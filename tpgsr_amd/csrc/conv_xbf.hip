@@ -920,6 +920,180 @@ __global__ __launch_bounds__(256) void conv_wgrad_xbf_kernel(tpgsr_wgrad_args w,
   conv_wgrad_xbf_body<LD, T>(w, M, K, MB, blockIdx.x, gridDim.x, Am, Ym);
 }
 
+// THREE k-blocks per workgroup (round 6).  The tile loop above spends ~600 instructions per wave on a 32-pixel chunk -- pixel decoding by
+// integer division, address arithmetic, the split of BOTH operands, LDS staging -- for SIX MFMAs: its launches are instruction-bound at
+// 0.10-0.13 of their class peak (SQ counters, profiles/r06_sq_family.md: matrix pipe 13 % busy, 32 % of the wave cycles issuing).  Here a
+// workgroup owns 192 k-rows x 64 columns (three taps of a 64-channel layer: one kernel row of the trunk's 3x3): dy is loaded, split and
+// staged ONCE for three times the MFMAs, every wave keeps three independent accumulator chains, and the output pixel of a thread is
+// advanced from chunk to chunk by additions (no division inside the loop).  Same slabs (part[z][k][n]), same per-split pixel ranges, same
+// summation order per output element as the one-block kernel.  Plain / affine loaders, dense dy, T <= 2.
+template <int LD, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_xbf3_kernel(tpgsr_wgrad_args w, int M, int K, int MB) {
+  __shared__ __attribute__((aligned(16))) unsigned char Am[3][T * XW_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Ym[T * XW_PLANE];
+  const tpgsr_conv_args& a = w.c;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wk = wave & 1, wn = wave >> 1;
+  const int nkb = K / (3 * WK), nnb = (a.Cout + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);       // k-block fastest: the k-blocks of one pixel split share an L2
+  const int kblk = tile % nkb, nblk = (tile / nkb) % nnb, zblk = tile / (nkb * nnb);
+  const int k0 = kblk * 3 * WK, n0 = nblk * BN;
+  const int mbeg = zblk * MB;
+  const int mend = min(M, mbeg + MB);
+  const int aq = tid & 15, ap0 = tid >> 4, yc = (tid & 15) * 4;
+
+  // this thread's three A quads: (tap, 4 channels) of k-block j, fixed for the whole kernel
+  int dih[3], diw[3], coff[3];
+  float4 qs[3], qt[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const KPos kp = kpos_init(a, ((k0 + j * WK) >> 2) + aq);
+    dih[j] = kp.kh - a.pad_h;
+    diw[j] = kp.kw - a.pad_w;
+    coff[j] = a.in_coff + kp.c;
+    qs[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    qt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LD & 1) {
+      qs[j] = *reinterpret_cast<const float4*>(a.in_scale + kp.c);
+      qt[j] = *reinterpret_cast<const float4*>(a.in_shift + kp.c);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (size_t)a.N * a.H * a.W * a.in_ld);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(w.dy, (size_t)M * w.dy_ld);
+  const bool cok = n0 + yc < a.Cout;
+
+  // output pixels of this thread's two rows (ap0, ap0 + 16) of the current chunk, decoded once and advanced by WM per chunk
+  int pm[2], pn[2], poh[2], pow_[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int m = mbeg + ap0 + 16 * r, ohw = a.OH * a.OW;
+    pm[r] = m;
+    pn[r] = m / ohw;
+    const int rem = m - pn[r] * ohw;
+    poh[r] = rem / a.OW;
+    pow_[r] = rem - poh[r] * a.OW;
+  }
+  float4 qa[2][3], ry[2];
+  bool qok[2][3];
+  auto load_chunk = [&]() __attribute__((always_inline)) {      // the chunk the position state points at; then advance the state
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool valid = pm[r] < mend;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ih = poh[r] + dih[j], iw = pow_[r] + diw[j];
+        const bool ok = valid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        qok[r][j] = ok;
+        qa[r][j] = buf_load4(rs_in, ok ? ((unsigned)((pn[r] * a.H + ih) * a.W + iw) * (unsigned)a.in_ld + (unsigned)coff[j]) * 4u : OOB_OFF);
+      }
+      ry[r] = buf_load4(rs_dy, (valid && cok) ? ((unsigned)pm[r] * (unsigned)w.dy_ld + (unsigned)(w.dy_coff + n0 + yc)) * 4u : OOB_OFF);
+      pm[r] += WM;
+      pow_[r] += WM;
+      while (pow_[r] >= a.OW) {        // (WM / OW + 1 iterations at most)
+        pow_[r] -= a.OW;
+        if (++poh[r] == a.OH) {
+          poh[r] = 0;
+          ++pn[r];
+        }
+      }
+    }
+  };
+  float4 dbq = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of dy over this thread's pixel rows (bias gradient)
+  const bool want_db = (w.dbpart != nullptr) && kblk == 0;
+  auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = ap0 + 16 * r;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float4 v = qa[r][j];
+        if (LD & 1) {      // (the affine maps the hardware zero fill to t: padding is re-zeroed)
+          v.x = qok[r][j] ? v.x * qs[j].x + qt[j].x : 0.f;
+          v.y = qok[r][j] ? v.y * qs[j].y + qt[j].y : 0.f;
+          v.z = qok[r][j] ? v.z * qs[j].z + qt[j].z : 0.f;
+          v.w = qok[r][j] ? v.w * qs[j].w + qt[j].w : 0.f;
+        }
+        uint2 h[T];
+        split4<T>(v, h);
+#pragma unroll
+        for (int t = 0; t < T; ++t) *reinterpret_cast<uint2*>(Am[j] + t * XW_PLANE + row * XW_ROW + aq * 8) = h[t];
+      }
+      uint2 y[T];
+      split4<T>(ry[r], y);
+#pragma unroll
+      for (int t = 0; t < T; ++t) *reinterpret_cast<uint2*>(Ym + t * XW_PLANE + row * XW_ROW + aq * 8) = y[t];
+    }
+    if (want_db) {      // (the pair first, as the one-block kernel: the same partial sums bit for bit)
+      dbq.x += ry[0].x + ry[1].x;
+      dbq.y += ry[0].y + ry[1].y;
+      dbq.z += ry[0].z + ry[1].z;
+      dbq.w += ry[0].w + ry[1].w;
+    }
+  };
+
+  floatx16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  if (mbeg < mend) {
+    load_chunk();
+    store_chunk();
+  }
+  __syncthreads();
+  for (int mc = mbeg; mc < mend; mc += WM) {
+    const bool more = mc + WM < mend;
+    if (more) load_chunk();
+#pragma unroll
+    for (int mb = 0; mb < WM / 16; ++mb) {
+      bf16x8 bv[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) bv[t] = frag_tr(Ym + t * XW_PLANE, lane, wn * 32, mb);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        bf16x8 av[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) av[t] = frag_tr(Am[j] + t * XW_PLANE, lane, wk * 32, mb);
+        acc[j] = mfma_terms<T>(av, bv, acc[j]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+  const int n = n0 + wn * 32 + (lane & 31);
+  float* dst = w.part + (size_t)zblk * K * a.Cout;
+  if (n < a.Cout) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + j * WK + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[(size_t)k * a.Cout + n] = acc[j][r];
+      }
+  }
+  if (want_db) {   // combine the 16 pixel-row lanes of every channel quad in a fixed order
+    float* red = reinterpret_cast<float*>(Am[0]);        // [16 row lanes][64 channels]; MFMA reads are behind the last barrier
+    *reinterpret_cast<float4*>(red + ap0 * 64 + yc) = dbq;
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Cout) {
+      float sdb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sdb += red[r * 64 + tid];
+      w.dbpart[(size_t)zblk * a.Cout + n0 + tid] = sdb;
+    }
+  }
+}
+
+static int g_wg3_on = [] { const char* e = getenv("TPGSR_XBF_WGRAD3"); return (e && e[0] == '0') ? 0 : 1; }();
+/* experiment / test switch: 0 sends every tile-loop weight gradient back to the one-block kernel */
+extern "C" void tpgsr_wgrad3_set_enabled(int on) { g_wg3_on = on ? 1 : 0; }
+
 // Several INDEPENDENT weight-gradient GEMMs in one launch (a device-resident item table, like the pack / reduce programs).  The two
 // BiLSTM layers of the text-prior generator have ten of them -- 2 directions x (hidden side, input side) + the embedding, per layer --
 // over M = N T = 1248 rows each: a launch alone is 25-65 us of start-up, four splits of ten 32-row chunks and a slab write, and the ten
@@ -996,8 +1170,21 @@ extern "C" int tpgsr_conv_wgrad_batch(const tpgsr_wgrad_batch_item* items_dev, i
 
 extern "C" int tpgsr_conv_wgrad_xbf_launch(const tpgsr_wgrad_args* w, long long M, int K, int Z, int MB, int ld, hipStream_t st) {
   const tpgsr_conv_args* a = &w->c;
-  dim3 grid(cdiv(K, WK) * cdiv(a->Cout, BN) * Z);
   const int T = a->terms;
+  // three k-blocks per workgroup where the shape allows: K a multiple of 192, the plain / affine loader, dense dy, a plain stride-1 geometry
+  if (g_wg3_on && T >= 1 && T <= 2 && K % (3 * WK) == 0 && (ld == 0 || ld == 1) && !w->dy_ps && a->in_dil_w <= 1 && a->stride_w <= 1 &&
+      !a->in_ps && (a->Cin & 3) == 0 && M * (long long)w->dy_ld * 4 <= 0x7fffffffll) {
+    dim3 grid3((K / (3 * WK)) * cdiv(a->Cout, BN) * Z);
+    if (ld == 0) {
+      if (T == 1) hipLaunchKernelGGL((conv_wgrad_xbf3_kernel<0, 1>), grid3, dim3(256), 0, st, *w, (int)M, K, MB);
+      else hipLaunchKernelGGL((conv_wgrad_xbf3_kernel<0, 2>), grid3, dim3(256), 0, st, *w, (int)M, K, MB);
+    } else {
+      if (T == 1) hipLaunchKernelGGL((conv_wgrad_xbf3_kernel<1, 1>), grid3, dim3(256), 0, st, *w, (int)M, K, MB);
+      else hipLaunchKernelGGL((conv_wgrad_xbf3_kernel<1, 2>), grid3, dim3(256), 0, st, *w, (int)M, K, MB);
+    }
+    TPGSR_LAUNCH_CHECK("tpgsr_conv_wgrad(bf16 MFMA, three k-blocks)");
+  }
+  dim3 grid(cdiv(K, WK) * cdiv(a->Cout, BN) * Z);
 #define XBF_WG_CASE(B)                                                                                       \
   case B:                                                                                                    \
     if (T == 1) hipLaunchKernelGGL((conv_wgrad_xbf_kernel<B, 1>), grid, dim3(256), 0, st, *w, (int)M, K, MB); \

@@ -198,7 +198,9 @@ class TPGSRTrainStep:
 
     def __init__(self, sr_models, students, teacher, stu_iter=1, sr_share=True, tpg_share=False, gradient=True,
                  loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1,
-                 force_collectives=False, precision: Optional[str] = None):
+                 force_collectives=False, precision: Optional[str] = None, ssim_loss: bool = False):
+        # `--ssim_loss` (interfaces/super_resolution.py:388-391): every stage adds (1 - ssim(cascade_images, images_hr).mean()) * 10 to its image loss
+        self.ssim_loss = bool(ssim_loss)
         # arithmetic policy of the step's GEMMs (kernels.py): `precision`, else an explicit TPGSR_CONV_PREC / set_conv_prec, else "x2" --
         # the benchmarked policy, gated at full size against the oracle on both north_star gates (tests/test_policy_x2*_gpu.py)
         self.precision = K.train_step_policy(precision)
@@ -254,6 +256,11 @@ class TPGSRTrainStep:
                       prior=[torch.empty(N, 37, 1, 26, device=dev) for _ in range(S)],
                       dsr=[torch.empty(N, C, 2 * H, 2 * W, device=dev) for _ in range(S)],
                       dcas=torch.empty(N, C, 2 * H, 2 * W, device=dev), dlogits=torch.empty(N, 26, 37, device=dev))
+            if self.ssim_loss:
+                from ..utils.ssim_psnr import create_window
+                cc = min(C, 3)
+                st.update(ssim_win=create_window(11, 1)[0, 0].contiguous().to(dev), ssim_part=torch.empty(256, dtype=torch.float64, device=dev),
+                          ssim_out=torch.empty(1, device=dev), ssim_gm=torch.empty(3 * N * cc * 4 * H * W, device=dev))
             self._static = st
         return self._static
 
@@ -314,6 +321,10 @@ class TPGSRTrainStep:
                 K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK_IMG)
                 n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
                 K.image_loss_finalize(st["part_img"][i], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
+                if self.ssim_loss:      # loss_img += (1 - ssim.mean()) * 10: the mean by tpgsr_ssim, the scalar arithmetic by three ATen launches
+                    K.ssim(sr, hr, st["ssim_win"], 11, N, C, H2, W2, st["ssim_part"], 256, st["ssim_out"])
+                    if not K.DRYRUN:
+                        st["l_img"][i].add_(st["ssim_out"][0].neg().add_(1.0).mul_(10.0))
             srs.append(sr)
             self._mark(f"SR{i} fwd + loss")
             cascade, ch, cw = sr, H2, W2
@@ -329,6 +340,8 @@ class TPGSRTrainStep:
             stu = self.stu[0 if self.tpg_share else i]
             srm = self.sr[0 if self.sr_share else i]
             K.image_loss_bwd(srs[i], hr, st["dloss"], N, C, H2, W2, self.gradient, self.w0, self.w1, st["dsr"][i])
+            if self.ssim_loss:             # d/d sr of (1 - mean ssim) * 10, added to the first three channels of the image-loss gradient
+                K.ssim_bwd(srs[i], hr, st["ssim_win"], 11, N, C, H2, W2, st["ssim_gm"], None, -10.0 / (N * min(C, 3) * H2 * W2), st["dsr"][i], True)
             if i < self.stu_iter - 1:      # gradient arriving through the next stage's parse_crnn_data
                 K.add(st["dsr"][i], st["dcas"], st["dsr"][i].numel(), st["dsr"][i])
             dprior = srm._engine().backward(tuple(lr_img.shape), srs[i], st["dsr"][i], slot=i, defer_join=self._defer_join)

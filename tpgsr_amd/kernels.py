@@ -1436,6 +1436,11 @@ def ssim(a, b, window, KS, N, Ctot, H, W, partial, nblk, out):
     _launch("tpgsr_ssim", _p(a), _p(b), _p(window), KS, N, Ctot, H, W, _p(partial), nblk, _p(out))
 
 
+def ssim_bwd(a, b, window, KS, N, Ctot, H, W, gm, coef, mult, da, accumulate):
+    """da[:, :min(Ctot,3)] (+)= mult * coef[0] * d(sum of the SSIM map)/da  (`--ssim_loss`; gm: scratch 3 N min(Ctot,3) H W floats)"""
+    _launch("tpgsr_ssim_bwd", _p(a), _p(b), _p(window), KS, N, Ctot, H, W, _p(gm), _p(coef), float(mult), _p(da), int(bool(accumulate)))
+
+
 # ---- ASTER evaluation recognizer, greedy decode (csrc/aster.hip) ----------------------------------------------------
 def bicubic_resize(x_nchw, N, Ctot, C_, H, W, OH, OW, scale, shift, out_nhwc):
     _launch("tpgsr_bicubic_resize", _p(x_nchw), N, Ctot, C_, H, W, OH, OW, float(scale), float(shift), _p(out_nhwc))

@@ -1,8 +1,9 @@
 """PSNR and SSIM of the evaluation path with the reference's signatures (reference: utils/ssim_psnr.py:9-15 calculate_psnr,
 :18-78 gaussian / create_window / SSIM): whole batch, first 3 channels, PSNR on x255 values; SSIM with the 11x11 Gaussian
 (sigma 1.5) window, zero padding, size_average.  CUDA tensors go through the tpgsr_psnr / tpgsr_ssim reduction kernels (one
-pass each, fp64 combine); the metric is a pure function of two image batches, no gradient is defined (the reference never
-back-propagates through it)."""
+pass each, fp64 combine).  Since round 6 the SSIM module is differentiable with respect to its FIRST argument (the reference's
+`--ssim_loss` branch, interfaces/super_resolution.py:388-391: `(1 - ssim(cascade_images, images_hr).mean()) * 10`): its backward is
+tpgsr_ssim_bwd (csrc/metrics.hip); the second image (HR) gets no gradient, as in the reference's use.  PSNR stays a pure metric."""
 from math import exp
 
 import torch
@@ -53,9 +54,38 @@ class SSIM(torch.nn.Module):
         from .. import kernels as K
         if not (img1.is_cuda and img2.is_cuda) and not K.DRYRUN:
             raise RuntimeError("tpgsr_amd.utils.ssim_psnr runs on the GPU only (no CPU fallback)")
+        win = self.window.to(img1.device)
+        if torch.is_grad_enabled() and img1.requires_grad:
+            return _SSIMFn.apply(img1, img2.detach(), win, self.window_size)
         a, b = img1.detach().contiguous().float(), img2.detach().contiguous().float()
         N, C, H, W = a.shape
-        win = self.window.to(a.device)
         part, out = _scratch(a.device)
         K.ssim(a, b, win, self.window_size, N, C, H, W, part, _NBLK, out)
         return out[0]
+
+
+class _SSIMFn(torch.autograd.Function):
+    """mean SSIM of the first min(C, 3) channels, differentiable in the first image (tpgsr_ssim / tpgsr_ssim_bwd)"""
+
+    @staticmethod
+    def forward(ctx, img1, img2, win, ks):
+        from .. import kernels as K
+        a, b = img1.detach().contiguous().float(), img2.detach().contiguous().float()
+        N, C, H, W = a.shape
+        part, out = _scratch(a.device)
+        K.ssim(a, b, win, ks, N, C, H, W, part, _NBLK, out)
+        ctx.save_for_backward(a, b, win)
+        ctx.ks = ks
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import kernels as K
+        a, b, win = ctx.saved_tensors
+        N, C, H, W = a.shape
+        cc = min(C, 3)
+        gm = torch.empty(3 * N * cc * H * W, dtype=torch.float32, device=a.device)
+        da = torch.zeros_like(a)
+        coef = g.detach().reshape(1).float().contiguous()
+        K.ssim_bwd(a, b, win, ctx.ks, N, C, H, W, gm, coef, 1.0 / (N * cc * H * W), da, False)
+        return da, None, None, None
