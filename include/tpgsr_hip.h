@@ -611,6 +611,12 @@ int tpgsr_softmax_prior_fwd(const float* logits, const float* q, int N, int T, i
 int tpgsr_semantic_loss_finalize(const float* partial, int nblk, long long count, float w, float* loss, void* stream);
 int tpgsr_softmax_prior_bwd(const float* p, const float* q, const float* dprior_nchw, const float* dp_in, int N, int T, int C,
                             int drop_n, float wsem, float* dlogits, int nblk, void* stream);
+/* CTC loss of the text-prior generator's logits (`--use_label`: ctc_loss = torch.nn.CTCLoss(blank=0, reduction='none') on
+ * label_vecs_logits.log_softmax(2), weighted by weighted_tics and averaged; interfaces/super_resolution.py:40, :347-366).
+ * nll[n]; dlogits (optional; element (n, t, c) at n * sn + t * st + c like logits) (+)= scale * weight[n] * d nll[n] / d logits.
+ * targets: concatenated int32 labels, sample n at [tgt_off[n], tgt_off[n] + tgt_len[n]); T <= 32, C <= 64, max_len (the longest target) <= 31. */
+int tpgsr_ctc_loss(const float* logits, int sn, int st, const int* targets, const int* tgt_off, const int* tgt_len, const float* weight,
+                   int N, int T, int C, int blank, float scale, float* nll, float* dlogits, int accumulate, int max_len, void* stream);
 /* SemanticLoss.forward(pred, gt) on probability tensors (loss/semantic_loss.py:21-39, the nn.Module entry point):
  * partial [nblk][2] = (sum|q-p|, sum q'(log q' - log p')) -> tpgsr_semantic_loss_finalize; bwd: dp = dloss*(-sign(q-p) - q'/p')/n */
 int tpgsr_semantic_loss_fwd(const float* p, const float* q, long long n, float* partial, int nblk, void* stream);

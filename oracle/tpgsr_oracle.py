@@ -613,7 +613,8 @@ def tsrn_train_step(p, opt: AdamState, lr_img: Tensor, hr_img: Tensor, *, stn=Tr
 
 def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dict, opt: AdamState,
                      lr_img: Tensor, hr_img: Tensor, *, stu_iter=1, sr_share=True, tpg_share=False, stn=True,
-                     srb_nums=5, gradient=True, explicit_rnn=False, grid_align_corners=False, tpg_forward=None, ssim_loss=False):
+                     srb_nums=5, gradient=True, explicit_rnn=False, grid_align_corners=False, tpg_forward=None, ssim_loss=False,
+                     use_label=False, use_distill=True, labels=None):
     """Configs C3-C5: ``tsrn_tl_cascade`` branch, super_resolution.py:295-406 + :419-424.
     teacher(HR).detach -> per stage: student(prev image) -> softmax -> distill loss -> (N,37,1,26)
     -> zero the prior of samples [0, N//4) -> SR net -> image loss; sum; backward;
@@ -634,7 +635,15 @@ def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dic
         logits = tpg_forward(stu, parse_crnn_data(cascade[:, :3]), training=True)
         pv = F.softmax(logits, -1)                                   # (26, N, 37)
         prior = pv.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)  # (N, 37, 1, 26)
-        loss_distill = loss_distill + semantic_loss(pv, q) * 100
+        if use_label:       # `--use_label`, super_resolution.py:347-366 (ctc_loss = torch.nn.CTCLoss(blank=0, reduction='none'), :40)
+            label_vecs, weighted_mask, weighted_tics = labels
+            text_sum = label_vecs.sum(1).squeeze(1)
+            text_len = (text_sum > 0).float().sum(1).reshape(-1)
+            predicted_length = torch.ones(logits.shape[1]) * logits.shape[0]
+            fsup = F.ctc_loss(logits.log_softmax(2), weighted_mask.long(), predicted_length.long(), text_len.long(), blank=0, reduction="none")
+            loss_distill = loss_distill + (fsup * weighted_tics.float()).mean()
+        if use_distill:
+            loss_distill = loss_distill + semantic_loss(pv, q) * 100
         drop = torch.ones(lr_img.shape[0])
         drop[: lr_img.shape[0] // 4] = 0.0
         prior = prior * drop.view(-1, 1, 1, 1)
@@ -661,6 +670,39 @@ def tpgsr_train_step(sr_params: List[dict], stu_params: List[dict], teacher: dic
     return {"loss": loss.detach(), "loss_img": torch.as_tensor(loss_img).detach(),
             "loss_distill": torch.as_tensor(loss_distill).detach(), "grad_norms": gnorms,
             "sr": cascade.detach(), "priors": priors, "grads": grads}
+
+
+COLLATE_D2A = "-0123456789abcdefghijklmnopqrstuvwxyz"
+
+
+def collate_labels(label_strs):
+    """The label half of alignCollate_realWTLAMask.__call__ (dataset/dataset.py:1255-1323; alphabet :1108-1116): per word (lower-cased, cut
+    to 15 characters when longer than 14) the indices of its characters in "-0123456789a..z" (characters outside it are dropped) ->
+    label_vecs (N, 37, 1, max_len) one-hot (max_len = the longest WORD), weighted_mask = all index lists concatenated (an empty list
+    contributes one 0 and a one-hot on the blank), weighted_tics (N) = 1 for words with at least one label, else 0."""
+    a2d = {ch: i for i, ch in enumerate(COLLATE_D2A)}
+    alsize = len(COLLATE_D2A)
+    max_len, batches, masks, tics = 0, [], [], []
+    for word in label_strs:
+        word = word.lower()
+        if not (len(word) <= 1 or 1 < len(word) < 15):
+            word = word[:15]
+        label_list = [a2d[ch] for ch in word if ch in a2d]
+        masks.extend(label_list if label_list else [0])
+        max_len = max(max_len, len(word))
+        if label_list:
+            v = torch.zeros(len(label_list), alsize)
+            v.scatter_(-1, torch.tensor(label_list)[:, None].long(), 1)
+            tics.append(1)
+        else:
+            v = torch.zeros(1, alsize)
+            v[0, 0] = 1.
+            tics.append(0)
+        batches.append(v)
+    out = torch.zeros(len(label_strs), max_len, alsize)
+    for i, v in enumerate(batches):
+        out[i][:v.shape[0]] = v
+    return out.unsqueeze(1).float().permute(0, 3, 1, 2), torch.tensor(masks).long(), torch.tensor(tics)
 
 
 def srcnn_train_step(p, opt: AdamState, lr_img: Tensor, hr_img: Tensor):

@@ -193,3 +193,27 @@ def test_ssim_loss_branch_oracle_vs_reference_fixture(golden_dir):
     assert abs(float(r["loss"]) - g["loss"][0]) < 1e-4 * g["loss"][0]
     assert abs(float(r["grad_norms"][0]) - g["gnorm"][0]) < 1e-3 * g["gnorm"][0]
     assert (r["priors"][0].argmax(-1).numpy() == g["prior_argmax_step0"]).all()
+
+
+def test_use_label_branch_oracle_vs_reference_fixture(golden_dir):
+    """`--use_label` (interfaces/super_resolution.py:347-366): the oracle's collate labels, CTC term and C3-shaped step against
+    tests/golden/ctc_loss.npz (written by make_golden_ctc.py: reference modules + torch.nn.CTCLoss as the reference file calls it)"""
+    import os
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import tpgsr_oracle as O
+    g = np.load(os.path.join(golden_dir, "ctc_loss.npz"))
+    lv, wm, wt = O.collate_labels([str(w) for w in g["words"]])
+    assert np.array_equal(lv.numpy(), g["label_vecs"]) and np.array_equal(wm.numpy(), g["weighted_mask"]) and np.array_equal(wt.numpy(), g["weighted_tics"])
+    logits = torch.tensor(g["logits"])
+    tl = (lv.sum(1).squeeze(1) > 0).float().sum(1).long()
+    nll = F.ctc_loss(logits.log_softmax(2), wm, torch.full((logits.shape[1],), logits.shape[0], dtype=torch.long), tl, blank=0, reduction="none")
+    assert (nll - torch.tensor(g["nll"])).abs().max() < 1e-4
+    lr, hr = torch.tensor(g["lr"]), torch.tensor(g["hr"])
+    ps = O.as_params(O.recipe_state_dict(O.tsrn_spec(STN=True, mask=True, text_prior=True), 301, tps_hw=(16, 64)))
+    pt, pu = O.as_params(O.recipe_state_dict(O.crnn_spec(), 302), False), O.as_params(O.recipe_state_dict(O.crnn_spec(), 303))
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [pu[k] for k in O.trainable_keys(pu)])
+    r = O.tpgsr_train_step([ps], [pu], pt, opt, lr, hr, stu_iter=1, use_label=True, labels=(lv, wm, wt))
+    assert abs(float(r["loss"]) - g["loss"][0]) < 1e-4 * g["loss"][0]
+    assert abs(float(r["grad_norms"][0]) - g["gnorm"][0]) < 1e-3 * g["gnorm"][0]

@@ -188,6 +188,7 @@ _SIGS = {
     "tpgsr_softmax_prior_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]),
     "tpgsr_semantic_loss_finalize": (ci, [vp, ci, ll, cf, vp, vp]),
     "tpgsr_softmax_prior_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, ci, vp]),
+    "tpgsr_ctc_loss": (ci, [vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, ci, ci, vp]),
     "tpgsr_tail_shiftsum_tanh": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_shiftsum_nhwc": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
     "tpgsr_tail_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]),

@@ -1032,3 +1032,113 @@ extern "C" int tpgsr_semantic_loss_bwd(const float* p, const float* q, const flo
   hipLaunchKernelGGL(semantic_loss_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, q, dloss, n, dp);
   TPGSR_LAUNCH_CHECK("tpgsr_semantic_loss_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// CTC loss of the text-prior generator's logits (`--use_label`, interfaces/super_resolution.py:40, :347-366:
+// ctc_loss = torch.nn.CTCLoss(blank=0, reduction='none') on label_vecs_logits.log_softmax(2); the per-sample values are weighted by
+// weighted_tics and averaged).  One wavefront per sample: lane s owns state s of the extended label l' (blank, l_1, blank, ... l_L, blank:
+// S = 2 L + 1 <= 63), the forward variables alpha_t(s) are kept in LDS for all T <= 32 steps, the backward variables beta_t(s) in a register;
+// everything in log space as ATen's LossCTC.cpp does (alpha and beta both include log p_t(l'_s)):
+//   nll      = -logsumexp(alpha_{T-1}(S-1), alpha_{T-1}(S-2))
+//   d nll / d logit[t][k] = p_t(k) - exp( logsumexp_{s: l'_s = k}(alpha_t(s) + beta_t(s)) + nll - log p_t(k) )
+// logits: element (n, t, c) at n * sn + t * st + c (the fused step keeps [N][T][C], the module API's tensor is [T][N][C]).
+// dlogits (same addressing) (+)= scale * weight[n] * d nll_n / d logits.  Infeasible targets (T too short) give nll = +inf as in ATen.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ctc_lse2(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float ctc_lse3(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+__global__ __launch_bounds__(64) void ctc_loss_kernel(const float* __restrict__ logits, int sn, int st, const int* __restrict__ targets,
+                                                      const int* __restrict__ tgt_off, const int* __restrict__ tgt_len,
+                                                      const float* __restrict__ weight, int T, int C, int blank, float scale,
+                                                      float* __restrict__ nll_out, float* __restrict__ dlogits, int accumulate) {
+  __shared__ float lp[32][64];      // log-softmax [t][c]
+  __shared__ float al[32][64];      // alpha [t][s]
+  __shared__ float ab[64];          // alpha_t(s) + beta_t(s) of the current step
+  __shared__ int lab[64];           // l'_s
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int L = tgt_len[n], S = 2 * L + 1, off = tgt_off[n];
+  const float* x = logits + (size_t)n * sn;
+  for (int t = 0; t < T; ++t) {
+    const float v = lane < C ? x[(size_t)t * st + lane] : -INFINITY;
+    float m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float e = lane < C ? expf(v - m) : 0.f;
+    const float lse = m + logf(wave_sum(e));
+    lp[t][lane] = v - lse;
+  }
+  const int ls = lane < S ? ((lane & 1) ? targets[off + (lane >> 1)] : blank) : blank;
+  lab[lane] = lane < S ? ls : -1;
+  __builtin_amdgcn_wave_barrier();
+  const int l_m2 = __shfl_up(ls, 2), l_p2 = __shfl_down(ls, 2);
+  // (ATen's rule, LossCTC.cpp: the skip s - 2 -> s exists iff l'_{s-2} != l'_s -- by VALUE, with no test for the blank: between two
+  //  blank positions the labels are equal anyway, and a LABEL that happens to carry the blank's index -- the collate's "-" -> 0 -- is
+  //  skipped over like any other label)
+  const bool skip_in = lane >= 2 && lane < S && ls != l_m2;             // alpha: from s - 2
+  const bool skip_out = lane + 2 < S && l_p2 != ls;                      // beta: to s + 2
+  // ---- forward variables ----
+  float a = -INFINITY;
+  if (lane == 0) a = lp[0][blank];
+  if (lane == 1 && S > 1) a = lp[0][ls];
+  al[0][lane] = a;
+  for (int t = 1; t < T; ++t) {
+    float a1 = __shfl_up(a, 1), a2 = __shfl_up(a, 2);
+    if (lane < 1) a1 = -INFINITY;
+    if (!skip_in) a2 = -INFINITY;
+    a = lane < S ? lp[t][ls] + ctc_lse3(a, a1, a2) : -INFINITY;
+    al[t][lane] = a;
+  }
+  const float aS1 = __shfl(a, S - 1), aS2 = S > 1 ? __shfl(a, S - 2) : -INFINITY;
+  const float nll = -ctc_lse2(aS1, aS2);
+  if (lane == 0) nll_out[n] = nll;
+  if (!dlogits) return;
+  // ---- backward variables + gradient ----
+  const float g = scale * (weight ? weight[n] : 1.f);
+  float b = -INFINITY;
+  if (lane == S - 1 || (S > 1 && lane == S - 2)) b = lp[T - 1][ls];
+  for (int t = T - 1; t >= 0; --t) {
+    ab[lane] = lane < S ? al[t][lane] + b : -INFINITY;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < C) {
+      float m = -INFINITY;
+      for (int s2 = 0; s2 < S; ++s2)
+        if (lab[s2] == lane) m = fmaxf(m, ab[s2]);
+      float occ = 0.f;
+      if (m != -INFINITY) {
+        float sum = 0.f;
+        for (int s2 = 0; s2 < S; ++s2)
+          if (lab[s2] == lane) sum += expf(ab[s2] - m);
+        occ = expf(m + logf(sum) + nll - lp[t][lane]);
+      }
+      const float gr = g * (expf(lp[t][lane]) - occ);
+      float* d = dlogits + (size_t)n * sn + (size_t)t * st + lane;
+      *d = accumulate ? *d + gr : gr;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (t > 0) {
+      float b1 = __shfl_down(b, 1), b2 = __shfl_down(b, 2);
+      if (lane + 1 >= S) b1 = -INFINITY;
+      if (!skip_out) b2 = -INFINITY;
+      b = lane < S ? lp[t - 1][ls] + ctc_lse3(b, b1, b2) : -INFINITY;
+    }
+  }
+}
+
+/* nll[n] = CTC negative log-likelihood of sample n (blank index `blank`, targets concatenated: sample n's labels are
+ * targets[tgt_off[n] .. + tgt_len[n])), T <= 32 time steps, C <= 64 classes, at most 31 labels per sample; dlogits (optional, same
+ * addressing as logits: n * sn + t * st + c) (+)= scale * weight[n] * d nll[n] / d logits.  torch.nn.CTCLoss(blank, reduction='none') on
+ * log_softmax(logits), interfaces/super_resolution.py:40, :355-366. */
+extern "C" int tpgsr_ctc_loss(const float* logits, int sn, int st, const int* targets, const int* tgt_off, const int* tgt_len, const float* weight,
+                              int N, int T, int C, int blank, float scale, float* nll, float* dlogits, int accumulate, int max_len, void* stream) {
+  TPGSR_CHECK_ARG(logits && targets && tgt_off && tgt_len && nll && N > 0 && T > 0 && T <= 32 && C > 0 && C <= 64 && blank >= 0 && blank < C &&
+                  max_len >= 0 && max_len <= 31, "tpgsr_ctc_loss: needs T <= 32, C <= 64, at most 31 labels per sample (got T %d, C %d, max_len %d)", T, C, max_len);
+  hipLaunchKernelGGL(ctc_loss_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, logits, sn, st, targets, tgt_off, tgt_len, weight, T, C, blank,
+                     scale, nll, dlogits, accumulate);
+  TPGSR_LAUNCH_CHECK("tpgsr_ctc_loss");
+}

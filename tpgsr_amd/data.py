@@ -91,15 +91,46 @@ class ResizeNormalize:
 
 class AlignCollate:
     """`alignCollate_real*` (dataset/dataset.py:1226-1323) reduced to what the training loop consumes: a list of
-    (HR image, LR image, label string) -> (images_HR (N, C, imgH, imgW), images_lr (N, C, imgH/ds, imgW/ds), label_strs)."""
+    (HR image, LR image, label string) -> (images_HR (N, C, imgH, imgW), images_lr (N, C, imgH/ds, imgW/ds), label_strs);
+    with `labels=True` (`alignCollate_realWTLAMask`, what `--use_label` trains on) also label_vecs (N, 37, 1, L) one-hot,
+    weighted_mask (all label indices concatenated) and weighted_tics (N) -- the three tensors TPGSRTrainStep.step(labels=) takes."""
 
-    def __init__(self, imgH=32, imgW=128, down_sample_scale=2, mask=True, device="cuda"):
+    D2A = "-0123456789abcdefghijklmnopqrstuvwxyz"      # dataset/dataset.py:1108-1116: index 0 is the CTC blank
+
+    def __init__(self, imgH=32, imgW=128, down_sample_scale=2, mask=True, device="cuda", labels=False):
         self.hr = ResizeNormalize((imgW, imgH), mask, device)
         self.lr = ResizeNormalize((imgW // down_sample_scale, imgH // down_sample_scale), mask, device)
+        self.labels = bool(labels)
+        self.a2d = {ch: i for i, ch in enumerate(self.D2A)}
+
+    def encode(self, label_strs):
+        """dataset/dataset.py:1255-1323: lower-case, words of 15 characters and more cut to 15, characters outside the alphabet dropped;
+        a word without any label gets one blank (index 0) and weight 0; max_len = the longest word (not label list)"""
+        alsize = len(self.D2A)
+        lists, max_len = [], 0
+        for word in label_strs:
+            word = word.lower()
+            if len(word) >= 15:
+                word = word[:15]
+            lists.append([self.a2d[ch] for ch in word if ch in self.a2d])
+            max_len = max(max_len, len(word))
+        label_vecs = torch.zeros(len(lists), max(max_len, 1), alsize)
+        mask, tics = [], []
+        for i, ll in enumerate(lists):
+            if ll:
+                label_vecs[i, torch.arange(len(ll)), torch.tensor(ll)] = 1.0
+                mask.extend(ll)
+                tics.append(1)
+            else:
+                label_vecs[i, 0, 0] = 1.0
+                mask.append(0)
+                tics.append(0)
+        return label_vecs.unsqueeze(1).permute(0, 3, 1, 2).contiguous(), torch.tensor(mask, dtype=torch.long), torch.tensor(tics)
 
     def __call__(self, batch):
         images_hr, images_lr, label_strs = zip(*batch)
-        return self.hr(images_hr), self.lr(images_lr), list(label_strs)
+        out = (self.hr(images_hr), self.lr(images_lr), list(label_strs))
+        return out + self.encode(label_strs) if self.labels else out
 
 
 class LmdbDatasetReal:

@@ -198,9 +198,16 @@ class TPGSRTrainStep:
 
     def __init__(self, sr_models, students, teacher, stu_iter=1, sr_share=True, tpg_share=False, gradient=True,
                  loss_weight=(1.0, 1e-4), lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, process_group=None, world_size=1,
-                 force_collectives=False, precision: Optional[str] = None, ssim_loss: bool = False):
+                 force_collectives=False, precision: Optional[str] = None, ssim_loss: bool = False, use_label: bool = False,
+                 use_distill: bool = True):
         # `--ssim_loss` (interfaces/super_resolution.py:388-391): every stage adds (1 - ssim(cascade_images, images_hr).mean()) * 10 to its image loss
         self.ssim_loss = bool(ssim_loss)
+        # `--use_label` (:347-366): every stage adds mean(CTC(log_softmax(student logits), labels) * weighted_tics) -- step(..., labels=) then
+        # takes what the reference's collate hands the loop: (label_vecs (N, 37, 1, L) one-hot, weighted_mask (sum L_n) concatenated indices,
+        # weighted_tics (N)).  `--use_distill` (:370-373, the launch scripts' default): the SemanticLoss term against the teacher's prior.
+        self.use_label, self.use_distill = bool(use_label), bool(use_distill)
+        if not (self.use_label or self.use_distill):
+            raise ValueError("TPGSRTrainStep: the cascade branch trains the text-prior generator through --use_distill and / or --use_label")
         # arithmetic policy of the step's GEMMs (kernels.py): `precision`, else an explicit TPGSR_CONV_PREC / set_conv_prec, else "x2" --
         # the benchmarked policy, gated at full size against the oracle on both north_star gates (tests/test_policy_x2*_gpu.py)
         self.precision = K.train_step_policy(precision)
@@ -256,6 +263,8 @@ class TPGSRTrainStep:
                       prior=[torch.empty(N, 37, 1, 26, device=dev) for _ in range(S)],
                       dsr=[torch.empty(N, C, 2 * H, 2 * W, device=dev) for _ in range(S)],
                       dcas=torch.empty(N, C, 2 * H, 2 * W, device=dev), dlogits=torch.empty(N, 26, 37, device=dev))
+            if self.use_label:
+                st.update(ctc_nll=[torch.empty(N, device=dev) for _ in range(S)])
             if self.ssim_loss:
                 from ..utils.ssim_psnr import create_window
                 cc = min(C, 3)
@@ -264,9 +273,27 @@ class TPGSRTrainStep:
             self._static = st
         return self._static
 
-    def _phase_a(self, lr_img, hr_img):
+    def _labels(self, labels, N, dev):
+        """(label_vecs, weighted_mask, weighted_tics) of the reference's collate (dataset/dataset.py:1239-1323) -> the CTC kernel's operands:
+        text_len as interfaces/super_resolution.py:349-352 derives it from the one-hot tensor, target offsets = its prefix sums"""
+        label_vecs, weighted_mask, weighted_tics = labels
+        text_sum = label_vecs.sum(1).squeeze(1)                                  # [N, L]
+        text_len = (text_sum > 0).float().sum(1).reshape(-1).to(torch.int32)
+        if text_len.numel() != N or weighted_tics.numel() != N:
+            raise ValueError("labels: label_vecs / weighted_tics must have one entry per image")
+        lens = text_len.cpu()
+        if int(lens.sum()) != weighted_mask.numel():
+            raise ValueError(f"labels: weighted_mask has {weighted_mask.numel()} indices, the label lengths add up to {int(lens.sum())}")
+        off = torch.zeros(N, dtype=torch.int32)
+        off[1:] = torch.cumsum(lens, 0)[:-1]
+        return (weighted_mask.to(torch.int32).to(dev).contiguous(), off.to(dev), text_len.to(dev).contiguous(),
+                weighted_tics.float().to(dev).contiguous(), int(lens.max()))
+
+    def _phase_a(self, lr_img, hr_img, labels=None):
         st = self._buffers(lr_img)
         N, C, H, W = lr_img.shape
+        ctc = self._labels(labels, N, lr_img.device) if self.use_label else None
+        wsem = 100.0 if self.use_distill else 0.0
         H2, W2 = 2 * H, 2 * W
         hr = hr_img.contiguous()
         lr_img = lr_img.contiguous().float()
@@ -303,6 +330,7 @@ class TPGSRTrainStep:
             # one) and queues the SR prologue behind that packing
             logits = stu._engine().forward(st["gray"][i], True, slot=i, late_stream=side, after_late=sr_prologue if pre_side else None)
             self._mark(f"student{i} fwd")
+            logits_keep.append(logits)
             if i == 0:
                 K.order(main, aux)              # the teacher's distribution q is needed from here on
                 self._mark("wait teacher")
@@ -317,7 +345,11 @@ class TPGSRTrainStep:
             # _join_side() orders the caller's stream after it before the step returns
             K.order(aux, main)
             with K.stream_ctx(aux):
-                K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, 100.0, st["l_sem"][i])
+                K.semantic_loss_finalize(st["part_sem"][i], _NBLK, N * 26 * 37, wsem, st["l_sem"][i])
+                if ctc is not None:      # + mean(ctc * weighted_tics): the per-sample values by the kernel (no gradient here), the mean by ATen
+                    K.ctc_loss(logits, 26 * 37, 37, ctc[0], ctc[1], ctc[2], None, N, 26, 37, 0, 0.0, st["ctc_nll"][i], None, False, ctc[4])
+                    if not K.DRYRUN:
+                        st["l_sem"][i].add_((st["ctc_nll"][i] * ctc[3]).mean())
                 K.image_loss_fwd(sr, hr, N, C, H2, W2, self.gradient, st["part_img"][i], _NBLK_IMG)
                 n_gp = N * min(C, 3) * H2 * W2 if self.gradient else 0
                 K.image_loss_finalize(st["part_img"][i], _NBLK_IMG, sr.numel(), n_gp, self.w0 * 100.0, self.w1 * 100.0, st["l_img"][i])
@@ -351,7 +383,9 @@ class TPGSRTrainStep:
                 # travels over xGMI while the text-prior generators' backward passes below run
                 self._launch_bucket_from_side(self._bucket("sr", srm), lr_img.device, sr_net=True)
             self._mark(f"SR{i} bwd")
-            K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, 100.0, st["dlogits"], _NBLK)
+            K.softmax_prior_bwd(st["p"][i], st["q"], dprior, None, N, 26, 37, N // 4, wsem, st["dlogits"], _NBLK)
+            if ctc is not None:          # d/d logits of mean(ctc * weighted_tics), added to the softmax's gradient
+                K.ctc_loss(logits_keep[i], 26 * 37, 37, ctc[0], ctc[1], ctc[2], ctc[3], N, 26, 37, 0, 1.0 / N, st["ctc_nll"][i], st["dlogits"], True, ctc[4])
             if getattr(self, "_debug", False):
                 self._dbg.setdefault("dprior", {})[i] = dprior.clone()
                 self._dbg.setdefault("dlogits", {})[i] = st["dlogits"].clone()
@@ -467,14 +501,16 @@ class TPGSRTrainStep:
             for m in self.pool.modules + [self.teacher]:      # the arenas changed behind the parameters' version counters
                 m._engine()._kernel_writes += 1
 
-    def step(self, lr_img, hr_img):
+    def step(self, lr_img, hr_img, labels=None):
         for m in self.sr + self.stu:
             if not m.training:
                 raise RuntimeError("TPGSRTrainStep.step needs the SR nets and students in train() mode")
+        if self.use_label and labels is None:
+            raise ValueError("TPGSRTrainStep(use_label=True).step needs labels=(label_vecs, weighted_mask, weighted_tics)")
         with K.policy(self.precision):
             self.pool.bind(lr_img.device)
             self.teacher._engine().bind(lr_img.device)
-            loss = self._phase_a(lr_img, hr_img)
+            loss = self._phase_a(lr_img, hr_img, labels)
             self._exchange()
             self._phase_b()
         self._mark("optimiser")

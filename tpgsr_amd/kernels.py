@@ -1436,6 +1436,12 @@ def ssim(a, b, window, KS, N, Ctot, H, W, partial, nblk, out):
     _launch("tpgsr_ssim", _p(a), _p(b), _p(window), KS, N, Ctot, H, W, _p(partial), nblk, _p(out))
 
 
+def ctc_loss(logits, sn, st, targets, tgt_off, tgt_len, weight, N, T, C_, blank, scale, nll, dlogits, accumulate, max_len):
+    """per-sample CTC negative log-likelihood (+ its gradient, scaled by scale * weight[n], into dlogits): csrc/crnn.hip, `--use_label`"""
+    _launch("tpgsr_ctc_loss", _p(logits), int(sn), int(st), _p(targets), _p(tgt_off), _p(tgt_len), _p(weight), N, T, C_, int(blank), float(scale),
+            _p(nll), _p(dlogits), int(bool(accumulate)), int(max_len))
+
+
 def ssim_bwd(a, b, window, KS, N, Ctot, H, W, gm, coef, mult, da, accumulate):
     """da[:, :min(Ctot,3)] (+)= mult * coef[0] * d(sum of the SSIM map)/da  (`--ssim_loss`; gm: scratch 3 N min(Ctot,3) H W floats)"""
     _launch("tpgsr_ssim_bwd", _p(a), _p(b), _p(window), KS, N, Ctot, H, W, _p(gm), _p(coef), float(mult), _p(da), int(bool(accumulate)))
