@@ -372,3 +372,28 @@ def test_full_size_properties_bs48():
         outs.append((losses, m._engine().arena.flat.clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0][2] < outs[0][0][0]                                      # and it trains
+
+
+@pytest.mark.parametrize("stn", [False, True])
+def test_three_channel_network_vs_oracle(stn, golden_policy):
+    """mask=False -- in_planes 3, the reference's default (`--mask` is a store_true flag, main.py; model/tsrn.py:24-26) -- forward, loss and
+    every parameter gradient against the oracle (round 5's folded data gradient of block1 / the tail's shift-sum rejected
+    KS * 3 = 27 columns).  Without the STN element-wise; with it (the TPS system's fp32 conditioning) loss and gradient norm."""
+    from tpgsr_amd.interfaces.super_resolution import TSRNTrainStep
+    net, sd = _build(stn=stn, mask=False, seed=23)
+    lr4, hr4 = O.synthetic_batch(3, 6)
+    lr, hr = lr4[:, :3].contiguous(), hr4[:, :3].contiguous()
+    p = O.as_params(sd)
+    y = O.tsrn_forward(p, lr, training=True, stn=stn, explicit_rnn=False)
+    loss_ref = O.image_loss(y, hr).mean() * 100
+    loss_ref.backward()
+    gref = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in p.values() if v.grad is not None)).item()
+    net.train()
+    ts = TSRNTrainStep(net)
+    loss = ts.step(lr.to(DEV), hr.to(DEV))
+    gn = ts.opt.grad_norm(net).item()
+    print(f"mask=False stn={stn} {golden_policy.name}: loss {loss.item():.6f} (oracle {loss_ref.item():.6f}), gradient norm {gn:.4f} (oracle {gref:.4f})")
+    assert abs(loss.item() - loss_ref.item()) < golden_policy.tol(3e-4 if stn else 1e-4) * abs(loss_ref.item())
+    assert abs(gn - gref) < (2e-2 * NOISE if stn else 2e-3) * gref
+    if not stn:
+        assert (ts.last_sr.cpu() - y.detach()).abs().max() < golden_policy.tol(5e-5)
