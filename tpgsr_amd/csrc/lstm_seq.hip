@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
     float* red = red0 + (s & 1) * 4096;
     if (s > 0) {
       const unsigned want = ((ep << 5) | (unsigned)s) << 16;                       // tag of step s - 1's data = (epoch, (s - 1) + 1)
-      const unsigned base = (unsigned)(((s - 1) & 1) * par_bytes + d * dir_bytes) + ((unsigned)(rb * 16 + kh * 8) * 4 * 64 + lane) * 16u;
+      // (rows past the batch are never published and stay zero: their lanes ask for an out-of-range offset -- hardware zeros, no memory
+      //  traffic: a quarter of the 131 KB a workgroup ingests per step at N = 48)
+      const unsigned base = row_live ? (unsigned)(((s - 1) & 1) * par_bytes + d * dir_bytes) + ((unsigned)(rb * 16 + kh * 8) * 4 * 64 + lane) * 16u
+                                     : 0x7ff00000u;
       ls_u32x4 raw[8][4];
       int tries = 0;
       while (true) {
@@ -323,6 +326,10 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
           break;
         }
       }
+      // (round 6, measured: products issued chunk by chunk INSIDE the attempt, behind the compiler's partial vmcnt waits, so that the MFMA
+      //  pipe time hides under the arrival of the 96 KB -- 125.8 us per launch against 120.0: a thrown-away attempt gets longer by its
+      //  products, and how soon the NEXT attempt starts is what the step waits for.  An attempt that re-loads only the chunks it found
+      //  stale: 119.7, no difference -- attempts fail whole, not in part.  tools/lab/lstm_seq_time.py)
       floatx16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -355,8 +362,9 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
     for (int it = 0; it < 2; ++it) {
       const int n = (tid >> 3) + 32 * it;
       unsigned glo = 0, ghi = 0;
+      float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (n < N) {
-        const int item = n * 8 + ul, unit = u0 + ul;
+        const int item = n * 8 + ul;
         float p[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -371,15 +379,11 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
         ls_split3(h, hv);
         glo = (unsigned)hv[0] | ((unsigned)hv[1] << 16);
         ghi = (unsigned)hv[2] | tagw;
-        float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + unit;
-        g[0] = ig;
-        g[Hh] = fg;
-        g[2 * Hh] = gg;
-        g[3 * Hh] = og;
-        Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = c;
-        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = tmo ? __builtin_nanf("") : h;
+        gv[0] = ig; gv[1] = fg; gv[2] = gg; gv[3] = og; gv[4] = c; gv[5] = h;
       }
-      if (s + 1 < T) {      // publish: the even unit of a pair stores both granules (16 bytes, write-through), nothing waits for it
+      if (s + 1 < T) {      // publish FIRST: the even unit of a pair stores both granules (16 bytes, write-through), nothing waits for it --
+        // the 31 other workgroups of the direction wait for exactly this store; the step's six bookkeeping stores (activated gates, cell
+        // state, output) queue up behind it instead of in front of it (round 6)
         const unsigned nlo = __shfl_xor(glo, 1), nhi = __shfl_xor(ghi, 1);
         if (n < N && !(ul & 1)) {
           ls_u32x4 v;
@@ -388,6 +392,16 @@ __global__ __launch_bounds__(256) void lstm_seq_fwdg_kernel(float* __restrict__ 
                                ((((unsigned)((n >> 5) * 16 + (u >> 1)) * 4 + (ul >> 1)) * 64) + (u & 1) * 32 + (n & 31)) * 16u;
           __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, LS_SC1);
         }
+      }
+      if (n < N) {
+        const int unit = u0 + ul;
+        float* g = G + (((size_t)n * T + t) * 2 + d) * G4 + unit;
+        g[0] = gv[0];
+        g[Hh] = gv[1];
+        g[2 * Hh] = gv[2];
+        g[3 * Hh] = gv[3];
+        Cst[(((size_t)n * T + t) * 2 + d) * Hh + unit] = gv[4];
+        out[((size_t)n * T + t) * 2 * Hh + d * Hh + unit] = tmo ? __builtin_nanf("") : gv[5];
       }
     }
   }
