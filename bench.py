@@ -107,10 +107,13 @@ def build_step(cfg_key, dev, world=1, pg=None, force_collectives=False, tpg="crn
     return ts, [sr] + students + [teacher]
 
 
-def module_api_bench(cfg_key, dev, images_lr, images_hr, steps=20, warmup=6):
+def module_api_bench(cfg_key, dev, images_lr, images_hr, steps=20, warmup=6, fused_optimizer=False):
     """One C3 step as a user of the REFERENCE writes it (interfaces/super_resolution.py:295-424, verbatim but for the imports): the drop-in
     modules driven by torch autograd, `clip_grad_norm_` and `torch.optim.Adam` -- tests/test_crnn_gpu.py::test_dropin_module_api_c3_step is
-    the same loop against the reference's recorded numbers.  Same networks / weights recipe / batch as the fused step of this line."""
+    the same loop against the reference's recorded numbers.  Same networks / weights recipe / batch as the fused step of this line.
+    fused_optimizer: the two-line change INTEGRATION.md offers -- `tpgsr_amd.optim.FusedAdam([model, stu_model], ..., clip_modules=[model])`
+    in place of torch.optim.Adam + clip_grad_norm_ (three launches per module over the flat arena instead of ~10 foreach kernels over
+    361 tensors and their Python bookkeeping); everything else stays the reference's loop."""
     from tpgsr_amd.interfaces.super_resolution import parse_crnn_data
     from tpgsr_amd.loss.image_loss import ImageLoss
     from tpgsr_amd.loss.semantic_loss import SemanticLoss
@@ -123,7 +126,11 @@ def module_api_bench(cfg_key, dev, images_lr, images_hr, steps=20, warmup=6):
     for q in aster.parameters():
         q.requires_grad = False
     image_crit, sem_loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4]), SemanticLoss()
-    optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu_model.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    if fused_optimizer:
+        from tpgsr_amd.optim import FusedAdam
+        optimizer_G = FusedAdam([model, stu_model], lr=1e-3, betas=(0.5, 0.999), clip_modules=[model], max_norm=0.25)
+    else:
+        optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu_model.parameters()), lr=1e-3, betas=(0.5, 0.999))
     drop_vec = torch.ones(images_lr.shape[0]).float()
     drop_vec[:int(images_lr.shape[0] // 4)] = 0.
     drop_vec = drop_vec.to(dev).view(-1, 1, 1, 1)
@@ -140,7 +147,8 @@ def module_api_bench(cfg_key, dev, images_lr, images_hr, steps=20, warmup=6):
         loss_im = loss_img + loss_recog_distill
         optimizer_G.zero_grad()
         loss_im.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+        if not fused_optimizer:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
         optimizer_G.step()
         return loss_im
 
@@ -676,6 +684,8 @@ def main():
             try:
                 out["module_api"] = module_api_bench(args.config, dev, lr_img, hr_img, steps=20, warmup=6)
                 out["module_api"]["vs_fused_step"] = round(out["module_api"]["ms_per_step"] / ms, 3)
+                fo = module_api_bench(args.config, dev, lr_img, hr_img, steps=20, warmup=6, fused_optimizer=True)
+                out["module_api"]["with_tpgsr_amd_FusedAdam"] = {k: fo[k] for k in ("ms_per_step", "value", "unit", "host_submission_ms_per_step", "final_loss")}
             except Exception as e:      # reported, never hidden
                 out["module_api"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:

@@ -372,9 +372,12 @@ def test_cascade_two_stages_vs_oracle():
         ofs += len(keys)
 
 
-def test_dropin_module_api_c3_step(golden_dir):
+@pytest.mark.parametrize("optimizer", ["torch.optim.Adam", "tpgsr_amd.optim.FusedAdam"])
+def test_dropin_module_api_c3_step(golden_dir, optimizer):
     """The reference's own loop body (interfaces/super_resolution.py:295-424) written against the drop-in modules:
-    torch autograd + torch.optim.Adam + clip_grad_norm_ drive the HIP plans through the nn.Module API."""
+    torch autograd + torch.optim.Adam + clip_grad_norm_ drive the HIP plans through the nn.Module API.  Second case: the two-line change
+    INTEGRATION.md offers for the loop's host time -- FusedAdam over the modules' flat arenas (clip included) in place of the two torch calls."""
+    fused = optimizer.endswith("FusedAdam")
     from tpgsr_amd.interfaces.super_resolution import parse_crnn_data
     from tpgsr_amd.loss.image_loss import ImageLoss
     from tpgsr_amd.loss.semantic_loss import SemanticLoss
@@ -384,7 +387,11 @@ def test_dropin_module_api_c3_step(golden_dir):
     for q in teacher.parameters():
         q.requires_grad = False
     image_crit, sem_loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4]), SemanticLoss()
-    optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    if fused:
+        from tpgsr_amd.optim import FusedAdam
+        optimizer_G = FusedAdam([model, stu], lr=1e-3, betas=(0.5, 0.999), clip_modules=[model], max_norm=0.25)
+    else:
+        optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu.parameters()), lr=1e-3, betas=(0.5, 0.999))
     images_lr, images_hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
     losses = []
     for step in range(2):
@@ -401,8 +408,12 @@ def test_dropin_module_api_c3_step(golden_dir):
         loss_im = loss_img + loss_recog_distill
         optimizer_G.zero_grad()
         loss_im.backward()
-        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
-        optimizer_G.step()
+        if fused:
+            optimizer_G.step()
+            gn = optimizer_G.grad_norm(model)
+        else:
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+            optimizer_G.step()
         losses.append(loss_im.item())
         if step == 0:
             assert abs(loss_im.item() - t["loss"][0]) < 3e-4 * t["loss"][0]

@@ -108,3 +108,51 @@ def test_no_scan_instruction_takes_its_low_half_from_the_odd_register_of_an_lds_
             assert len(packed) > 100, (src, len(packed))             # the scans ARE packed multiply-adds
             bad = [ln.strip() for ln in packed if re.search(r"op_sel:\[(0|1),1", ln) or re.search(r"op_sel:\[1", ln)]
             assert not bad, f"{src}: {len(bad)} packed instructions read a high register for their low half, e.g. {bad[:3]}"
+
+
+def test_cached_arena_check_notices_what_the_full_walk_noticed():
+    """ParamArena.ensure() runs in front of every forward pass; since round 6 its common answer ("nothing moved") comes from a cached list
+    (one identity test + one data_ptr() per parameter) instead of a walk over the module tree.  Everything the walk caught must still
+    trigger a rebuild: a parameter's storage replaced (`p.data = ..`), the module moved / re-typed (`.double()` and back), a Parameter
+    object replaced; and `attach_grads` re-attaches gradient views after `zero_grad(set_to_none=True)`."""
+    import torch
+    from tpgsr_amd.engine import ParamArena
+    from tpgsr_amd.model.nn_params import BatchNormParams, Conv2dParams
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = Conv2dParams(4, 8, 3, padding=1)
+            self.b = BatchNormParams(8)
+            self.c = torch.nn.Sequential(Conv2dParams(8, 8, 1), BatchNormParams(8))
+
+    cpu = torch.device("cpu")
+    net = Net()
+    want = {n: p.detach().clone() for n, p in net.named_parameters()}
+    ar = ParamArena(net)
+    assert ar.ensure(cpu) is True
+    assert ar.ensure(cpu) is False and ar.ensure(cpu) is False            # cached answer
+    base = ar.flat.data_ptr()
+    assert all(p.data_ptr() == base + 4 * ar.offsets[n] for n, p in net.named_parameters())
+    # (1) one parameter's storage replaced behind the arena's back
+    net.c[0].weight.data = net.c[0].weight.data.clone() * 2
+    want["c.0.weight"] *= 2
+    assert ar.ensure(cpu) is True and ar.ensure(cpu) is False
+    # (2) the module re-typed and back (every parameter gets new storage)
+    net.double().float()
+    assert ar.ensure(cpu) is True and ar.ensure(cpu) is False
+    # (3) a Parameter object replaced
+    net.a.bias = torch.nn.Parameter(torch.full((8,), 0.5))
+    want["a.bias"] = torch.full((8,), 0.5)
+    assert ar.ensure(cpu) is True and ar.ensure(cpu) is False
+    base = ar.flat.data_ptr()
+    for n, p in net.named_parameters():
+        assert p.data_ptr() == base + 4 * ar.offsets[n] and torch.equal(p.detach(), want[n]), n
+        assert p.grad is not None and p.grad.data_ptr() == ar.grad.data_ptr() + 4 * ar.offsets[n]
+    # gradient views: dropped by zero_grad(set_to_none=True), re-attached (and the arena zeroed) by attach_grads
+    ar.grad.fill_(3.0)
+    assert ar.attach_grads() is False and float(ar.grad.sum()) == 3.0 * ar.grad.numel()
+    torch.optim.SGD(net.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in net.parameters())
+    assert ar.attach_grads() is True and float(ar.grad.abs().sum()) == 0.0
+    assert all(p.grad.data_ptr() == ar.grad.data_ptr() + 4 * ar.offsets[n] for n, p in net.named_parameters())
