@@ -76,6 +76,29 @@ def main():
     for _ in range(8):
         loop_body(False)
     torch.cuda.synchronize()
+    # inside the module calls: the plan executor (tpgsr_plan_run3: every launch + stream edge of a recorded plan, in C++) by plan, and the
+    # engines' backward entry points (called from autograd's thread)
+    plan_t, plan_n = {}, {}
+    orig_run = K.Plan.run
+
+    def timed_run(self):
+        t0 = time.perf_counter()
+        orig_run(self)
+        key = f"{self.name} ({len(self.ops)} ops)"
+        plan_t[key] = plan_t.get(key, 0.0) + time.perf_counter() - t0
+        plan_n[key] = plan_n.get(key, 0) + 1
+    K.Plan.run = timed_run
+    bwd_t = {}
+    for tag, mod in (("TSRN_TL", model), ("CRNN student", stu_model)):
+        eng = mod._engine()
+        ob = eng.backward
+
+        def wrapped(*a, _ob=ob, _tag=tag, **k):
+            t0 = time.perf_counter()
+            r = _ob(*a, **k)
+            bwd_t[_tag] = bwd_t.get(_tag, 0.0) + time.perf_counter() - t0
+            return r
+        eng.backward = wrapped
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = loop_body(True)
@@ -87,6 +110,15 @@ def main():
     for name in order:
         print(f"  {name:44s} {1e3 * acc[name] / steps:7.3f} ms")
     print(f"  {'(sum of the stamps)':44s} {1e3 * sum(acc.values()) / steps:7.3f} ms")
+    print("inside loss.backward(): the engines' backward entry points (autograd's thread)")
+    for tag, v in bwd_t.items():
+        print(f"  {tag + ' engine.backward':44s} {1e3 * v / steps:7.3f} ms")
+    print("plan executor (C++), by plan:")
+    tot = 0.0
+    for key in sorted(plan_t, key=lambda k: -plan_t[k]):
+        tot += plan_t[key]
+        print(f"  {key:44s} {1e3 * plan_t[key] / steps:7.3f} ms   ({plan_n[key] / steps:.1f} runs per step)")
+    print(f"  {'(all plans)':44s} {1e3 * tot / steps:7.3f} ms")
 
 
 if __name__ == "__main__":
