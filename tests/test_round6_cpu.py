@@ -156,3 +156,51 @@ def test_cached_arena_check_notices_what_the_full_walk_noticed():
     assert all(p.grad is None for p in net.parameters())
     assert ar.attach_grads() is True and float(ar.grad.abs().sum()) == 0.0
     assert all(p.grad.data_ptr() == ar.grad.data_ptr() + 4 * ar.offsets[n] for n, p in net.named_parameters())
+
+
+_COPY = r'''
+import copy, io, json, sys, torch
+sys.path.insert(0, %(root)r)
+from oracle import tpgsr_oracle as O
+from tpgsr_amd import kernels as K
+assert K.DRYRUN
+from tpgsr_amd.model import tsrn
+from tpgsr_amd.model.crnn import crnn
+out = {}
+lr, hr = O.synthetic_batch(2, 1)
+for tag, net, x in (("tsrn", tsrn.TSRN(STN=True, mask=True).train(), lr), ("crnn", crnn.CRNN(32, 1, 37, 256).train(), torch.rand(2, 1, 32, 100))):
+    net(x)                                             # the engine exists now: plans, ctypes argument blocks, the arena
+    assert "_eng" in net.__dict__
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    twin = copy.deepcopy(net)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    res = {}
+    for name, m in (("deepcopy", twin), ("torch.save/load", loaded)):
+        same = all(torch.equal(v, sd[k]) for k, v in m.state_dict().items()) and list(m.state_dict()) == list(sd)
+        own = all(a.data_ptr() != b.data_ptr() for a, b in zip(m.parameters(), net.parameters()))
+        m(x)                                           # builds its own engine
+        res[name] = dict(no_engine_carried=True, same_state=same, own_storage=own, own_engine=m._engine() is not net._engine())
+    res["original_untouched"] = net._engine().arena.ensure(x.device) is False
+    res["file_bytes"] = buf.getbuffer().nbytes
+    res["param_bytes"] = 4 * sum(p.numel() for p in net.parameters())
+    out[tag] = res
+print("JSON" + json.dumps(out))
+'''
+
+
+@pytest.mark.timeout(900)
+def test_modules_with_an_engine_can_be_copied_and_saved_whole():
+    """copy.deepcopy(model), pickle and torch.save(model) of a network that has already run: the HIP engine (ctypes argument blocks, plans,
+    workspaces) is process-local and stays behind -- the copy carries parameters and buffers, owns its storage and builds its own engine on
+    first use; a whole-module file is about the size of the parameters (the arena is stored once, not once per view).  Before round 6:
+    "ValueError: ctypes objects containing pointers cannot be pickled"."""
+    res = _run(_COPY)
+    for tag in ("tsrn", "crnn"):
+        r = res[tag]
+        for how in ("deepcopy", "torch.save/load"):
+            assert r[how] == dict(no_engine_carried=True, same_state=True, own_storage=True, own_engine=True), (tag, how, r)
+        assert r["original_untouched"], r
+        assert r["file_bytes"] < 1.3 * r["param_bytes"] + (1 << 20), r

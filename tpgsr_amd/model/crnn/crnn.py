@@ -10,7 +10,7 @@ import weakref
 import torch
 from torch import nn
 
-from ..nn_params import BatchNormParams, Conv2dParams, LinearParams, LSTMParams, _NoForward
+from ..nn_params import BatchNormParams, Conv2dParams, EngineHolder, LinearParams, LSTMParams, _NoForward
 
 
 class BidirectionalLSTM(_NoForward):
@@ -51,7 +51,7 @@ class _CRNNFunction(torch.autograd.Function):
         return dgray, None, None
 
 
-class CRNN(nn.Module):
+class CRNN(EngineHolder, nn.Module):
     def __init__(self, imgH, nc, nclass, nh, n_rnn=2, leakyRelu=False):
         super().__init__()
         assert imgH % 16 == 0, "imgH has to be a multiple of 16"

@@ -5,11 +5,11 @@ Same constructor (an `opt` object with the reference's attribute names) and stat
 from torch import nn
 
 from ... import functional as Fh
-from ..nn_params import LinearParams, _NoForward
+from ..nn_params import EngineHolder, LinearParams, _NoForward
 from .modules.feature_extraction import ResNet_FeatureExtractor
 
 
-class Model(nn.Module):
+class Model(EngineHolder, nn.Module):
     def __init__(self, opt):
         super().__init__()
         g = (lambda k, d=None: opt.get(k, d)) if isinstance(opt, dict) else (lambda k, d=None: getattr(opt, k, d))

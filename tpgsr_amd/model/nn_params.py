@@ -17,6 +17,30 @@ def _uniform(t, bound):
         return t.uniform_(-bound, bound)
 
 
+class EngineHolder:
+    """Mixin of the modules that own a lazily built HIP engine (`_eng`: recorded plans, ctypes argument blocks, device workspaces, the flat
+    parameter arena).  The engine is process-local state: `copy.deepcopy(module)`, `pickle` and `torch.save(module)` carry the parameters
+    and buffers only, and the copy builds its own engine (and arena) on first use.  (Before round 6 all three raised "ctypes objects
+    containing pointers cannot be pickled" once the module had run.)"""
+
+    def __getstate__(self):
+        eng = self.__dict__.get("_eng")
+        if eng is not None and hasattr(eng, "flush_counters"):
+            eng.flush_counters()                     # num_batches_tracked is kept lazily by the engine
+        d = self.__dict__.copy()
+        d.pop("_eng", None)
+        d.pop("_grad_sync", None)                    # (tpgsr_amd.distributed.DataParallel's hook: a closure over a process group)
+        return d
+
+    def _replicate_for_data_parallel(self):
+        # torch.nn.DataParallel over several devices (the reference's interfaces/base.py:394-400 with --ngpu > 1) copies a module's
+        # __dict__ per device and threads: the replicas would share ONE engine bound to one device.  Say so instead of computing garbage.
+        raise RuntimeError(f"{type(self).__name__}: torch.nn.DataParallel over several GPUs is not supported by tpgsr_amd (one engine = one "
+                           "device).  Run one process per GPU (python -m torch.distributed.run ...) and wrap the module in "
+                           "tpgsr_amd.distributed.DataParallel, or use TPGSRTrainStep(..., world_size=W): INTEGRATION.md section 4.  "
+                           "(torch.nn.DataParallel with ONE device id calls the module directly and works.)")
+
+
 class _NoForward(nn.Module):
     def forward(self, *a, **k):
         raise RuntimeError(f"{type(self).__name__} only holds parameters; it is executed by the fused HIP plan of its "

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fh
-from .nn_params import BatchNormParams, Conv2dParams, ConvTranspose2dParams, GRUParams, PReLUParams, _NoForward
+from .nn_params import BatchNormParams, Conv2dParams, ConvTranspose2dParams, EngineHolder, GRUParams, PReLUParams, _NoForward
 from .stn_head import STNHead
 from .tps_spatial_transformer import TPSSpatialTransformer
 
@@ -169,7 +169,7 @@ class _TSRNFunction(torch.autograd.Function):
         return None, None, None, (dprior if ctx.has_prior else None)
 
 
-class _TSRNBase(nn.Module):
+class _TSRNBase(EngineHolder, nn.Module):
     def _engine(self):
         eng = self.__dict__.get("_eng")
         if eng is None:
