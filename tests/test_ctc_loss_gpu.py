@@ -82,3 +82,49 @@ def test_collate_labels_product_equals_oracle():
     ac.a2d = {ch: i for i, ch in enumerate(AlignCollate.D2A)}
     for a, b in zip(O.collate_labels(words), ac.encode(words)):
         assert torch.equal(a.float(), b.float())
+
+
+def test_cascade_with_ssim_loss_and_labels_vs_oracle():
+    """Both optional loss branches at once in a TWO-stage cascade (stu_iter 2, sr_share, two students, no STN, bs 4): the CTC term of
+    every stage's student and the SSIM term of every stage's SR image, loss value and raw gradients against oracle autograd
+    (oracle/tpgsr_oracle.py: tpgsr_train_step(ssim_loss=True, use_label=True), pinned at stu_iter 1 by the two reference fixtures).
+    Tolerances as tests/test_crnn_gpu.py::test_cascade_two_stages_vs_oracle (the students' gradients are percent-level in fp32)."""
+    from oracle import tpgsr_oracle as O
+    from test_crnn_gpu import _c3_models
+    from tpgsr_amd.interfaces.super_resolution import TPGSRTrainStep
+    srs, stus, teacher, sds, sd_s, sd_t = _c3_models(stn=False, n_sr=1, n_stu=2)
+    lr, hr = O.synthetic_batch(4, 78)
+    labels = O.collate_labels(["Hotel", "a1", "", "OPEN-24h"])
+    ps = O.as_params(sds[0]); pt = O.as_params(sd_t, False); pu = [O.as_params(x) for x in sd_s]
+    opt = O.AdamState([ps[k] for k in O.trainable_keys(ps)] + [q[k] for q in pu for k in O.trainable_keys(q)])
+    ref = O.tpgsr_train_step([ps], pu, pt, opt, lr, hr, stu_iter=2, sr_share=True, tpg_share=False, stn=False, ssim_loss=True,
+                             use_label=True, labels=labels)
+    ts = TPGSRTrainStep(srs, stus, teacher, stu_iter=2, sr_share=True, tpg_share=False, ssim_loss=True, use_label=True)
+    ts.pool.bind(torch.device(DEV, 0))
+    teacher._engine().bind(torch.device(DEV, 0))
+    loss = ts._phase_a(lr.to(DEV), hr.to(DEV), labels)            # forward + backward only (no optimiser): raw gradients
+    torch.cuda.synchronize()
+    print("cascade + ssim + ctc: loss", loss.item(), ref["loss"].item())
+    assert abs(loss.item() - ref["loss"].item()) < 3e-4 * ref["loss"].item()
+    flat_ref = ref["grads"]
+    names_sr = O.trainable_keys(ps)
+    n_sr = len(names_sr)
+    coef = min(1.0, 0.25 / (float(ref["grad_norms"][0]) + 1e-6))   # the oracle clipped the SR group in place
+    P = dict(srs[0].named_parameters())
+    num = den = 0.0
+    for k, gref in zip(names_sr, flat_ref[:n_sr]):
+        d = P[k].grad.cpu() * coef - gref
+        num += d.double().pow(2).sum().item(); den += gref.double().pow(2).sum().item()
+    print("  SR gradients: global rel err", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < 5e-3
+    ofs = n_sr
+    for j, q in enumerate(pu):
+        Ps = dict(stus[j].named_parameters())
+        keys = O.trainable_keys(q)
+        num = den = 0.0
+        for k, gref in zip(keys, flat_ref[ofs:ofs + len(keys)]):
+            d = Ps[k].grad.cpu() - gref
+            num += d.double().pow(2).sum().item(); den += gref.double().pow(2).sum().item()
+        print(f"  student {j}: global rel err {(num / den) ** 0.5:.3e}")
+        assert (num / den) ** 0.5 < 3e-2, (j, (num / den) ** 0.5)
+        ofs += len(keys)
