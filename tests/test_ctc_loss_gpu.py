@@ -128,3 +128,46 @@ def test_cascade_with_ssim_loss_and_labels_vs_oracle():
         print(f"  student {j}: global rel err {(num / den) ** 0.5:.3e}")
         assert (num / den) ** 0.5 < 3e-2, (j, (num / den) ** 0.5)
         ofs += len(keys)
+
+
+def test_module_api_loop_with_use_label(golden_dir):
+    """the reference's loop body with `--use_label` on the drop-in modules (interfaces/super_resolution.py:347-366): torch's OWN
+    `nn.CTCLoss(blank=0, reduction='none')` on the drop-in student's logits, autograd through it into the HIP backward plans --
+    the line keeps working as it is."""
+    from test_crnn_gpu import _c3_models
+    from tpgsr_amd.interfaces.super_resolution import parse_crnn_data
+    from tpgsr_amd.loss.image_loss import ImageLoss
+    from tpgsr_amd.loss.semantic_loss import SemanticLoss
+    t = np.load(os.path.join(golden_dir, "ctc_loss.npz"))
+    srs, stus, teacher, *_ = _c3_models()
+    model, stu = srs[0], stus[0]
+    for q in teacher.parameters():
+        q.requires_grad = False
+    image_crit, sem_loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4]), SemanticLoss()
+    ctc_loss = torch.nn.CTCLoss(blank=0, reduction='none')
+    optimizer_G = torch.optim.Adam(list(model.parameters()) + list(stu.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    images_lr, images_hr = torch.tensor(t["lr"]).to(DEV), torch.tensor(t["hr"]).to(DEV)
+    label_vecs_gt, weighted_mask, weighted_tics = torch.tensor(t["label_vecs"]), torch.tensor(t["weighted_mask"]), torch.tensor(t["weighted_tics"])
+    text_sum = label_vecs_gt.sum(1).squeeze(1)
+    text_len = (text_sum > 0).float().sum(1).reshape(-1)
+    label_vecs_hr = torch.nn.functional.softmax(teacher(parse_crnn_data(images_hr[:, :3, :, :])).detach(), -1)
+    label_vecs_logits = stu(parse_crnn_data(images_lr[:, :3, :, :]))
+    label_vecs = torch.nn.functional.softmax(label_vecs_logits, -1)
+    label_vecs_final = label_vecs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+    predicted_length = torch.ones(label_vecs_logits.shape[1]) * label_vecs_logits.shape[0]
+    fsup_sem_loss = ctc_loss(label_vecs_logits.log_softmax(2), weighted_mask.long().to(DEV), predicted_length.long().to(DEV), text_len.long().to(DEV))
+    loss_recog_distill = (fsup_sem_loss * weighted_tics.float().to(DEV)).mean() + sem_loss(label_vecs, label_vecs_hr) * 100
+    drop_vec = torch.ones(images_lr.shape[0]).float()
+    drop_vec[:int(images_lr.shape[0] // 4)] = 0.
+    label_vecs_final = label_vecs_final * drop_vec.to(DEV).view(-1, 1, 1, 1)
+    cascade_images = model(images_lr, label_vecs_final)
+    loss_img = image_crit(cascade_images, images_hr).mean() * 100
+    loss_im = loss_img + loss_recog_distill
+    optimizer_G.zero_grad()
+    loss_im.backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
+    l_c = float((fsup_sem_loss.detach() * weighted_tics.float().to(DEV)).mean())
+    print("module API + ctc:", loss_im.item(), t["loss"][0], l_c, t["loss_ctc"][0], float(gn), t["gnorm"][0])
+    assert abs(l_c - t["loss_ctc"][0]) < 1e-4 * abs(t["loss_ctc"][0])
+    assert abs(loss_im.item() - t["loss"][0]) < 3e-4 * t["loss"][0]
+    assert abs(float(gn) - t["gnorm"][0]) < 3e-3 * t["gnorm"][0]
