@@ -135,7 +135,22 @@ typedef struct {
    *     the data-gradient convolution that consumes dy (in = dz, in2 = y, in_scale = c0, in_shift = c2, in2_scale = c1): the caller's
    *     stream no longer runs tpgsr_bn_bwd_apply in front of it.  Whole-CU halo kernel only: ask tpgsr_conv_in2_scale_ok() first. --- */
   const float* in2_scale;    /* optional [Cin], 16-byte aligned; needs in2 and in_scale / in_shift, no in_act / in_b / in_ps */
+  /* --- split-K for the tile loop (round 6).  A few launches of the step have fewer 64 x 64 output tiles than the chip has CUs and a long
+   *     contraction -- the BiLSTM projections' data gradients (2048 -> 512 / 256 over 1248 pixels), InfoGen's transposed convolutions
+   *     (512 -> 128, 1 x 3 over a zero-dilated strip), the STN head's 3 x 3 convolutions on 96-pixel maps: 8 .. 160 workgroups walking
+   *     48 .. 72 K chunks, every chunk a full round trip.  With sk_splits = S > 1 the launch runs S workgroups per tile, each over
+   *     1 / S of the chunks, their raw accumulators go to sk_part [S][tiles][256 threads][16] (fp32, fragment order), and a second
+   *     launch of `tiles` workgroups adds them in split order and runs the ordinary epilogue (bias, activation, pixel-shuffle store,
+   *     BatchNorm statistics).  Deterministic; the sum is associated differently from the unsplit launch (last-bit differences).
+   *     Ask tpgsr_conv_splitk_plan() for S and the scratch size; sk_part must not be shared by launches that may run concurrently. --- */
+  float* sk_part;
+  int sk_splits;             /* 0 / 1: off */
+  int reserved2;
 } tpgsr_conv_args;
+/* split-K plan of tpgsr_conv_fwd(a) under the current switches: returns S (0 = do not split: the launch is another kernel's, or has
+ * enough tiles / too short a contraction) and the bytes sk_part needs.  On by default; TPGSR_XBF_SPLITK=0 / tpgsr_splitk_set_enabled(0): always 0 */
+int tpgsr_conv_splitk_plan(const tpgsr_conv_args* a, long long* bytes);
+void tpgsr_splitk_set_enabled(int on);
 /* 1 when tpgsr_conv_fwd(a) with a->in2_scale set will be taken (by the whole-CU halo kernel), else 0 */
 int tpgsr_conv_in2_scale_ok(const tpgsr_conv_args* a);
 /* 3 when tpgsr_conv_fwd(a) will run on the whole-CU halo kernel (which can leave one bn_partial row per 192 pixels), else 1 */

@@ -34,7 +34,8 @@ class ConvArgs(C.Structure):
                 ("bnb_y", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_act", ci), ("bnb_store_dz", ci),
                 ("fin_mode", ci), ("fin_accumulate", ci), ("fin_count", ll), ("fin_counter", vp), ("fin_gamma", vp), ("fin_beta", vp),
                 ("fin_bias", vp), ("fin_scale", vp), ("fin_shift", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_rm", vp), ("fin_rv", vp),
-                ("fin_momentum", cf), ("fin_eps", cf), ("bn_row_tiles", ci), ("reserved1", ci), ("in2_scale", vp)]
+                ("fin_momentum", cf), ("fin_eps", cf), ("bn_row_tiles", ci), ("reserved1", ci), ("in2_scale", vp),
+                ("sk_part", vp), ("sk_splits", ci), ("reserved2", ci)]
 
 
 class WgradArgs(C.Structure):
@@ -234,6 +235,8 @@ _SIGS = {
     "tpgsr_halo_capacity": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_conv_bn_row_tiles": (ci, [C.POINTER(ConvArgs)]),
     "tpgsr_conv_in2_scale_ok": (ci, [C.POINTER(ConvArgs)]),
+    "tpgsr_conv_splitk_plan": (ci, [C.POINTER(ConvArgs), C.POINTER(C.c_longlong)]),
+    "tpgsr_splitk_set_enabled": (None, [ci]),
     "tpgsr_halo_set_colmajor_min_bytes": (None, [C.c_longlong]),
     "tpgsr_halo_set_min_taps": (None, [ci]),
     "tpgsr_halo_set_ne9": (None, [ci]),

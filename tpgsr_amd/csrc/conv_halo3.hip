@@ -604,6 +604,9 @@ static int halo3_takes(const tpgsr_conv_args* a, long long M, int ld) {
   }
 }
 
+/* (launcher-internal, conv_xbf.hip's split-K plan) does this kernel take the launch? */
+extern "C" int tpgsr_conv_halo3_would_take(const tpgsr_conv_args* a, long long M, int ld) { return halo3_takes(a, M, ld) > 0 ? 1 : 0; }
+
 /* 1 when a launch with a scaled residual operand (tpgsr_conv_args.in2_scale) is this kernel's -- the only one whose loader has it */
 extern "C" int tpgsr_conv_in2_scale_ok(const tpgsr_conv_args* a) {
   if (!a || !(a->terms > 0 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) || a->fin_mode || !a->in2 || !a->in_scale || a->in_act || a->in_b) return 0;

@@ -140,8 +140,8 @@ extern "C" void tpgsr_panel_set_k192(int on) { g_panel_k192 = on ? 1 : 0; }
 // (K / 32, 32-column blocks per wave) pairs instantiated: 64 -> <= 192, 96 -> <= 192, 192 -> <= 64
 #define PANEL_LD_CASES(X) X(0) X(1) X(4) X(17)
 
-// returns 1 when launched, 0 when the shape is not this kernel's, < 0 on error
-extern "C" int tpgsr_conv_panel_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+// 32-column blocks per wave when the shape is this kernel's, else 0
+static int panel_takes(const tpgsr_conv_args* a, long long M, int ld) {
   const int T = a->terms;
   if (!g_panel_on || a->KH * a->KW != 1 || a->wt_bf_cin != 0 || a->stride_w > 1 || a->in_dil_w > 1 || a->in_ps || a->pad_h || a->pad_w ||
       a->OH != a->H || a->OW != a->W || M < g_panel_min_m || T < 1 || T > 3)
@@ -151,6 +151,23 @@ extern "C" int tpgsr_conv_panel_xbf_launch(const tpgsr_conv_args* a, long long M
   if ((nq8 == 2 || nq8 == 3) && nb32 <= 6) nbw = 3;
   else if (nq8 == 6 && nb32 <= 2 && g_panel_k192) nbw = 1;
   else return 0;
+  switch (ld) {
+#define PANEL_OK(B) case B:
+    PANEL_LD_CASES(PANEL_OK)
+#undef PANEL_OK
+    return nbw;
+    default: return 0;
+  }
+}
+/* (launcher-internal, conv_xbf.hip's split-K plan) */
+extern "C" int tpgsr_conv_panel_would_take(const tpgsr_conv_args* a, long long M, int ld) { return panel_takes(a, M, ld) > 0 ? 1 : 0; }
+
+// returns 1 when launched, 0 when the shape is not this kernel's, < 0 on error
+extern "C" int tpgsr_conv_panel_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+  const int T = a->terms;
+  const int nbw = panel_takes(a, M, ld);
+  if (nbw <= 0) return 0;
+  const int nq8 = a->kp >> 5;
   size_t lds = (size_t)T * 64 * (nq8 * 64 + 16);
   if (lds < (size_t)(4 * 64 * nbw + 4 * 1024) * 4) lds = (size_t)(4 * 64 * nbw + 4 * 1024) * 4;      // (epilogue scratch: statistics + staging)
   const void* fn = nullptr;

@@ -50,7 +50,9 @@ __device__ __forceinline__ int xa_off(int row, int slot) { return row * 64 + ((s
 
 // register budget: 1 x 1 wave tiles must keep three workgroups per CU resident (the trunk convolutions launch exactly
 // three per CU), i.e. <= 168 VGPRs + AGPRs
-template <int LD, int T, int WMB, int WNB>
+// SK = 1 (split-K, tpgsr_conv_args.sk_splits; 1 x 1 wave tiles only): the grid is sk_splits x tiles, workgroup (z, tile) walks chunks
+// [z cps, (z + 1) cps) and leaves its raw accumulators in sk_part; conv_splitk_reduce_kernel below adds them and runs the epilogue
+template <int LD, int T, int WMB, int WNB, int SK = 0>
 __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1)) void conv_fwd_xbf_kernel(tpgsr_conv_args a, int M, int K) {
   constexpr int BMT = 64 * WMB, BNT = 64 * WNB;
   constexpr int A_PLANE = BMT * 64;               // bytes per term
@@ -63,10 +65,15 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int nbn = (a.Cout + BNT - 1) / BNT;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = SK ? (int)gridDim.x / a.sk_splits : (int)gridDim.x;
+  const int skz = SK ? (int)blockIdx.x / ntile : 0;
+  const int tile = xcd_remap(SK ? (int)blockIdx.x - skz * ntile : (int)blockIdx.x, ntile);
   const int mblk = tile / nbn;
   const int m0 = mblk * BMT, n0 = (tile - mblk * nbn) * BNT;
-  const int nchunks = a.kp / KC;
+  const int nchunks_all = a.kp / KC;
+  const int cps = SK ? (nchunks_all + a.sk_splits - 1) / a.sk_splits : nchunks_all;     // chunks per split
+  const int c0 = skz * cps;                                                              // first chunk of this workgroup
+  const int nchunks = SK ? min(cps, nchunks_all - c0) : nchunks_all;
 
   // A staging: quad (tid & 7) = 16 of a row's 64 bytes -> half of slot (tid & 7) >> 1; pixels (tid >> 3) + 32 i
   const int aq = tid & 7;
@@ -101,6 +108,14 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
   // k' = ((ci / 32) * KH KW + tap) * 32 + ci % 32 (the order the halo kernel below consumes; chunk = one tap of one block)
   const bool kperm = a.wt_bf_cin > 0;
   KPos kp_ = kperm ? KPos{0, 0, aq * 4} : kpos_init(a, aq);
+  if (SK && c0 > 0) {       // start at chunk c0
+    if (kperm) {
+      const int taps = a.KH * a.KW, cb = c0 / taps, tp = c0 - cb * taps;
+      kp_ = KPos{tp / a.KW, tp - (tp / a.KW) * a.KW, cb * 32 + aq * 4};
+    } else {
+      kpos_advance(a, kp_, c0 * KC);
+    }
+  }
   const KStep kstep = kstep_init(a, KC);
   auto load_chunk = [&]() {          // past the last chunk: kh >= KH, every load is the hardware-zero-filled out-of-range one
 #pragma unroll
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
 #pragma unroll
         for (int t = 0; t < T; ++t)
           bw[S][kb][j][t] = __builtin_amdgcn_raw_buffer_load_b128(
-              rs_w, woff[j] == OOB_OFF ? (int)OOB_OFF : (int)(woff[j] + t * plane_w + (unsigned)(ch * 2 + kb) * 1024u), 0, 0);
+              rs_w, woff[j] == OOB_OFF ? (int)OOB_OFF : (int)(woff[j] + t * plane_w + (unsigned)((ch + c0) * 2 + kb) * 1024u), 0, 0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -242,9 +257,46 @@ __global__ __launch_bounds__(256, (WMB * WNB == 1 ? 3 : WMB * WNB == 2 ? 2 : 1))
         for (int r = 0; r < 16; ++r) acc[i][j][r] += accl[TWO ? i : 0][TWO ? j : 0][r];
   }
 
+  if constexpr (SK != 0) {     // raw accumulators, fragment order: [split][tile][thread][16]
+    float4* dst = reinterpret_cast<float4*>(a.sk_part) + ((size_t)(skz * ntile + tile) * 256 + tid) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]);
+    return;
+  }
   __syncthreads();      // every wave is through with the A image: it becomes the epilogue's scratch
   xbf_epilogue<WMB, WNB>(a, acc, M, m0, n0, mblk, wm, wn, lane, tid, reinterpret_cast<float*>(xsm),
                          reinterpret_cast<float*>(xsm) + 4 * 64 * WNB + wave * 1024);
+}
+
+// second launch of a split-K convolution: workgroup = output tile; the S partial accumulators of every thread are added in split order
+// (deterministic) and handed to the tile loop's own epilogue
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(tpgsr_conv_args a, int M) {
+  constexpr int EPI = (4 * 64 + 4 * 1024) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char xsm[EPI];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int nbn = (a.Cout + 63) / 64;
+  const int ntile = (int)gridDim.x, tile = (int)blockIdx.x;
+  const int mblk = tile / nbn;
+  const int m0 = mblk * 64, n0 = (tile - mblk * nbn) * 64;
+  floatx16 acc[1][1];
+  const float4* src = reinterpret_cast<const float4*>(a.sk_part) + ((size_t)tile * 256 + tid) * 4;
+  float4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = src[q];
+  for (int z = 1; z < a.sk_splits; ++z) {
+    const float4* sz = src + (size_t)z * ntile * 256 * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 w = sz[q];
+      v[q].x += w.x; v[q].y += w.y; v[q].z += w.z; v[q].w += w.w;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc[0][0][4 * q] = v[q].x; acc[0][0][4 * q + 1] = v[q].y; acc[0][0][4 * q + 2] = v[q].z; acc[0][0][4 * q + 3] = v[q].w;
+  }
+  xbf_epilogue<1, 1>(a, acc, M, m0, n0, mblk, wm, wn, lane, tid, reinterpret_cast<float*>(xsm), reinterpret_cast<float*>(xsm) + 4 * 64 + wave * 1024);
 }
 
 // loader variants instantiated for the bf16 path (the same set as the fp32 kernel)
@@ -606,7 +658,8 @@ extern "C" void tpgsr_halo_set_min_taps(int v) { g_halo_min_taps = v < 1 ? 1 : v
 #define XBF_HALO_LD_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(7)
 
 // returns 1 when launched, 0 when the shape is not one of the halo kernel's, < 0 on error
-static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+// does the two-workgroup halo kernel take this launch?  0: no; else the halo capacity (`small`: the 7-entries-per-thread variant)
+static int halo_takes(const tpgsr_conv_args* a, int ld, bool* small_out) {
   static const bool on = [] { const char* e = getenv("TPGSR_XBF_HALO"); return !(e && e[0] == '0'); }();
   const int T = a->terms;
   if (!on || a->KH * a->KW < g_halo_min_taps || (a->wt_bf_cin != a->Cin && !(a->KH * a->KW == 1 && a->wt_bf_cin == 0)) || (a->Cin & 31) || a->stride_w > 1 || a->in_dil_w > 1 ||
@@ -623,6 +676,23 @@ static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, h
   // loop (128 -> 64 data gradient at batch 48, profiles/r03j_kernel_stats_c3_x2.md) -- off unless TPGSR_XBF_HALO_NE9=1
   static const bool ne9 = [] { const char* e = getenv("TPGSR_XBF_HALO_NE9"); return e && e[0] == '1'; }();
   if (!small && !ne9 && !g_halo_force_ne9) return 0;
+  switch (ld) {
+#define XBF_HALO_OK(B) case B:
+    XBF_HALO_LD_CASES(XBF_HALO_OK)
+#undef XBF_HALO_OK
+    case 8: break;
+    default: return 0;
+  }
+  if (small_out) *small_out = small;
+  return Lcap;
+}
+
+static int conv_halo_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st) {
+  const int T = a->terms;
+  bool small = false;
+  const int Lcap = halo_takes(a, ld, &small);
+  if (Lcap <= 0) return 0;
+  const size_t lds = (size_t)2 * T * Lcap * 64 + 2048;      // two halo buffers + two 1 KB statistics scratch areas
   const void* fn = nullptr;
 #define XBF_HALO_CASE(B)                                                                                                      \
   case B:                                                                                                                     \
@@ -711,10 +781,78 @@ static int xbf_fwd_tile(long long M, int Cout) {
 extern "C" int tpgsr_conv_panel_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st);
 extern "C" int tpgsr_conv_halo3_xbf_launch(const tpgsr_conv_args* a, long long M, int ld, hipStream_t st);   // conv_halo3.hip
 
+// ---- split-K (tpgsr_conv_args.sk_splits) ----
+// on by default (C3 x2 interleaved on one box: 5.391 / 5.380 -> 5.363 / 5.340 ms per step, family replay 4.29 -> 4.15 ms; the STN head's
+// 96-pixel convolutions 32 -> 13 us, InfoGen's 512 -> 128 47 -> 31, the BiLSTM projections' data gradients 34 / 30 -> 29 / 20);
+// TPGSR_XBF_SPLITK=0 / tpgsr_splitk_set_enabled(0): every launch unsplit
+static int g_sk_on = [] { const char* e = getenv("TPGSR_XBF_SPLITK"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" void tpgsr_splitk_set_enabled(int on) { g_sk_on = on ? 1 : 0; }
+extern "C" int tpgsr_conv_halo3_would_take(const tpgsr_conv_args* a, long long M, int ld);    // conv_halo3.hip
+extern "C" int tpgsr_conv_panel_would_take(const tpgsr_conv_args* a, long long M, int ld);    // conv_panel.hip
+
+// launches with fewer tiles than ~2/3 of the CUs and >= 24 K chunks: S workgroups per tile so that ~640 are resident, >= 6 chunks each
+static int splitk_choice(long long M, int Cout, int kp) {
+  static const int target = [] { const char* e = getenv("TPGSR_XBF_SPLITK_TARGET"); return e ? atoi(e) : 640; }();      // resident workgroups aimed at
+  static const int min_cps = [] { const char* e = getenv("TPGSR_XBF_SPLITK_MIN_CHUNKS"); return e ? atoi(e) : 6; }();   // chunks per split at least
+  static const int max_tiles = [] { const char* e = getenv("TPGSR_XBF_SPLITK_MAX_TILES"); return e ? atoi(e) : 256; }();
+  const long long ntiles = cdiv(M, 64) * cdiv(Cout, 64);
+  const int nchunks = kp / KC;
+  if (ntiles > max_tiles || nchunks < 24) return 0;
+  int S = (int)(target / ntiles);
+  S = S < 2 ? 2 : S > 8 ? 8 : S;
+  int cps = (nchunks + S - 1) / S;
+  if (cps < min_cps) cps = min_cps;
+  S = (nchunks + cps - 1) / cps;          // no empty split
+  return S > 1 ? S : 0;
+}
+
+extern "C" int tpgsr_conv_splitk_plan(const tpgsr_conv_args* a, long long* bytes) {
+  if (bytes) *bytes = 0;
+  if (!a || !g_sk_on || !(a->terms > 0 && a->terms <= 3 && a->wt_bf && (a->Cin & 3) == 0 && (a->wt_coff & 31) == 0) || a->bn_row_tiles > 1 || a->in2_scale)
+    return 0;
+  const int ld = (a->in_scale ? 1 : 0) | (a->in_act ? 2 : 0) | (a->in2 ? 4 : 0) | (a->in_ps ? 8 : 0) | (a->in_b ? 16 : 0);
+  switch (ld) {
+#define XBF_SK_OK(B) case B:
+    XBF_LD_CASES(XBF_SK_OK)
+#undef XBF_SK_OK
+    break;
+    default: return 0;
+  }
+  const long long M = (long long)a->N * a->OH * a->OW;
+  // (a launch the two-workgroup halo kernel would take is split all the same -- conv6, 2 x 2 over 1248 pixels: 36.7 -> 31.3 us in x3,
+  //  28.9 -> 23.5 in x2 -- unless TPGSR_XBF_SPLITK_OVER_HALO=0; an explicit sk_splits wins in the launcher)
+  static const int over_halo = [] { const char* e = getenv("TPGSR_XBF_SPLITK_OVER_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (tpgsr_conv_halo3_would_take(a, M, ld) || (!over_halo && halo_takes(a, ld, nullptr) > 0) || tpgsr_conv_panel_would_take(a, M, ld)) return 0;
+  const int S = splitk_choice(M, a->Cout, a->kp);
+  if (S > 1 && bytes) *bytes = (long long)S * cdiv(M, 64) * cdiv(a->Cout, 64) * 256 * 16 * 4;
+  return S;
+}
+
 extern "C" int tpgsr_conv_fwd_xbf_launch(const tpgsr_conv_args* a, long long M, int K, int ld, hipStream_t st) {
   const int T = a->terms;
   TPGSR_CHECK_ARG(a->wt_bf_cin == 0 || (a->wt_bf_cin == a->Cin && (a->Cin & 31) == 0),
                   "tpgsr_conv_fwd: weights were split in channel-block order for Cin %d, the convolution has Cin %d", a->wt_bf_cin, a->Cin);
+  if (a->sk_splits > 1) {       // split-K: S workgroups per tile + the reduce / epilogue launch (the caller asked tpgsr_conv_splitk_plan)
+    TPGSR_CHECK_ARG(a->sk_part && a->sk_splits <= 64 && a->sk_splits <= a->kp / KC && ((uintptr_t)a->sk_part & 15) == 0,
+                    "tpgsr_conv_fwd: sk_splits %d needs sk_part (16-byte aligned) and at most one split per K chunk (%d)", a->sk_splits, a->kp / KC);
+    const unsigned ntile = (unsigned)(cdiv(M, 64) * cdiv(a->Cout, 64));
+    dim3 gsk(ntile * (unsigned)a->sk_splits);
+#define XBF_SK_CASE(B)                                                                                                   \
+  case B:                                                                                                                \
+    if (T == 1) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 1, 1, 1, 1>), gsk, dim3(256), 0, st, *a, (int)M, K);          \
+    else if (T == 2) hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 2, 1, 1, 1>), gsk, dim3(256), 0, st, *a, (int)M, K);     \
+    else hipLaunchKernelGGL((conv_fwd_xbf_kernel<B, 3, 1, 1, 1>), gsk, dim3(256), 0, st, *a, (int)M, K);                 \
+    break;
+    switch (ld) {
+      XBF_LD_CASES(XBF_SK_CASE)
+      default:
+        tpgsr_set_error("tpgsr_conv_fwd: unsupported loader combination %d", ld);
+        return TPGSR_ERR_ARG;
+    }
+#undef XBF_SK_CASE
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ntile), dim3(256), 0, st, *a, (int)M);
+    TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA, split-K)");
+  }
   const int h3 = tpgsr_conv_halo3_xbf_launch(a, M, ld, st);      // whole-CU kernel: three tiles per workgroup, one round of the chip
   if (h3 < 0) return h3;
   if (h3 > 0) TPGSR_LAUNCH_CHECK("tpgsr_conv_fwd(bf16 MFMA, whole-CU halo)");

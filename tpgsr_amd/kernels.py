@@ -731,6 +731,19 @@ def bnb_fusable(cin: int) -> bool:
 
 
 def conv_fwd(args: ConvArgs):
+    """tpgsr_conv_fwd.  The launch is first offered to the split-K planner (tpgsr_conv_splitk_plan: the few
+    launches with fewer output tiles than CUs and a long contraction -- BiLSTM projections' data gradients, InfoGen's transposed
+    convolutions, the STN head's 3 x 3 convolutions on 96 pixels); a taker gets a scratch buffer of its OWN (plans of different engines
+    run on different physical streams at the same time: nothing may be shared), kept alive by the argument block the plan holds."""
+    if not DRYRUN and args.terms and not args.sk_splits:
+        # (eager launches too -- the operator-by-operator path gives the recorded plan's bits; its buffer goes back to torch's
+        #  stream-ordered allocator right after the call, which is safe on the stream the launch was queued on)
+        nb = C.c_longlong(0)
+        S = _lib.load().tpgsr_conv_splitk_plan(C.byref(args), C.byref(nb))
+        if S > 1:
+            buf = torch.empty(nb.value // 4, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            args._sk_buf = buf
+            args.sk_part, args.sk_splits = buf.data_ptr(), S
     _launch("tpgsr_conv_fwd", C.byref(args))
 
 
