@@ -795,9 +795,10 @@ static int splitk_choice(long long M, int Cout, int kp) {
   static const int target = [] { const char* e = getenv("TPGSR_XBF_SPLITK_TARGET"); return e ? atoi(e) : 640; }();      // resident workgroups aimed at
   static const int min_cps = [] { const char* e = getenv("TPGSR_XBF_SPLITK_MIN_CHUNKS"); return e ? atoi(e) : 6; }();   // chunks per split at least
   static const int max_tiles = [] { const char* e = getenv("TPGSR_XBF_SPLITK_MAX_TILES"); return e ? atoi(e) : 256; }();
+  static const int min_k = [] { const char* e = getenv("TPGSR_XBF_SPLITK_MIN_K"); return e ? atoi(e) : 24; }();          // K chunks of the launch at least
   const long long ntiles = cdiv(M, 64) * cdiv(Cout, 64);
   const int nchunks = kp / KC;
-  if (ntiles > max_tiles || nchunks < 24) return 0;
+  if (ntiles > max_tiles || nchunks < min_k) return 0;
   int S = (int)(target / ntiles);
   S = S < 2 ? 2 : S > 8 ? 8 : S;
   int cps = (nchunks + S - 1) / S;
