@@ -1,5 +1,5 @@
 # round 6: the split-K planner's knobs against the per-shape table (tools/lab/shape_table.py); usage on the box: bash tools/lab/sk_sweep.sh
-for cfg in "640 6 256 24" "640 4 256 24" "640 4 256 16" "640 4 256 12" "640 3 256 12" "1024 4 384 12"; do
+for cfg in "640 6 256 24" "640 6 384 24" "640 6 512 24" "1024 6 512 24"; do
   set -- $cfg
   echo "== target $1 min_chunks $2 max_tiles $3 min_k $4"
   TPGSR_XBF_SPLITK_TARGET=$1 TPGSR_XBF_SPLITK_MIN_CHUNKS=$2 TPGSR_XBF_SPLITK_MAX_TILES=$3 TPGSR_XBF_SPLITK_MIN_K=$4 timeout 300 python tools/lab/shape_table.py c3 2>/dev/null | python -c "
