@@ -281,15 +281,32 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(tpgsr_conv_args
   const int m0 = mblk * 64, n0 = (tile - mblk * nbn) * 64;
   floatx16 acc[1][1];
   const float4* src = reinterpret_cast<const float4*>(a.sk_part) + ((size_t)tile * 256 + tid) * 4;
+  // all S x 4 loads in flight before the first addition (the planner's S <= 8; a loop over z waited for a round trip per split:
+  // 8 us for 64 KB); added in split order as before
+  float4 w[8][4];
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (z < a.sk_splits) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[z][q] = src[(size_t)z * ntile * 256 * 4 + q];
+    }
   float4 v[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = src[q];
-  for (int z = 1; z < a.sk_splits; ++z) {
+  for (int q = 0; q < 4; ++q) v[q] = w[0][q];
+#pragma unroll
+  for (int z = 1; z < 8; ++z)
+    if (z < a.sk_splits) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q].x += w[z][q].x; v[q].y += w[z][q].y; v[q].z += w[z][q].z; v[q].w += w[z][q].w;
+      }
+    }
+  for (int z = 8; z < a.sk_splits; ++z) {          // (a caller's own S > 8)
     const float4* sz = src + (size_t)z * ntile * 256 * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 w = sz[q];
-      v[q].x += w.x; v[q].y += w.y; v[q].z += w.z; v[q].w += w.w;
+      const float4 u = sz[q];
+      v[q].x += u.x; v[q].y += u.y; v[q].z += u.z; v[q].w += u.w;
     }
   }
 #pragma unroll
