@@ -726,6 +726,9 @@ int tpgsr_clip_coef(const float* partial, int nblk, float max_norm, float* coef,
 int tpgsr_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* gscale, float lr,
                     float beta1, float beta2, float eps, const int* step_dev, void* stream);
 int tpgsr_step_inc(int* step_dev, void* stream);
+/* tpgsr_clip_coef (partial == NULL: skipped) and tpgsr_step_inc of up to eight counters in ONE single-wave launch -- the optimiser's launches
+ * sit on the step's exposed tail.  `steps`: a HOST array of nsteps distinct device pointers (copied into the launch's arguments). */
+int tpgsr_clip_coef_steps(const float* partial, int nblk, float max_norm, float* coef, float* norm_out, int* const* steps, int nsteps, void* stream);
 int tpgsr_scale_(float* x, long long n, const float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

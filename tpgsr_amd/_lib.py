@@ -201,6 +201,7 @@ _SIGS = {
     "tpgsr_clip_coef": (ci, [vp, ci, cf, vp, vp, vp]),
     "tpgsr_adam_step": (ci, [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]),
     "tpgsr_step_inc": (ci, [vp, vp]),
+    "tpgsr_clip_coef_steps": (ci, [vp, ci, cf, vp, vp, vp, ci, vp]),
     "tpgsr_scale_": (ci, [vp, ll, vp, vp]),
     "tpgsr_im2col3x3_c1": (ci, [vp, ci, ci, ci, vp, vp]),
     "tpgsr_col2im3x3_c1": (ci, [vp, ci, ci, ci, vp, vp]),

@@ -362,6 +362,38 @@ extern "C" int tpgsr_adam_step(float* p, const float* g, float* m, float* v, lon
   TPGSR_LAUNCH_CHECK("tpgsr_adam_step");
 }
 
+// clip coefficient of ONE module + the step counters of up to eight modules in one single-wave launch: the optimiser runs on the step's
+// critical tail, after the last gradient, where every launch boundary is exposed (round 6: sumsq, THIS, Adam, Adam instead of
+// sumsq, clip_coef, step_inc, Adam, step_inc, Adam)
+struct StepPtrs {
+  int* s[8];
+};
+__global__ void clip_coef_steps_kernel(const float* __restrict__ partial, int nblk, float max_norm, float* coef, float* norm_out, StepPtrs sp) {
+  if (partial) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[b];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) {
+      float total = (float)sqrt(s);
+      float c = max_norm / (total + 1e-6f);
+      coef[0] = c < 1.f ? c : 1.f;
+      if (norm_out) norm_out[0] = total;
+    }
+  }
+  if (threadIdx.x < 8 && sp.s[threadIdx.x]) sp.s[threadIdx.x][0] += 1;
+}
+extern "C" int tpgsr_clip_coef_steps(const float* partial, int nblk, float max_norm, float* coef, float* norm_out, int* const* steps, int nsteps,
+                                     void* stream) {
+  TPGSR_CHECK_ARG((partial == nullptr || (coef && nblk > 0)) && nsteps >= 0 && nsteps <= 8 && (nsteps == 0 || steps),
+                  "tpgsr_clip_coef_steps: needs coef with partial, and at most eight step counters (HOST array of device pointers)");
+  StepPtrs sp;
+  for (int i = 0; i < 8; ++i) sp.s[i] = i < nsteps ? steps[i] : nullptr;
+  for (int i = 0; i < nsteps; ++i)
+    for (int j = 0; j < i; ++j) TPGSR_CHECK_ARG(sp.s[i] != sp.s[j] && sp.s[i], "tpgsr_clip_coef_steps: step counters must be distinct and non-null");
+  hipLaunchKernelGGL(clip_coef_steps_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nblk, max_norm, coef, norm_out, sp);
+  TPGSR_LAUNCH_CHECK("tpgsr_clip_coef_steps");
+}
+
 __global__ void step_inc_kernel(int* s) { s[0] += 1; }
 extern "C" int tpgsr_step_inc(int* step_dev, void* stream) {
   TPGSR_CHECK_ARG(step_dev, "tpgsr_step_inc: null pointer");

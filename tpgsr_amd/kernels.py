@@ -1354,6 +1354,12 @@ def step_inc(step_dev):
     _launch("tpgsr_step_inc", _p(step_dev))
 
 
+def clip_coef_steps(partial, nblk, max_norm, coef, norm_out, step_devs):
+    """clip_coef (partial None: skipped) + step_inc of every counter in `step_devs` (<= 8 device tensors) in one launch"""
+    arr = (C.c_void_p * max(1, len(step_devs)))(*[t.data_ptr() for t in step_devs])
+    _launch("tpgsr_clip_coef_steps", _p(partial), nblk, max_norm, _p(coef), _p(norm_out), C.cast(arr, C.c_void_p), len(step_devs))
+
+
 def scale_(x, n, coef):
     _launch("tpgsr_scale_", _p(x), n, _p(coef))
 

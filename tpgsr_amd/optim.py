@@ -53,14 +53,28 @@ class FusedAdam:
             K.zero(a.grad, a.numel)
 
     def step(self):
-        for m in self.modules:
-            a, st = self._st(m)
+        # These launches run on the step's exposed tail (behind the last gradient): as few as possible.  ALL modules' step counters go up
+        # in ONE launch -- the first clipped module's clip-coefficient launch when it comes first, else a launch of their own -- :
+        # C3: sumsq, clip + counters, Adam, Adam (round 5: sumsq, clip, counter, Adam, counter, Adam)
+        sts = [self._st(m) for m in self.modules]
+        counters = [st["step"] for _, st in sts]
+        fuse = len(counters) <= 8
+        bumped = False
+        for m, (a, st) in zip(self.modules, sts):
             gscale = None
             if id(m) in self.clip:
                 K.sumsq_partial(a.grad, a.numel, st["part"], _NBLK)
-                K.clip_coef(st["part"], _NBLK, self.max_norm, st["coef"], st["norm"])
+                if fuse and not bumped:
+                    K.clip_coef_steps(st["part"], _NBLK, self.max_norm, st["coef"], st["norm"], counters)
+                    bumped = True
+                else:
+                    K.clip_coef(st["part"], _NBLK, self.max_norm, st["coef"], st["norm"])
                 gscale = st["coef"]
-            K.step_inc(st["step"])
+            elif fuse and not bumped:
+                K.clip_coef_steps(None, 0, 0.0, None, None, counters)
+                bumped = True
+            if not fuse:
+                K.step_inc(st["step"])
             K.adam_step(a.flat, a.grad, st["m"], st["v"], a.numel, gscale, self.lr, self.betas[0], self.betas[1], self.eps,
                         st["step"])
             m._engine()._kernel_writes += 1       # the arena was rewritten through a raw pointer: eval-mode plans must re-pack
