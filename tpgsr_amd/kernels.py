@@ -649,6 +649,7 @@ def make_conv_args(g: ConvGeom, inp, wt=None, out=None, *, bias=None, in2=None, 
             tw = getattr(wt, "_tpgsr_twin", None)
             if tw is not None:
                 a.terms, a.kp, a.wt_bf, a.wt_bf_cin = CONV_TERMS, tw[1], tw[0].data_ptr(), tw[2]
+                a._dev = tw[0].device               # (where a split-K scratch buffer of this launch has to live: conv_fwd)
                 assert tw[2] in (0, g.Cin), f"operand split for Cin {tw[2]}, used by a convolution over {g.Cin} channels"
                 if _REC is not None:
                     _REC.keep.append(tw[0])
@@ -741,7 +742,7 @@ def conv_fwd(args: ConvArgs):
         nb = C.c_longlong(0)
         S = _lib.load().tpgsr_conv_splitk_plan(C.byref(args), C.byref(nb))
         if S > 1:
-            buf = torch.empty(nb.value // 4, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            buf = torch.empty(nb.value // 4, dtype=torch.float32, device=getattr(args, "_dev", None) or torch.device("cuda", torch.cuda.current_device()))
             args._sk_buf = buf
             args.sk_part, args.sk_splits = buf.data_ptr(), S
     _launch("tpgsr_conv_fwd", C.byref(args))
